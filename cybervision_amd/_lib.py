@@ -1,0 +1,79 @@
+"""ctypes binding of libcvhip.so — one Python function per C-ABI entry point (include/cvhip.h).
+
+Fails loudly when the extension has not been built: there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libcvhip.so"
+_lib = None
+
+
+class CvhipError(RuntimeError):
+    """Non-zero return of a cvhip_* call; mirrors GpuError::Internal (gpu/vulkan.rs:1204-1272)."""
+
+    def __init__(self, code: int, where: str, msg: str):
+        super().__init__(f"{where}: {msg} (code {code})")
+        self.code = code
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float)
+_vp = C.c_void_p
+_u32 = C.c_uint32
+
+# name -> (restype, argtypes); kept in sync with include/cvhip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "cvhip_last_error": (C.c_char_p, []),
+    "cvhip_abi_version": (_u32, []),
+    "cvhip_device_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "cvhip_device_destroy": (None, [_vp]),
+    "cvhip_device_name": (C.c_char_p, [_vp]),
+    "cvhip_device_synchronize": (C.c_int, [_vp]),
+    "cvhip_ctx_create": (C.c_int, [_vp, _u32, _u32, _u32, _u32, C.c_int, C.POINTER(C.c_double), C.POINTER(_vp)]),
+    "cvhip_ctx_destroy": (None, [_vp]),
+    "cvhip_correlate_images": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, C.c_float, C.c_int, C.c_int,
+                                         PROGRESS_FN, _vp]),
+    "cvhip_cross_check_filter": (C.c_int, [_vp, C.c_float, C.c_int]),
+    "cvhip_correlate_level": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, C.c_float, C.c_int, PROGRESS_FN,
+                                        _vp]),
+    "cvhip_complete": (C.c_int, [_vp, _vp, _vp]),
+    "cvhip_complete_dir": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "cvhip_ctx_set_row_shard": (C.c_int, [_vp, _u32, _u32]),
+    "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u32),
+                                       C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "cvhip_ctx_set_profiling": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "cvhip_ctx_get_profile": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                        C.c_int]),
+    "cvhip_orb_extract": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "cvhip_match_points": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "cvhip_ransac_score": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp, _vp]),
+}
+
+
+def lib():
+    """Load libcvhip.so (once).  Raises if it has not been built — no fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -m cybervision_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, where: str):
+    if rc != 0:
+        msg = lib().cvhip_last_error()
+        raise CvhipError(rc, where, msg.decode("utf-8", "replace") if msg else "")
+
+
+NULL_PROGRESS = PROGRESS_FN()

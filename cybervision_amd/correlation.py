@@ -1,0 +1,199 @@
+"""Host-side front-end of the dense-correlation C ABI (include/cvhip.h).
+
+Mirrors how the reference drives its GPU backend: ``create_gpu_context`` (correlation/mod.rs:145),
+``PointCorrelations::{new, correlate_images, complete, optimal_scale_steps}``
+(correlation/mod.rs:150-245, 542-550) and the level loop of ``correlate_dense``
+(reconstruction.rs:554-588).  Everything here forwards to libcvhip.so — no compute in Python.
+
+Images may be numpy uint8 arrays (host) or anything exposing ``data_ptr()`` (torch CUDA uint8
+tensors); the library detects host vs device pointers itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from enum import IntEnum
+
+import numpy as np
+
+from . import _lib
+from .synth import optimal_scale_steps  # noqa: F401  (PointCorrelations::optimal_scale_steps)
+
+
+class ProjectionMode(IntEnum):  # correlation/mod.rs:43-47
+    Affine = 0
+    Perspective = 1
+
+
+class HardwareMode(IntEnum):  # correlation/mod.rs:49-54
+    Gpu = 0
+    GpuLowPower = 1
+    Cpu = 2
+
+
+class CorrelationDirection(IntEnum):  # correlation/mod.rs:77-81
+    Forward = 0
+    Reverse = 1
+
+
+def _ptr_shape(img):
+    """(pointer, width, height, keepalive) of a 2-D uint8 image on host or device."""
+    if hasattr(img, "data_ptr"):  # torch tensor
+        assert img.dim() == 2 and img.element_size() == 1 and img.is_contiguous()
+        return C.c_void_p(img.data_ptr()), int(img.shape[1]), int(img.shape[0]), img
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    assert a.ndim == 2
+    return C.c_void_p(a.ctypes.data), int(a.shape[1]), int(a.shape[0]), a
+
+
+class GpuDevice:
+    """create_gpu_context(HardwareMode) -> GpuDevice (correlation/mod.rs:145-147)."""
+
+    def __init__(self, hardware_mode: HardwareMode = HardwareMode.Gpu, ordinal: int = -1):
+        if hardware_mode == HardwareMode.Cpu:
+            raise ValueError("HardwareMode.Cpu has no GPU device (the CPU path is the reference's own)")
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().cvhip_device_create(int(hardware_mode == HardwareMode.GpuLowPower), ordinal,
+                                                  C.byref(self._h)), "cvhip_device_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def name(self) -> str:
+        return _lib.lib().cvhip_device_name(self._h).decode()
+
+    def synchronize(self):
+        _lib.check(_lib.lib().cvhip_device_synchronize(self._h), "cvhip_device_synchronize")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cvhip_device_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_gpu_context(hardware_mode: HardwareMode = HardwareMode.Gpu, ordinal: int = -1) -> GpuDevice:
+    return GpuDevice(hardware_mode, ordinal)
+
+
+class PointCorrelations:
+    """PointCorrelations with a GPU context (correlation/mod.rs:63-245, GPU branch)."""
+
+    def __init__(self, device: GpuDevice, img1_dimensions, img2_dimensions, fundamental_matrix,
+                 projection_mode: ProjectionMode = ProjectionMode.Affine):
+        self.device = device
+        self.w1, self.h1 = int(img1_dimensions[0]), int(img1_dimensions[1])
+        self.w2, self.h2 = int(img2_dimensions[0]), int(img2_dimensions[1])
+        F = np.ascontiguousarray(np.asarray(fundamental_matrix, dtype=np.float64).reshape(9))
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().cvhip_ctx_create(device.handle, self.w1, self.h1, self.w2, self.h2,
+                                               int(projection_mode), F.ctypes.data_as(C.POINTER(C.c_double)),
+                                               C.byref(self._h)), "cvhip_ctx_create")
+        self.first_pass = True
+        self.selected_hardware = f"GPU {device.name()}"
+        self.correlated_points = None
+
+    def get_selected_hardware(self) -> str:
+        return self.selected_hardware
+
+    # -- the four GpuContext calls (correlation/gpu/mod.rs:172-362) ---------------------------
+    def correlate_images_step(self, img1, img2, scale: float, direction: CorrelationDirection,
+                              progress=None):
+        p1, w1, h1, k1 = _ptr_shape(img1)
+        p2, w2, h2, k2 = _ptr_shape(img2)
+        cb = _lib.PROGRESS_FN(lambda _u, v: progress(v)) if progress else _lib.NULL_PROGRESS
+        _lib.check(_lib.lib().cvhip_correlate_images(self._h, p1, w1, h1, p2, w2, h2, scale, int(self.first_pass),
+                                                     int(direction), cb, None), "cvhip_correlate_images")
+        del k1, k2
+
+    def cross_check_filter(self, scale: float, direction: CorrelationDirection):
+        _lib.check(_lib.lib().cvhip_cross_check_filter(self._h, scale, int(direction)), "cvhip_cross_check_filter")
+
+    def correlate_images(self, img1, img2, scale: float, progress=None, fused: bool = True):
+        """PointCorrelations::correlate_images (mod.rs:217-245).  fused=True issues the single
+        cvhip_correlate_level call, fused=False the reference's four backend calls."""
+        if fused:
+            p1, w1, h1, k1 = _ptr_shape(img1)
+            p2, w2, h2, k2 = _ptr_shape(img2)
+            cb = _lib.PROGRESS_FN(lambda _u, v: progress(v)) if progress else _lib.NULL_PROGRESS
+            _lib.check(_lib.lib().cvhip_correlate_level(self._h, p1, w1, h1, p2, w2, h2, scale,
+                                                        int(self.first_pass), cb, None), "cvhip_correlate_level")
+            del k1, k2
+        else:
+            self.correlate_images_step(img1, img2, scale, CorrelationDirection.Forward, progress)
+            self.correlate_images_step(img2, img1, scale, CorrelationDirection.Reverse, progress)
+            self.cross_check_filter(scale, CorrelationDirection.Forward)
+            self.cross_check_filter(scale, CorrelationDirection.Reverse)
+        self.first_pass = False
+
+    def complete(self, direction: CorrelationDirection = CorrelationDirection.Forward, out_xy=None, out_corr=None):
+        """complete() (mod.rs:208-215): returns (xy[h, w, 2] int32 with -1 = None, corr[h, w] f32)."""
+        w, h = (self.w1, self.h1) if direction == CorrelationDirection.Forward else (self.w2, self.h2)
+        if out_xy is None:
+            out_xy = np.empty((h, w, 2), dtype=np.int32)
+            out_corr = np.empty((h, w), dtype=np.float32)
+        pxy = C.c_void_p(out_xy.data_ptr() if hasattr(out_xy, "data_ptr") else out_xy.ctypes.data)
+        pc = None
+        if out_corr is not None:
+            pc = C.c_void_p(out_corr.data_ptr() if hasattr(out_corr, "data_ptr") else out_corr.ctypes.data)
+        _lib.check(_lib.lib().cvhip_complete_dir(self._h, int(direction), pxy, pc), "cvhip_complete_dir")
+        if direction == CorrelationDirection.Forward:
+            self.correlated_points = (out_xy, out_corr)
+        return out_xy, out_corr
+
+    # -- measurement / sharding hooks -----------------------------------------------------------
+    def set_profiling(self, time_kernels: bool, count_candidates: bool):
+        _lib.check(_lib.lib().cvhip_ctx_set_profiling(self._h, int(time_kernels), int(count_candidates)),
+                   "cvhip_ctx_set_profiling")
+
+    def get_profile(self, reset: bool = True):
+        n, ms, cand = C.c_uint32(0), C.c_double(0.0), C.c_uint64(0)
+        _lib.check(_lib.lib().cvhip_ctx_get_profile(self._h, C.byref(n), C.byref(ms), C.byref(cand), int(reset)),
+                   "cvhip_ctx_get_profile")
+        return {"launches": n.value, "search_ms": ms.value, "candidates": cand.value}
+
+    def set_row_shard(self, num: int, den: int):
+        _lib.check(_lib.lib().cvhip_ctx_set_row_shard(self._h, num, den), "cvhip_ctx_set_row_shard")
+
+    def level_grid(self, direction: CorrelationDirection):
+        xy, corr = C.c_void_p(), C.c_void_p()
+        lw, lh, r0, r1 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(_lib.lib().cvhip_ctx_level_grid(self._h, int(direction), C.byref(xy), C.byref(corr), C.byref(lw),
+                                                   C.byref(lh), C.byref(r0), C.byref(r1)), "cvhip_ctx_level_grid")
+        return {"xy": xy.value, "corr": corr.value, "lw": lw.value, "lh": lh.value, "row0": r0.value,
+                "row1": r1.value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cvhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def correlate_dense(device: GpuDevice, pyr1, pyr2, fundamental_matrix,
+                    projection_mode: ProjectionMode = ProjectionMode.Affine, fused: bool = True):
+    """The dense stage of ImageReconstruction::correlate_dense (reconstruction.rs:554-588) over
+    prebuilt pyramids: pyr[k] is the 1/2^k image, levels run coarse to fine, then complete()."""
+    steps = len(pyr1) - 1
+
+    def dims(img):
+        return (int(img.shape[1]), int(img.shape[0]))
+
+    pc = PointCorrelations(device, dims(pyr1[0]), dims(pyr2[0]), fundamental_matrix, projection_mode)
+    try:
+        for i in range(steps + 1):
+            k = steps - i
+            pc.correlate_images(pyr1[k], pyr2[k], 1.0 / float(1 << k), fused=fused)
+        return pc.complete()
+    finally:
+        pc.close()

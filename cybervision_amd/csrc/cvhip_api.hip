@@ -1,0 +1,486 @@
+// cvhip_api.hip — C ABI of libcvhip.so: device + dense-correlation context.
+// Host-side orchestration only; the kernels are in corr_kernels.hip.  See include/cvhip.h for
+// the reference interface each entry point replaces.
+#include "cvhip_internal.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace cvhip {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+// Is `p` a device pointer usable on the current GPU?  Unregistered host memory makes
+// hipPointerGetAttributes fail, which is not an error for us.
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof(attr));
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // clear sticky error state
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static int copy_in(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    const hipMemcpyKind kind = is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    CVHIP_TRY_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
+    return CVHIP_OK;
+}
+
+// scale must be exactly 2^-k; returns k or -1.
+static int scale_to_k(float scale)
+{
+    if (!(scale > 0.0f) || scale > 1.0f) return -1;
+    int e = 0;
+    const float m = std::frexp(scale, &e); // scale = m * 2^e, m in [0.5, 1)
+    if (m != 0.5f) return -1;
+    const int k = 1 - e;
+    return (k >= 0 && k <= 15) ? k : -1;
+}
+
+static int set_device(const cvhip_device *dev)
+{
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    return CVHIP_OK;
+}
+
+static void free_ctx_buffers(cvhip_ctx *c)
+{
+    for (int d = 0; d < 2; d++) {
+        for (int i = 0; i < 2; i++) {
+            if (c->dir[d].xy[i]) (void)hipFree(c->dir[d].xy[i]);
+            if (c->dir[d].corr[i]) (void)hipFree(c->dir[d].corr[i]);
+            c->dir[d].xy[i] = nullptr;
+            c->dir[d].corr[i] = nullptr;
+        }
+        if (c->img[d]) (void)hipFree(c->img[d]);
+        if (c->stats[d]) (void)hipFree(c->stats[d]);
+        c->img[d] = nullptr;
+        c->stats[d] = nullptr;
+    }
+    if (c->range) (void)hipFree(c->range);
+    if (c->d_cand) (void)hipFree(c->d_cand);
+    c->range = nullptr;
+    c->d_cand = nullptr;
+    for (auto &ev : c->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    c->events.clear();
+}
+
+// Rows of an lh-row level image owned by this context's shard: equal chunks of ceil(lh/den).
+static void shard_rows(const cvhip_ctx *c, uint32_t lh, uint32_t *row0, uint32_t *row1)
+{
+    const uint32_t rpr = (lh + c->shard_den - 1) / c->shard_den;
+    const uint32_t r0 = std::min(lh, c->shard_num * rpr);
+    *row0 = r0;
+    *row1 = std::min(lh, r0 + rpr);
+}
+
+// One search pass (mod.rs:247-319) given level images already staged in c->img[a] (searched)
+// and c->img[b] (target) with their window statistics in c->stats[a], c->stats[b].
+static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2,
+                       float scale, int k, int first_pass, int dir)
+{
+    DirState &ds = c->dir[dir];
+    hipStream_t s = c->dev->d.stream;
+    if (lw1 != (ds.gw >> k) || lh1 != (ds.gh >> k))
+        return fail(CVHIP_ERR_UNSUPPORTED, "level dims must be floor(full * scale) (reconstruction.rs:146-152)");
+    if (!first_pass) {
+        if (!ds.valid) return fail(CVHIP_ERR_INVALID, "first_pass = 0 but this direction has no previous level");
+        if ((int)ds.k <= k)
+            return fail(CVHIP_ERR_UNSUPPORTED, "scale must shrink by powers of two from level to level");
+    }
+    CorrParams p;
+    std::memset(&p, 0, sizeof(p));
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) p.F[i * 3 + j] = dir == 0 ? c->F[i * 3 + j] : c->F[j * 3 + i]; // mod.rs:268-271
+    p.min_range = c->min_range;
+    p.extend_range = c->extend_range;
+    p.scale = scale;
+    p.min_stdev = c->min_stdev;
+    p.threshold = c->threshold;
+    p.corridor_size = c->corridor_size;
+    p.w1 = lw1;
+    p.h1 = lh1;
+    p.w2 = lw2;
+    p.h2 = lh2;
+    p.gw = ds.gw;
+    p.gh = ds.gh;
+    p.pw = ds.lw;
+    p.ph = ds.lh;
+    p.pk = ds.k;
+    p.k = (uint32_t)k;
+    p.first_pass = first_pass ? 1 : 0;
+    shard_rows(c, lh1, &p.row0, &p.row1);
+
+    const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
+    if (!first_pass) launch_search_range(p, c->stats[a], ds.xy[prev], c->range, s);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->time_kernels) {
+        if (c->events_used == c->events.size()) {
+            hipEvent_t x, y;
+            CVHIP_TRY_HIP(hipEventCreate(&x));
+            CVHIP_TRY_HIP(hipEventCreate(&y));
+            c->events.emplace_back(x, y);
+        }
+        e0 = c->events[c->events_used].first;
+        e1 = c->events[c->events_used].second;
+        c->events_used++;
+        CVHIP_TRY_HIP(hipEventRecord(e0, s));
+    }
+    launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.xy[next], ds.corr[next],
+                  c->count_candidates ? c->d_cand : nullptr, s);
+    if (c->time_kernels) CVHIP_TRY_HIP(hipEventRecord(e1, s));
+    CVHIP_TRY_HIP(hipGetLastError());
+
+    ds.cur = next;
+    ds.valid = true;
+    ds.lw = lw1;
+    ds.lh = lh1;
+    ds.k = (uint32_t)k;
+    return CVHIP_OK;
+}
+
+static int cross_check_pass(cvhip_ctx *c, int k, int dir)
+{
+    DirState &own = c->dir[dir];
+    DirState &other = c->dir[1 - dir];
+    if (!own.valid || !other.valid) return fail(CVHIP_ERR_INVALID, "cross_check_filter before both passes ran");
+    if ((int)own.k != k || (int)other.k != k)
+        return fail(CVHIP_ERR_INVALID, "cross_check_filter scale does not match the grids' current level");
+    launch_cross_check(own.xy[own.cur], own.corr[own.cur], other.xy[other.cur], own.lw, own.lh, other.lw, other.lh,
+                       c->dev->d.stream);
+    CVHIP_TRY_HIP(hipGetLastError());
+    return CVHIP_OK;
+}
+
+static int check_level_args(const cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
+                            uint32_t w2, uint32_t h2, float scale, int *k)
+{
+    if (!ctx || !img1 || !img2) return fail(CVHIP_ERR_INVALID, "null argument");
+    *k = scale_to_k(scale);
+    if (*k < 0) return fail(CVHIP_ERR_UNSUPPORTED, "scale must be 2^-k, 0 <= k <= 15 (reconstruction.rs:566)");
+    if (w1 < KERNEL_WIDTH || h1 < KERNEL_WIDTH || w2 < KERNEL_WIDTH || h2 < KERNEL_WIDTH)
+        return fail(CVHIP_ERR_INVALID, "level image smaller than the 11x11 correlation window");
+    if (w1 > 65535 || h1 > 65535 || w2 > 65535 || h2 > 65535)
+        return fail(CVHIP_ERR_UNSUPPORTED, "level dimension above 65535");
+    if ((size_t)w1 * h1 > ctx->max_px || (size_t)w2 * h2 > ctx->max_px)
+        return fail(CVHIP_ERR_INVALID, "level image larger than the context's full-resolution images");
+    return CVHIP_OK;
+}
+
+static void report(cvhip_progress_fn progress, void *user, int dir, float value)
+{
+    // same mapping as GpuContext::correlate_images' send_progress (gpu/mod.rs:241-249)
+    if (!progress) return;
+    progress(user, dir == 0 ? value * 0.98f / 2.0f : 0.51f + value * 0.98f / 2.0f);
+}
+
+} // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" {
+
+const char *cvhip_last_error(void) { return g_last_error.c_str(); }
+uint32_t cvhip_abi_version(void) { return 1; }
+
+int cvhip_device_create(int low_power, int ordinal, cvhip_device **out)
+{
+    if (!out) return fail(CVHIP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int count = 0;
+    CVHIP_TRY_HIP(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(CVHIP_ERR_DEVICE, "no HIP device");
+    if (ordinal < 0) CVHIP_TRY_HIP(hipGetDevice(&ordinal));
+    if (ordinal >= count) return fail(CVHIP_ERR_INVALID, "device ordinal out of range");
+    CVHIP_TRY_HIP(hipSetDevice(ordinal));
+    hipDeviceProp_t prop;
+    CVHIP_TRY_HIP(hipGetDeviceProperties(&prop, ordinal));
+    cvhip_device *dev = new (std::nothrow) cvhip_device();
+    if (!dev) return fail(CVHIP_ERR_NOMEM, "out of host memory");
+    dev->d.ordinal = ordinal;
+    dev->d.low_power = low_power;
+    dev->d.name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    hipError_t e = hipStreamCreateWithFlags(&dev->d.stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete dev;
+        return fail(CVHIP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = dev;
+    return CVHIP_OK;
+}
+
+void cvhip_device_destroy(cvhip_device *dev)
+{
+    if (!dev) return;
+    (void)hipSetDevice(dev->d.ordinal);
+    if (dev->d.stream) {
+        (void)hipStreamSynchronize(dev->d.stream);
+        (void)hipStreamDestroy(dev->d.stream);
+    }
+    delete dev;
+}
+
+const char *cvhip_device_name(const cvhip_device *dev) { return dev ? dev->d.name.c_str() : ""; }
+
+int cvhip_device_synchronize(cvhip_device *dev)
+{
+    if (!dev) return fail(CVHIP_ERR_INVALID, "dev is null");
+    CVHIP_TRY(set_device(dev));
+    CVHIP_TRY_HIP(hipStreamSynchronize(dev->d.stream));
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, uint32_t h2, int projection,
+                     const double *F, cvhip_ctx **out)
+{
+    if (!dev || !F || !out) return fail(CVHIP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (w1 < KERNEL_WIDTH || h1 < KERNEL_WIDTH || w2 < KERNEL_WIDTH || h2 < KERNEL_WIDTH)
+        return fail(CVHIP_ERR_INVALID, "image smaller than the 11x11 correlation window");
+    if (w1 > 65535 || h1 > 65535 || w2 > 65535 || h2 > 65535)
+        return fail(CVHIP_ERR_UNSUPPORTED, "image dimension above 65535");
+    if (projection != 0 && projection != 1) return fail(CVHIP_ERR_INVALID, "projection must be 0 or 1");
+    CVHIP_TRY(set_device(dev));
+    cvhip_ctx *c = new (std::nothrow) cvhip_ctx();
+    if (!c) return fail(CVHIP_ERR_NOMEM, "out of host memory");
+    c->dev = dev;
+    c->w1 = w1;
+    c->h1 = h1;
+    c->w2 = w2;
+    c->h2 = h2;
+    c->projection = projection;
+    std::memcpy(c->F, F, sizeof(c->F));
+    if (projection == 0) { // mod.rs:120-126
+        c->min_stdev = 1.0f;
+        c->threshold = 0.6f;
+        c->corridor_size = 2;
+        c->min_range = 2.5;
+        c->extend_range = 1.0;
+    } else { // mod.rs:127-133
+        c->min_stdev = 1.0f;
+        c->threshold = 0.5f;
+        c->corridor_size = 4;
+        c->min_range = 0.75;
+        c->extend_range = 0.5;
+    }
+    c->dir[0].gw = w1;
+    c->dir[0].gh = h1;
+    c->dir[1].gw = w2;
+    c->dir[1].gh = h2;
+    const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
+    c->max_px = std::max(n1, n2);
+    // Level grids are gathered in equal row chunks when sharded, so leave room for one padded
+    // chunk: (rows + den - 1) rows at most; 64 extra rows cover any den <= 64.
+    auto grid_elems = [](uint32_t w, uint32_t h) { return (size_t)w * ((size_t)h + 64); };
+    hipError_t e = hipSuccess;
+    for (int d = 0; d < 2 && e == hipSuccess; d++) {
+        const size_t ge = grid_elems(c->dir[d].gw, c->dir[d].gh);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) {
+            e = hipMalloc(&c->dir[d].xy[i], ge * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(&c->dir[d].corr[i], ge * sizeof(float));
+        }
+        if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
+        if (e == hipSuccess) e = hipMalloc(&c->stats[d], c->max_px * sizeof(float2));
+    }
+    if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_cand, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), dev->d.stream);
+    for (int d = 0; d < 2 && e == hipSuccess; d++)
+        e = hipMemsetAsync(c->img[d], 0, c->max_px + IMG_PAD, dev->d.stream);
+    if (e != hipSuccess) {
+        free_ctx_buffers(c);
+        delete c;
+        return fail(e == hipErrorOutOfMemory ? CVHIP_ERR_NOMEM : CVHIP_ERR_DEVICE,
+                    std::string("allocating device buffers: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return CVHIP_OK;
+}
+
+void cvhip_ctx_destroy(cvhip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->dev->d.ordinal);
+    (void)hipStreamSynchronize(ctx->dev->d.stream);
+    free_ctx_buffers(ctx);
+    delete ctx;
+}
+
+int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
+                           uint32_t w2, uint32_t h2, float scale, int first_pass, int dir,
+                           cvhip_progress_fn progress, void *user)
+{
+    int k = 0;
+    CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
+    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
+    CVHIP_TRY(set_device(ctx->dev));
+    hipStream_t s = ctx->dev->d.stream;
+    CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s)); // transfer_in_images, gpu/mod.rs:274
+    CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
+    report(progress, user, dir, 0.02f);
+    launch_window_stats(ctx->img[0], w1, h1, ctx->stats[0], s);
+    launch_window_stats(ctx->img[1], w2, h2, ctx->stats[1], s);
+    report(progress, user, dir, 0.20f);
+    CVHIP_TRY(search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, dir));
+    // Pageable host sources must not be reused by the caller before the copy has happened.
+    if (!is_device_ptr(img1) || !is_device_ptr(img2)) CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    report(progress, user, dir, 1.0f);
+    return CVHIP_OK;
+}
+
+int cvhip_cross_check_filter(cvhip_ctx *ctx, float scale, int dir)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
+    const int k = scale_to_k(scale);
+    if (k < 0) return fail(CVHIP_ERR_UNSUPPORTED, "scale must be 2^-k");
+    CVHIP_TRY(set_device(ctx->dev));
+    return cross_check_pass(ctx, k, dir);
+}
+
+int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
+                          uint32_t w2, uint32_t h2, float scale, int first_pass, cvhip_progress_fn progress,
+                          void *user)
+{
+    int k = 0;
+    CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
+    if (ctx->shard_den != 1)
+        return fail(CVHIP_ERR_UNSUPPORTED, "cvhip_correlate_level on a row-sharded context: use the per-pass calls");
+    CVHIP_TRY(set_device(ctx->dev));
+    hipStream_t s = ctx->dev->d.stream;
+    CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s));
+    CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
+    launch_window_stats(ctx->img[0], w1, h1, ctx->stats[0], s);
+    launch_window_stats(ctx->img[1], w2, h2, ctx->stats[1], s);
+    report(progress, user, 0, 0.20f);
+    CVHIP_TRY(search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0)); // mod.rs:224-230
+    report(progress, user, 0, 1.0f);
+    CVHIP_TRY(search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1)); // mod.rs:231-237
+    report(progress, user, 1, 1.0f);
+    CVHIP_TRY(cross_check_pass(ctx, k, 0)); // mod.rs:239
+    CVHIP_TRY(cross_check_pass(ctx, k, 1)); // mod.rs:240
+    if (!is_device_ptr(img1) || !is_device_ptr(img2)) CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    return CVHIP_OK;
+}
+
+int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr)
+{
+    if (!ctx || !out_xy) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
+    CVHIP_TRY(set_device(ctx->dev));
+    hipStream_t s = ctx->dev->d.stream;
+    DirState &ds = ctx->dir[dir];
+    const size_t n = (size_t)ds.gw * ds.gh;
+    const bool xy_dev = is_device_ptr(out_xy);
+    const bool corr_dev = out_corr ? is_device_ptr(out_corr) : true;
+    int32_t *d_xy = out_xy;
+    float *d_corr = out_corr;
+    if (!xy_dev) CVHIP_TRY_HIP(hipMalloc(&d_xy, n * 2 * sizeof(int32_t)));
+    if (out_corr && !corr_dev) {
+        hipError_t e = hipMalloc(&d_corr, n * sizeof(float));
+        if (e != hipSuccess) {
+            if (!xy_dev) (void)hipFree(d_xy);
+            return fail(CVHIP_ERR_NOMEM, "allocating readback buffer");
+        }
+    }
+    if (ds.valid) {
+        launch_expand_grid(ds.xy[ds.cur], ds.corr[ds.cur], ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy, d_corr, s);
+    } else { // nothing computed: all None, like a fresh Grid (mod.rs:183-184)
+        launch_fill_u32(reinterpret_cast<uint32_t *>(d_xy), 0xFFFFFFFFu, n * 2, s);
+        if (d_corr) launch_fill_u32(reinterpret_cast<uint32_t *>(d_corr), 0x7FC00000u, n, s);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !xy_dev) e = hipMemcpyAsync(out_xy, d_xy, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && out_corr && !corr_dev)
+        e = hipMemcpyAsync(out_corr, d_corr, n * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (!xy_dev) (void)hipFree(d_xy);
+    if (out_corr && !corr_dev) (void)hipFree(d_corr);
+    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("complete: ") + hipGetErrorString(e));
+    return CVHIP_OK;
+}
+
+int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr)
+{
+    return cvhip_complete_dir(ctx, 0, out_xy, out_corr);
+}
+
+int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (den == 0 || den > 64 || num >= den) return fail(CVHIP_ERR_INVALID, "need 0 <= num < den <= 64");
+    ctx->shard_num = num;
+    ctx->shard_den = den;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **xy, void **corr, uint32_t *lw, uint32_t *lh,
+                         uint32_t *row0, uint32_t *row1)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
+    DirState &ds = ctx->dir[dir];
+    if (!ds.valid) return fail(CVHIP_ERR_INVALID, "no level computed yet");
+    if (xy) *xy = ds.xy[ds.cur];
+    if (corr) *corr = ds.corr[ds.cur];
+    if (lw) *lw = ds.lw;
+    if (lh) *lh = ds.lh;
+    uint32_t r0, r1;
+    shard_rows(ctx, ds.lh, &r0, &r1);
+    if (row0) *row0 = r0;
+    if (row1) *row1 = r1;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_profiling(cvhip_ctx *ctx, int time_kernels, int count_candidates)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    ctx->time_kernels = time_kernels ? 1 : 0;
+    ctx->count_candidates = count_candidates ? 1 : 0;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms, uint64_t *candidates, int reset)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(set_device(ctx->dev));
+    hipStream_t s = ctx->dev->d.stream;
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < ctx->events_used; i++) {
+        float ms = 0.0f;
+        CVHIP_TRY_HIP(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
+        ctx->prof_ms += (double)ms;
+        ctx->prof_launches++;
+    }
+    ctx->events_used = 0;
+    unsigned long long cand = 0;
+    CVHIP_TRY_HIP(hipMemcpy(&cand, ctx->d_cand, sizeof(cand), hipMemcpyDeviceToHost));
+    if (launches) *launches = ctx->prof_launches;
+    if (search_ms) *search_ms = ctx->prof_ms;
+    if (candidates) *candidates = (uint64_t)cand;
+    if (reset) {
+        ctx->prof_launches = 0;
+        ctx->prof_ms = 0.0;
+        CVHIP_TRY_HIP(hipMemset(ctx->d_cand, 0, sizeof(unsigned long long)));
+    }
+    return CVHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,118 @@
+// cvhip_internal.hpp — shared declarations of libcvhip.so (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/cvhip.h"
+
+namespace cvhip {
+
+// ---- error plumbing -----------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define CVHIP_TRY_HIP(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return ::cvhip::fail(CVHIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define CVHIP_TRY(expr)      \
+    do {                     \
+        int _rc = (expr);    \
+        if (_rc != CVHIP_OK) \
+            return _rc;      \
+    } while (0)
+
+// ---- constants of the reference (src/correlation/mod.rs:15-31) -----------------------------
+constexpr int KERNEL_SIZE = 5;
+constexpr int KERNEL_WIDTH = 11;
+constexpr int KERNEL_POINT_COUNT = 121;
+constexpr int NEIGHBOR_DISTANCE = 10;
+constexpr int CROSS_CHECK_SEARCH_AREA = 4;
+
+constexpr uint32_t CELL_NONE = 0xFFFFFFFFu;  // packed level-grid cell: x | y << 16, or None
+constexpr uint32_t RANGE_NONE = 0xFFFFFFFFu; // packed corridor range: start | end << 16, or None
+constexpr size_t IMG_PAD = 64;               // bytes readable past the end of every image buffer
+
+// Per-pass parameters handed to the kernels by value.
+struct CorrParams {
+    double F[9];  // fundamental matrix of this direction, row-major (transposed for Reverse)
+    double min_range, extend_range;
+    float scale;
+    float min_stdev, threshold;
+    int corridor_size;
+    uint32_t w1, h1, w2, h2; // level dims of the searched (1) and target (2) image
+    uint32_t gw, gh;         // full-resolution grid dims of this direction
+    uint32_t pw, ph, pk;     // previous level's compact grid dims and its k (scale = 2^-k)
+    uint32_t k;              // this level's k
+    uint32_t row0, row1;     // rows of the searched image handled by this launch
+    int first_pass;
+};
+
+// ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------
+void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float2 *stats, hipStream_t s);
+void launch_search_range(const CorrParams &p, const float2 *stats1, const uint32_t *prev_xy, uint32_t *range,
+                         hipStream_t s);
+void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                   const float2 *stats2, const uint32_t *range, uint32_t *out_xy, float *out_corr,
+                   unsigned long long *cand_counter, hipStream_t s);
+void launch_cross_check(uint32_t *own_xy, float *own_corr, const uint32_t *other_xy, uint32_t ow, uint32_t oh,
+                        uint32_t rw, uint32_t rh, hipStream_t s);
+void launch_expand_grid(const uint32_t *xy, const float *corr, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw,
+                        uint32_t gh, int32_t *out_xy, float *out_corr, hipStream_t s);
+void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
+
+// ---- handles --------------------------------------------------------------------------------
+struct Device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    std::string name;
+    int low_power = 0;
+};
+
+struct DirState {
+    uint32_t *xy[2] = {nullptr, nullptr}; // ping-pong level grids (packed cells)
+    float *corr[2] = {nullptr, nullptr};
+    int cur = 0;        // index of the grid holding the most recent level
+    bool valid = false; // a level has been computed
+    uint32_t lw = 0, lh = 0, k = 0;
+    uint32_t gw = 0, gh = 0; // full-res dims of this direction's grid
+};
+
+} // namespace cvhip
+
+struct cvhip_device {
+    cvhip::Device d;
+};
+
+struct cvhip_ctx {
+    cvhip_device *dev = nullptr;
+    uint32_t w1 = 0, h1 = 0, w2 = 0, h2 = 0;
+    int projection = 0;
+    double F[9] = {0};
+    // CorrelationParameters::for_projection (mod.rs:111-143)
+    float min_stdev = 1.0f, threshold = 0.6f;
+    int corridor_size = 2;
+    double min_range = 2.5, extend_range = 1.0;
+
+    cvhip::DirState dir[2];
+    uint8_t *img[2] = {nullptr, nullptr}; // level image staging (padded), [0]=searched [1]=target of the call
+    float2 *stats[2] = {nullptr, nullptr};
+    uint32_t *range = nullptr;
+    size_t max_px = 0;
+
+    uint32_t shard_num = 0, shard_den = 1;
+
+    int time_kernels = 0, count_candidates = 0;
+    unsigned long long *d_cand = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    uint32_t prof_launches = 0;
+    double prof_ms = 0.0;
+};

@@ -1,0 +1,155 @@
+"""Deterministic, integer-only synthetic inputs for the dense-correlation path.
+
+The reference ships no images, so every platform must be able to produce
+byte-identical inputs: all arithmetic here is integer (uint32 hashing, 8.8 fixed-point
+bilinear value noise), no libm.  Layout follows the reference's `Grid<u8>`: row-major,
+``index = width*y + x`` (src/data.rs:22-64).
+
+``make_pair``       img1 = T(x, y), img2(x, y) = T(x + d(x, y), y) with an integer disparity
+                    field d, so surviving matches have a known answer.
+``box_pyramid``     2x2 integer box-filter pyramid, level k has dims floor(W / 2^k) — the
+                    documented stand-in for the `image` crate's Lanczos3 resize, which is
+                    upstream of the accelerated boundary (src/reconstruction.rs:146-152).
+``level_schedule``  the reference's level loop (src/reconstruction.rs:565-568).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+_U32 = np.uint64(0xFFFFFFFF)
+
+
+def hash32(x, y, seed: int):
+    """32-bit integer mix of (x, y, seed); x, y are int64 arrays (may be negative)."""
+    x = np.asarray(x, dtype=np.int64).astype(np.uint64) & _U32
+    y = np.asarray(y, dtype=np.int64).astype(np.uint64) & _U32
+    h = (x * np.uint64(0x9E3779B1)) ^ (y * np.uint64(0x85EBCA77)) ^ np.uint64((seed * 0xC2B2AE3D) & 0xFFFFFFFF)
+    h &= _U32
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x2C1B3C6D)) & _U32
+    h ^= h >> np.uint64(12)
+    h = (h * np.uint64(0x297A2D39)) & _U32
+    h ^= h >> np.uint64(15)
+    return h
+
+
+def _octave(xs, ys, cell: int, seed: int):
+    """Bilinear value noise with lattice spacing `cell`, 8.8 fixed point, result 0..255."""
+    ix = np.floor_divide(xs, cell)
+    iy = np.floor_divide(ys, cell)
+    fx = ((xs - ix * cell) * 256) // cell
+    fy = ((ys - iy * cell) * 256) // cell
+    l00 = (hash32(ix, iy, seed) & np.uint64(0xFF)).astype(np.int64)
+    l10 = (hash32(ix + 1, iy, seed) & np.uint64(0xFF)).astype(np.int64)
+    l01 = (hash32(ix, iy + 1, seed) & np.uint64(0xFF)).astype(np.int64)
+    l11 = (hash32(ix + 1, iy + 1, seed) & np.uint64(0xFF)).astype(np.int64)
+    top = l00 * (256 - fx) + l10 * fx
+    bot = l01 * (256 - fx) + l11 * fx
+    return (top * (256 - fy) + bot * fy) >> 16
+
+
+def texture(xs, ys, seed: int = 1234):
+    """T(x, y): mean of four value-noise octaves (cells 4/16/64/256 px), 0..255, int64."""
+    xs = np.asarray(xs, dtype=np.int64)
+    ys = np.asarray(ys, dtype=np.int64)
+    acc = np.zeros(np.broadcast(xs, ys).shape, dtype=np.int64)
+    for k, cell in enumerate((4, 16, 64, 256)):
+        acc = acc + _octave(xs, ys, cell, seed + 17 * k)
+    return (acc + 2) >> 2
+
+
+def _tri(v, period: int):
+    """Integer triangle wave in [-256, 256] with the given period."""
+    u = np.mod(v, period)
+    t = (u * 1024) // period
+    return np.where(t < 512, t - 256, 768 - t)
+
+
+def disparity(width: int, height: int):
+    """d(x, y) = (A * tri(x, P) * tri(y, Q)) >> 16, A = W/64, P = W/4, Q = H/4; |d| <= A."""
+    a = max(width // 64, 1)
+    p = max(width // 4, 4)
+    q = max(height // 4, 4)
+    xs = np.arange(width, dtype=np.int64)[None, :]
+    ys = np.arange(height, dtype=np.int64)[:, None]
+    return (a * _tri(xs, p) * _tri(ys, q)) >> 16
+
+
+def make_pair(width: int, height: int | None = None, seed: int = 1234, sem_style: bool = False):
+    """Return (img1, img2, d): two uint8 (H, W) images and the int64 disparity field."""
+    height = width if height is None else height
+    xs = np.arange(width, dtype=np.int64)[None, :]
+    ys = np.arange(height, dtype=np.int64)[:, None]
+    d = disparity(width, height)
+    t1 = texture(xs, ys, seed)
+    t2 = texture(xs + d, ys + 0 * xs, seed)
+    if sem_style:
+        # linear shading ramp of +-16 grey levels and 2 % salt noise, both integer
+        ramp = ((xs * 32) // max(width, 1)) - 16
+        t1 = t1 + ramp
+        t2 = t2 + ramp
+        for t, s in ((t1, seed + 1), (t2, seed + 2)):
+            h = hash32(xs + 0 * ys, ys + 0 * xs, s)
+            salt = (h % np.uint64(50)) == 0
+            t[salt] = 255
+    img1 = np.clip(t1, 0, 255).astype(np.uint8)
+    img2 = np.clip(t2, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(img1), np.ascontiguousarray(img2), d
+
+
+def add_blocks(img: np.ndarray, count: int = 400, seed: int = 77):
+    """Overlay random axis-aligned rectangles (contrast +-40) so FAST has corners to find."""
+    out = img.astype(np.int64)
+    h, w = img.shape
+    idx = np.arange(count, dtype=np.int64)
+    x0 = (hash32(idx, 0 * idx, seed) % np.uint64(max(w - 8, 1))).astype(np.int64)
+    y0 = (hash32(idx, 0 * idx + 1, seed) % np.uint64(max(h - 8, 1))).astype(np.int64)
+    bw = 8 + (hash32(idx, 0 * idx + 2, seed) % np.uint64(max(w // 16, 1))).astype(np.int64)
+    bh = 8 + (hash32(idx, 0 * idx + 3, seed) % np.uint64(max(h // 16, 1))).astype(np.int64)
+    sg = np.where((hash32(idx, 0 * idx + 4, seed) & np.uint64(1)) == 0, 40, -40)
+    for i in range(count):
+        out[y0[i]:y0[i] + bh[i], x0[i]:x0[i] + bw[i]] += sg[i]
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def box_downsample(img: np.ndarray) -> np.ndarray:
+    """One 2x2 box-filter step with rounding; dims floor(w/2) x floor(h/2)."""
+    h, w = img.shape
+    h2, w2 = h // 2, w // 2
+    v = img[: h2 * 2, : w2 * 2].astype(np.uint16)
+    s = v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2]
+    return np.ascontiguousarray(((s + 2) >> 2).astype(np.uint8))
+
+
+def box_pyramid(img: np.ndarray, steps: int):
+    """[level 0 (full res), level 1 (1/2), ..., level `steps` (1/2^steps)]."""
+    out = [np.ascontiguousarray(img)]
+    for _ in range(steps):
+        out.append(box_downsample(out[-1]))
+    return out
+
+
+def optimal_scale_steps(width: int, height: int, min_size: int = 64) -> int:
+    """PointCorrelations::optimal_scale_steps (src/correlation/mod.rs:542-550)."""
+    m = min(width, height)
+    if m <= min_size:
+        return 0
+    return int(math.floor(math.log2(m / min_size)))
+
+
+def level_schedule(width: int, height: int, min_size: int = 64):
+    """[(k, scale)] coarse to fine, scale = 1 / (1 << k) (src/reconstruction.rs:565-566)."""
+    steps = optimal_scale_steps(width, height, min_size)
+    return [(steps - i, 1.0 / float(1 << (steps - i))) for i in range(steps + 1)]
+
+
+F_HORIZONTAL = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0]])
+
+
+def f_tilt(theta_deg: float) -> np.ndarray:
+    """Affine fundamental matrix whose epipolar lines are tilted by theta."""
+    t = math.radians(theta_deg)
+    s, c = math.sin(t), math.cos(t)
+    return np.array([[0.0, 0.0, -s], [0.0, 0.0, c], [s, -c, 0.0]])

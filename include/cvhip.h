@@ -1,0 +1,157 @@
+/*
+ * cvhip.h — C ABI of libcvhip.so, the MI355X (gfx950) backend for cybervision's hot path.
+ *
+ * This is the drop-in boundary: every entry point names the reference interface it replaces
+ * (file:line into zlogic/cybervision v0.20.3, src/...).  Plain C types only; no HIP or torch
+ * types cross the boundary.  INTEGRATION.md shows the Rust `extern "C"` block and the
+ * `hip.rs` backend module a maintainer would add next to gpu/vulkan.rs and gpu/metal.rs.
+ *
+ * Conventions
+ *  - Return value: 0 = CVHIP_OK, negative = error class; the message for the calling thread's
+ *    last failure is cvhip_last_error() (maps to GpuError::Internal(&'static str),
+ *    correlation/gpu/vulkan.rs:1204-1272).  Nothing throws or aborts across the ABI.
+ *  - Ownership: the caller owns every host pointer and it only has to stay valid for the
+ *    duration of the call; the library owns all device memory behind the opaque handles.
+ *  - Image and output pointers may be HOST or DEVICE (HIP) pointers; the library detects
+ *    which (hipPointerGetAttributes).  Device pointers must belong to the handle's GPU.
+ *  - Grids are row-major, index = width*y + x (data.rs:22-64).  Option<Match> is encoded as
+ *    int32 (x, y) with (-1, -1) = None plus a separate float score plane (NaN for None).
+ *  - Threading: a handle is used by one thread at a time, as in the reference where every
+ *    call goes through `&mut` (correlation/mod.rs:255).  Different handles are independent.
+ *  - dir: 0 = CorrelationDirection::Forward, 1 = Reverse (correlation/mod.rs:77-81).  As in
+ *    the reference, the caller swaps the images for Reverse (mod.rs:231-237) and the library
+ *    transposes F (mod.rs:268-271).
+ *  - projection: 0 = ProjectionMode::Affine, 1 = Perspective (correlation/mod.rs:43-47).
+ */
+#ifndef CVHIP_H
+#define CVHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVHIP_OK 0
+#define CVHIP_ERR_INVALID (-1)     /* bad argument / call sequence */
+#define CVHIP_ERR_DEVICE (-2)      /* HIP runtime error (message has hipGetErrorString) */
+#define CVHIP_ERR_UNSUPPORTED (-3) /* valid in the reference, not supported here (documented) */
+#define CVHIP_ERR_NOMEM (-4)
+
+typedef struct cvhip_device cvhip_device;
+typedef struct cvhip_ctx cvhip_ctx;
+
+/* Progress hook: replaces ProgressListener::report_status (correlation/mod.rs:56-61).
+ * Invoked synchronously on the calling thread between kernel submissions; never retained. */
+typedef void (*cvhip_progress_fn)(void *user, float pos);
+
+/* Message of the calling thread's last error ("" if none). Static lifetime per thread. */
+const char *cvhip_last_error(void);
+/* ABI version, bumped on incompatible change. */
+uint32_t cvhip_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Device — replaces GpuDevice::new / create_gpu_context (correlation/mod.rs:145-147) and
+ * the DeviceContext trait (correlation/gpu/mod.rs:64-81).
+ * ---------------------------------------------------------------------------------------- */
+
+/* low_power mirrors HardwareMode::GpuLowPower (mod.rs:50-54); accepted and ignored (no
+ * dispatch segmenting is needed on MI355X).  ordinal < 0 = HIP's current device. */
+int cvhip_device_create(int low_power, int ordinal, cvhip_device **out);
+void cvhip_device_destroy(cvhip_device *dev);
+/* DeviceContext::get_device_name (gpu/mod.rs:70). Valid until cvhip_device_destroy. */
+const char *cvhip_device_name(const cvhip_device *dev);
+/* Block until everything submitted on the device's stream has finished. */
+int cvhip_device_synchronize(cvhip_device *dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense correlation context — replaces GpuContext (correlation/gpu/mod.rs:106-362) as used by
+ * PointCorrelations (correlation/mod.rs:150-245).
+ * ---------------------------------------------------------------------------------------- */
+
+/* GpuContext::new (gpu/mod.rs:125-163; called mod.rs:159-165).  dims are the FULL-RES image
+ * dimensions, F is row-major 3x3 (nalgebra Matrix3 (r,c) -> F[3*r+c]). */
+int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, uint32_t h2, int projection,
+                     const double *F, cvhip_ctx **out);
+void cvhip_ctx_destroy(cvhip_ctx *ctx);
+
+/* GpuContext::correlate_images (gpu/mod.rs:218-362; called mod.rs:255-259): one search pass
+ * over level images img1 (searched) and img2 (target) at `scale`, results replace this
+ * direction's level grid.  Results follow the reference's --mode=cpu semantics
+ * (mod.rs:247-540), NOT the GLSL shaders' (SURVEY.md §8a N1).
+ * Supported schedule (the only one the reference issues, reconstruction.rs:565-568):
+ * scale = 2^-k exactly, k strictly decreasing from call to call per direction, level dims =
+ * floor(full * scale); anything else returns CVHIP_ERR_UNSUPPORTED. */
+int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
+                           uint32_t w2, uint32_t h2, float scale, int first_pass, int dir,
+                           cvhip_progress_fn progress, void *user);
+
+/* GpuContext::cross_check_filter (gpu/mod.rs:172-208; called mod.rs:557-560) with the CPU
+ * semantics of mod.rs:552-624. */
+int cvhip_cross_check_filter(cvhip_ctx *ctx, float scale, int dir);
+
+/* One whole PointCorrelations::correlate_images (mod.rs:217-245) in a single call: forward
+ * pass, reverse pass (images swapped, F transposed), cross-check forward, cross-check reverse.
+ * Same results as the four calls above; uploads and window statistics are shared. */
+int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
+                          uint32_t w2, uint32_t h2, float scale, int first_pass, cvhip_progress_fn progress,
+                          void *user);
+
+/* GpuContext::complete_process (gpu/mod.rs:210-216; called mod.rs:208-215): write the forward
+ * full-resolution grid.  out_xy: 2*w1*h1 int32, out_corr: w1*h1 float (may be NULL).
+ * Synchronises.  The context can be destroyed or reused for cvhip_complete_dir afterwards. */
+int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr);
+/* Same for either direction (dir 1 = correlated_points_reverse, mod.rs:65); test hook. */
+int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr);
+
+/* Row sharding (multi-GPU): restrict the search passes of this context to level rows
+ * [floor(h_level*num/den), floor(h_level*(num+1)/den)) of the searched image.  Rows outside
+ * the band keep whatever the level grid holds (the host fills them with an all-gather).
+ * num = 0, den = 1 (default) = all rows. */
+int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den);
+/* Device pointers + geometry of direction `dir`'s current level grid, for collectives done
+ * by the host (RCCL all-gather of row bands).  xy: packed u32 per level pixel
+ * (x | y << 16 in LEVEL coordinates, 0xFFFFFFFF = None), corr: float per level pixel. */
+int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **xy, void **corr, uint32_t *lw, uint32_t *lh,
+                         uint32_t *row0, uint32_t *row1);
+
+/* Measurement hooks (bench.py): when enabled, every search-kernel launch is bracketed by HIP
+ * events on the context's stream and evaluated candidates are counted on the device. */
+int cvhip_ctx_set_profiling(cvhip_ctx *ctx, int time_kernels, int count_candidates);
+/* Accumulated since the last reset: search-kernel launches, their summed duration (ms) and the
+ * number of candidates that executed the 121-term sum (mod.rs:442-454).  Synchronises. */
+int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms, uint64_t *candidates,
+                          int reset);
+
+/* ------------------------------------------------------------------------------------------
+ * ORB — replaces orb::extract_points (orb.rs:50-84).
+ * out_xy: 2*cap u32 (x, y), out_desc: 8*cap u32, *out_n = keypoints written (<= cap).
+ * Order = the reference's (Harris-descending stable, then BRIEF filter).  cap >= 10000 to
+ * receive everything the reference returns (MAX_KEYPOINTS, orb.rs:41).
+ * ---------------------------------------------------------------------------------------- */
+int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
+                      uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n);
+
+/* ------------------------------------------------------------------------------------------
+ * Keypoint matcher — replaces KeypointMatching::match_points (pointmatching.rs:43-77).
+ * xy: 2 u32 per keypoint, desc: 8 u32 per keypoint.  out_matches: 4*n1 u32 (x1,y1,x2,y2),
+ * sorted by Hamming distance (stable); out_dist (n1, may be NULL).
+ * ---------------------------------------------------------------------------------------- */
+int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const uint32_t *desc1, uint32_t n1,
+                       const uint32_t *xy2, const uint32_t *desc2, uint32_t n2, uint32_t threshold,
+                       uint32_t *out_matches, uint32_t *out_dist, uint32_t *out_n);
+
+/* ------------------------------------------------------------------------------------------
+ * RANSAC hypothesis scoring — replaces the all-matches fold of FundamentalMatrix::validate_f
+ * (fundamentalmatrix.rs:210-216) with fits_model/reprojection_error (:452-471), for H
+ * hypotheses at once.  F: 9*H doubles row-major, matches: 4*N u32 (x1,y1,x2,y2).
+ * out_count[h] = inliers, out_err_sum[h] = sum of their errors in match order.
+ * ---------------------------------------------------------------------------------------- */
+int cvhip_ransac_score(cvhip_device *dev, const double *F, uint32_t H, const uint32_t *matches, uint32_t N,
+                       double t, uint32_t *out_count, double *out_err_sum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

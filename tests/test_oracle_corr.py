@@ -1,0 +1,128 @@
+"""CPU tests of the dense-correlation oracle (oracle/cvref_corr.c): analytic known-answer
+cases, independent re-derivations of small pieces, and the committed golden fixtures."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+from cybervision_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def run_oracle(oracle, c, nthreads=8):
+    p1, p2 = cases.pyramids(c)
+    return oracle.correlate_dense(p1, p2, c["F"], c["projection"], nthreads)
+
+
+def test_optimal_scale_steps(oracle):
+    # mod.rs:542-550: floor(log2(min_dim / 64)), 0 if <= 64
+    for dims, want in [((64, 64), 0), ((65, 100), 0), ((127, 500), 0), ((128, 128), 1), ((256, 256), 2),
+                       ((1024, 768), 3), ((4096, 4096), 6), ((4032, 3024), 5)]:
+        assert oracle.lib().cvref_corr_optimal_scale_steps(*dims) == want
+        assert synth.optimal_scale_steps(*dims) == want
+
+
+def test_window_stats_against_python_serial_f32(oracle):
+    """compute_point_avg/stdev (mod.rs:658-694) re-derived with explicit float32 steps."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(20, 23), dtype=np.uint8)
+    avg, std = oracle.image_point_data(img)
+    assert np.isnan(avg[:5]).all() and np.isnan(avg[-5:]).all() and np.isnan(avg[:, :5]).all()
+    assert np.isnan(std[:, -5:]).all()
+    f32 = np.float32
+    for (y, x) in [(5, 5), (9, 11), (14, 17), (7, 12)]:
+        win = img[y - 5:y + 6, x - 5:x + 6].astype(np.float32).reshape(-1)
+        a = f32(0)
+        for v in win:
+            a = f32(a + v)
+        a = f32(a / f32(121))
+        s = f32(0)
+        for v in win:
+            d = f32(v - a)
+            s = f32(s + f32(d * d))
+        s = np.sqrt(f32(s / f32(121)), dtype=np.float32)
+        assert avg[y, x].view(np.uint32) == a.view(np.uint32)
+        assert std[y, x].view(np.uint32) == s.view(np.uint32)
+
+
+def test_flat_images_give_no_matches(oracle):
+    """stdev < MIN_STDEV rejects every point (mod.rs:334)."""
+    xy, corr, cand = run_oracle(oracle, cases.make_case("flat"))
+    assert (xy == -1).all() and np.isnan(corr).all() and cand == 0
+
+
+def test_identical_images_match_themselves(oracle):
+    """img2 == img1 with horizontal epipolar lines: nearly every surviving match is the
+    identity with correlation 1 (up to f32 rounding), and most interior pixels survive."""
+    a, _, _ = synth.make_pair(128, 128, seed=5)
+    steps = synth.optimal_scale_steps(128, 128)
+    p = synth.box_pyramid(a, steps)
+    xy, corr, _ = oracle.correlate_dense(p, p, synth.F_HORIZONTAL, 0, 4)
+    valid = xy[..., 0] >= 0
+    ys, xs = np.nonzero(valid)
+    assert valid[5:-5, 5:-5].mean() > 0.95
+    ident = (xy[..., 0][valid] == xs) & (xy[..., 1][valid] == ys)
+    # the search interval of refined levels is estimated from coarser matches (mod.rs:468-540),
+    # so a few pixels never see their own position; all others must be exact identities
+    assert ident.mean() > 0.9
+    assert np.allclose(corr[valid][ident], 1.0, atol=1e-5)
+    assert not valid[:5].any() and not valid[:, :5].any() and not valid[-5:].any() and not valid[:, -5:].any()
+
+
+def test_known_disparity_is_recovered(oracle):
+    """img2(x, y) = T(x + d, y): a match (x2, y2) of pixel (x, y) must satisfy x2 + d(x2, y2) ~ x."""
+    c = cases.make_case("h256")
+    _, _, d = synth.make_pair(256, 256)
+    xy, corr, cand = run_oracle(oracle, c)
+    valid = xy[..., 0] >= 0
+    ys, xs = np.nonzero(valid)
+    x2, y2 = xy[..., 0][valid], xy[..., 1][valid]
+    err = np.abs(x2 + d[y2, x2] - xs)
+    assert valid.mean() > 0.75
+    assert (err <= 1).mean() > 0.97
+    assert (np.abs(y2 - ys) <= 2).all()  # corridor stripes, mod.rs:371-381
+    assert (corr[valid] >= np.float32(0.6)).all()  # THRESHOLD_AFFINE, mod.rs:20
+    assert cand > 0
+
+
+def test_thread_count_does_not_change_results(oracle):
+    c = cases.make_case("tilt3_200x150")
+    a = run_oracle(oracle, c, nthreads=1)
+    b = run_oracle(oracle, c, nthreads=7)
+    assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all() and a[2] == b[2]
+
+
+@pytest.mark.parametrize("name", cases.GOLDEN_CASES)
+def test_oracle_reproduces_golden(oracle, name):
+    g = np.load(GOLDEN / f"corr_{name}.npz")
+    c = cases.make_case(name)
+    assert (c["img1"] == g["img1"]).all() and (c["img2"] == g["img2"]).all(), "synthetic generator drifted"
+    xy, corr, cand = run_oracle(oracle, c)
+    assert (xy == g["fwd_xy"].astype(np.int32)).all()
+    assert (corr.view(np.uint32) == g["fwd_corr"].view(np.uint32)).all()
+    assert cand == int(g["candidates"])
+
+
+def test_cross_check_removes_one_sided_matches(oracle):
+    """A forward match whose target has no reverse match back within +-4 cells is dropped
+    (mod.rs:588-624): after the level, every surviving forward match has such a reverse match."""
+    c = cases.make_case("tilt3_200x150")
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    oc = oracle.Corr((w1, h1), (w2, h2), c["F"], 0, 4)
+    for i in range(c["steps"] + 1):
+        k = c["steps"] - i
+        oc.correlate_images(p1[k], p2[k], 1.0 / (1 << k))
+    fxy, _ = oc.get(0)
+    rxy, _ = oc.get(1)
+    ys, xs = np.nonzero(fxy[..., 0] >= 0)
+    rng = np.random.default_rng(0)
+    for i in rng.choice(len(xs), size=300, replace=False):
+        x, y = xs[i], ys[i]
+        mx, my = fxy[y, x]
+        win = rxy[max(my - 4, 0):my + 5, max(mx - 4, 0):mx + 5].reshape(-1, 2)
+        win = win[win[:, 0] >= 0]
+        assert ((np.abs(win[:, 0] - x) <= 4) & (np.abs(win[:, 1] - y) <= 4)).any()
