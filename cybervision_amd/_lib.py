@@ -21,6 +21,7 @@ class CvhipError(RuntimeError):
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int)
 _vp = C.c_void_p
 _u32 = C.c_uint32
 
@@ -29,6 +30,7 @@ SIGNATURES = {
     "cvhip_last_error": (C.c_char_p, []),
     "cvhip_abi_version": (_u32, []),
     "cvhip_device_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "cvhip_device_create_on_stream": (C.c_int, [C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "cvhip_device_destroy": (None, [_vp]),
     "cvhip_device_name": (C.c_char_p, [_vp]),
     "cvhip_device_synchronize": (C.c_int, [_vp]),
@@ -41,8 +43,8 @@ SIGNATURES = {
                                         _vp]),
     "cvhip_complete": (C.c_int, [_vp, _vp, _vp]),
     "cvhip_complete_dir": (C.c_int, [_vp, C.c_int, _vp, _vp]),
-    "cvhip_ctx_set_row_shard": (C.c_int, [_vp, _u32, _u32]),
-    "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u32),
+    "cvhip_ctx_set_row_shard": (C.c_int, [_vp, _u32, _u32, ALLGATHER_FN, _vp]),
+    "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32),
                                        C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "cvhip_ctx_set_profiling": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cvhip_ctx_get_profile": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
@@ -61,6 +63,13 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -m cybervision_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+        try:
+            # torch bundles its own ROCm runtime; loading it FIRST makes libcvhip.so bind to that
+            # same libamdhip64.so.7, so one process never holds two HIP runtimes (the second one
+            # would see "no HIP GPUs").
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI symbol is missing
@@ -77,3 +86,4 @@ def check(rc: int, where: str):
 
 
 NULL_PROGRESS = PROGRESS_FN()
+NULL_ALLGATHER = ALLGATHER_FN()

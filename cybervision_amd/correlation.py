@@ -48,12 +48,15 @@ def _ptr_shape(img):
 class GpuDevice:
     """create_gpu_context(HardwareMode) -> GpuDevice (correlation/mod.rs:145-147)."""
 
-    def __init__(self, hardware_mode: HardwareMode = HardwareMode.Gpu, ordinal: int = -1):
+    def __init__(self, hardware_mode: HardwareMode = HardwareMode.Gpu, ordinal: int = -1, stream: int | None = None):
+        """stream: optional raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) to
+        submit all work to; default is a private stream."""
         if hardware_mode == HardwareMode.Cpu:
             raise ValueError("HardwareMode.Cpu has no GPU device (the CPU path is the reference's own)")
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().cvhip_device_create(int(hardware_mode == HardwareMode.GpuLowPower), ordinal,
-                                                  C.byref(self._h)), "cvhip_device_create")
+        _lib.check(_lib.lib().cvhip_device_create_on_stream(int(hardware_mode == HardwareMode.GpuLowPower), ordinal,
+                                                            C.c_void_p(stream or 0), C.byref(self._h)),
+                   "cvhip_device_create")
 
     @property
     def handle(self):
@@ -77,8 +80,9 @@ class GpuDevice:
             pass
 
 
-def create_gpu_context(hardware_mode: HardwareMode = HardwareMode.Gpu, ordinal: int = -1) -> GpuDevice:
-    return GpuDevice(hardware_mode, ordinal)
+def create_gpu_context(hardware_mode: HardwareMode = HardwareMode.Gpu, ordinal: int = -1,
+                       stream: int | None = None) -> GpuDevice:
+    return GpuDevice(hardware_mode, ordinal, stream)
 
 
 class PointCorrelations:
@@ -157,16 +161,30 @@ class PointCorrelations:
                    "cvhip_ctx_get_profile")
         return {"launches": n.value, "search_ms": ms.value, "candidates": cand.value}
 
-    def set_row_shard(self, num: int, den: int):
-        _lib.check(_lib.lib().cvhip_ctx_set_row_shard(self._h, num, den), "cvhip_ctx_set_row_shard")
+    def set_row_shard(self, num: int, den: int, gather=None):
+        """gather(cells_ptr: int, shard_bytes: int, n_shards: int, direction: int) -> None does the
+        in-place all-gather of the level grid (see cybervision_amd.sharding)."""
+        if gather is None:
+            cb = _lib.NULL_ALLGATHER
+        else:
+            def _cb(_user, cells, shard_bytes, n_shards, direction):
+                try:
+                    gather(int(cells), int(shard_bytes), int(n_shards), int(direction))
+                    return 0
+                except Exception as exc:  # never let an exception cross the C frame
+                    self._gather_error = exc
+                    return 1
+            cb = _lib.ALLGATHER_FN(_cb)
+        self._gather_cb = cb  # keep the thunk alive as long as the context may call it
+        _lib.check(_lib.lib().cvhip_ctx_set_row_shard(self._h, num, den, cb, None), "cvhip_ctx_set_row_shard")
 
     def level_grid(self, direction: CorrelationDirection):
-        xy, corr = C.c_void_p(), C.c_void_p()
-        lw, lh, r0, r1 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        _lib.check(_lib.lib().cvhip_ctx_level_grid(self._h, int(direction), C.byref(xy), C.byref(corr), C.byref(lw),
-                                                   C.byref(lh), C.byref(r0), C.byref(r1)), "cvhip_ctx_level_grid")
-        return {"xy": xy.value, "corr": corr.value, "lw": lw.value, "lh": lh.value, "row0": r0.value,
-                "row1": r1.value}
+        cells = C.c_void_p()
+        lw, lh, r0, r1, rps = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(_lib.lib().cvhip_ctx_level_grid(self._h, int(direction), C.byref(cells), C.byref(lw), C.byref(lh),
+                                                   C.byref(r0), C.byref(r1), C.byref(rps)), "cvhip_ctx_level_grid")
+        return {"cells": cells.value, "lw": lw.value, "lh": lh.value, "row0": r0.value, "row1": r1.value,
+                "rows_per_shard": rps.value}
 
     def close(self):
         if getattr(self, "_h", None):

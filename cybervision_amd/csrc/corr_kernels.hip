@@ -148,7 +148,7 @@ void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float2 *sta
 // One thread per searched pixel; writes start | end << 16, or RANGE_NONE.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const float2 *__restrict__ stats1,
-                                                            const uint32_t *__restrict__ prev_xy,
+                                                            const uint2 *__restrict__ prev,
                                                             uint32_t *__restrict__ range)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
                 uint32_t neighbor_count = 0;
                 for (uint32_t yy = ys0; yy < ys1; yy++) {
                     for (uint32_t xx = xs0; xx < xs1; xx++) {
-                        const uint32_t cell = prev_xy[(size_t)yy * p.pw + xx];
+                        const uint32_t cell = prev[(size_t)yy * p.pw + xx].x;
                         if (cell == CELL_NONE) continue;
                         const double p2x = dscale * (double)((cell & 0xFFFFu) << p.pk);
                         const double p2y = dscale * (double)((cell >> 16) << p.pk);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
                     double range_stdev = 0.0;
                     for (uint32_t yy = ys0; yy < ys1; yy++) {
                         for (uint32_t xx = xs0; xx < xs1; xx++) {
-                            const uint32_t cell = prev_xy[(size_t)yy * p.pw + xx];
+                            const uint32_t cell = prev[(size_t)yy * p.pw + xx].x;
                             if (cell == CELL_NONE) continue;
                             const double p2x = dscale * (double)((cell & 0xFFFFu) << p.pk);
                             const double p2y = dscale * (double)((cell >> 16) << p.pk);
@@ -224,12 +224,12 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
     range[(size_t)y * p.w1 + x] = out;
 }
 
-void launch_search_range(const CorrParams &p, const float2 *stats1, const uint32_t *prev_xy, uint32_t *range,
+void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
                          hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
-    hipLaunchKernelGGL(search_range_kernel, grid, dim3(256), 0, s, p, stats1, prev_xy, range);
+    hipLaunchKernelGGL(search_range_kernel, grid, dim3(256), 0, s, p, stats1, prev, range);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
                                                       const float2 *__restrict__ stats1,
                                                       const float2 *__restrict__ stats2,
                                                       const uint32_t *__restrict__ range,
-                                                      uint32_t *__restrict__ out_xy, float *__restrict__ out_corr,
+                                                      uint2 *__restrict__ out,
                                                       unsigned long long *__restrict__ cand_counter)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -324,10 +324,7 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
             }
         }
     }
-    if (in_image) {
-        out_xy[(size_t)y * p.w1 + x] = best_xy;
-        out_corr[(size_t)y * p.w1 + x] = best_corr;
-    }
+    if (in_image) out[(size_t)y * p.w1 + x] = make_uint2(best_xy, __float_as_uint(best_corr));
     if (cand_counter) {
         // wave-level sum, one atomic per wave
         uint32_t v = evaluated;
@@ -338,13 +335,12 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
 }
 
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                   const float2 *stats2, const uint32_t *range, uint32_t *out_xy, float *out_corr,
-                   unsigned long long *cand_counter, hipStream_t s)
+                   const float2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
+                   hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
-    hipLaunchKernelGGL(search_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, stats2, range, out_xy, out_corr,
-                       cand_counter);
+    hipLaunchKernelGGL(search_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, stats2, range, out, cand_counter);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,14 +349,13 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
 // match (x2, y2) is the full-res match (x2, y2) << k, so the window test reduces to +-4 level
 // cells.  Each thread owns one cell of `own` and only reads `other`.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cross_check_kernel(uint32_t *__restrict__ own_xy, float *__restrict__ own_corr,
-                                                           const uint32_t *__restrict__ other_xy, uint32_t ow,
-                                                           uint32_t oh, uint32_t rw, uint32_t rh)
+__global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ own, const uint2 *__restrict__ other,
+                                                           uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= ow || y >= oh) return;
-    const uint32_t cell = own_xy[(size_t)y * ow + x];
+    const uint32_t cell = own[(size_t)y * ow + x].x;
     if (cell == CELL_NONE) return;
     const uint32_t sa = CROSS_CHECK_SEARCH_AREA;
     const uint32_t mx = cell & 0xFFFFu, my = cell >> 16;
@@ -371,7 +366,7 @@ __global__ __launch_bounds__(256) void cross_check_kernel(uint32_t *__restrict__
     bool found = false;
     for (uint32_t sy = min_y; sy < max_y && !found; sy++) {
         for (uint32_t sx = min_x; sx < max_x; sx++) {
-            const uint32_t rm = other_xy[(size_t)sy * rw + sx];
+            const uint32_t rm = other[(size_t)sy * rw + sx].x;
             if (rm == CELL_NONE) continue;
             const uint32_t rx = rm & 0xFFFFu, ry = rm >> 16;
             if (rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y) {
@@ -380,17 +375,14 @@ __global__ __launch_bounds__(256) void cross_check_kernel(uint32_t *__restrict__
             }
         }
     }
-    if (!found) {
-        own_xy[(size_t)y * ow + x] = CELL_NONE;
-        own_corr[(size_t)y * ow + x] = __builtin_nanf("");
-    }
+    if (!found) own[(size_t)y * ow + x] = make_uint2(CELL_NONE, 0x7FC00000u);
 }
 
-void launch_cross_check(uint32_t *own_xy, float *own_corr, const uint32_t *other_xy, uint32_t ow, uint32_t oh,
-                        uint32_t rw, uint32_t rh, hipStream_t s)
+void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
+                        hipStream_t s)
 {
     dim3 grid((ow + 63) / 64, (oh + 3) / 4);
-    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, own_xy, own_corr, other_xy, ow, oh, rw, rh);
+    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, own, other, ow, oh, rw, rh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,8 +390,7 @@ void launch_cross_check(uint32_t *own_xy, float *own_corr, const uint32_t *other
 // once at complete(): full-res cell (x << k, y << k) = level cell (x, y) with the match scaled
 // back by round(x2 / scale) = x2 << k.  All other full-res cells are None.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void expand_grid_kernel(const uint32_t *__restrict__ xy,
-                                                           const float *__restrict__ corr, uint32_t lw, uint32_t lh,
+__global__ __launch_bounds__(256) void expand_grid_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
                                                            uint32_t k, uint32_t gw, uint32_t gh,
                                                            int32_t *__restrict__ out_xy, float *__restrict__ out_corr)
 {
@@ -412,11 +403,11 @@ __global__ __launch_bounds__(256) void expand_grid_kernel(const uint32_t *__rest
     if ((gx & mask) == 0 && (gy & mask) == 0) {
         const uint32_t lx = gx >> k, ly = gy >> k;
         if (lx < lw && ly < lh) {
-            const uint32_t cell = xy[(size_t)ly * lw + lx];
-            if (cell != CELL_NONE) {
-                ox = (int32_t)((cell & 0xFFFFu) << k);
-                oy = (int32_t)((cell >> 16) << k);
-                oc = corr[(size_t)ly * lw + lx];
+            const uint2 c = cells[(size_t)ly * lw + lx];
+            if (c.x != CELL_NONE) {
+                ox = (int32_t)((c.x & 0xFFFFu) << k);
+                oy = (int32_t)((c.x >> 16) << k);
+                oc = __uint_as_float(c.y);
             }
         }
     }
@@ -425,11 +416,11 @@ __global__ __launch_bounds__(256) void expand_grid_kernel(const uint32_t *__rest
     if (out_corr) out_corr[o] = oc;
 }
 
-void launch_expand_grid(const uint32_t *xy, const float *corr, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw,
-                        uint32_t gh, int32_t *out_xy, float *out_corr, hipStream_t s)
+void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+                        int32_t *out_xy, float *out_corr, hipStream_t s)
 {
     dim3 grid((gw + 63) / 64, (gh + 3) / 4);
-    hipLaunchKernelGGL(expand_grid_kernel, grid, dim3(256), 0, s, xy, corr, lw, lh, k, gw, gh, out_xy, out_corr);
+    hipLaunchKernelGGL(expand_grid_kernel, grid, dim3(256), 0, s, cells, lw, lh, k, gw, gh, out_xy, out_corr);
 }
 
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, size_t n)

@@ -60,10 +60,8 @@ static void free_ctx_buffers(cvhip_ctx *c)
 {
     for (int d = 0; d < 2; d++) {
         for (int i = 0; i < 2; i++) {
-            if (c->dir[d].xy[i]) (void)hipFree(c->dir[d].xy[i]);
-            if (c->dir[d].corr[i]) (void)hipFree(c->dir[d].corr[i]);
-            c->dir[d].xy[i] = nullptr;
-            c->dir[d].corr[i] = nullptr;
+            if (c->dir[d].cells[i]) (void)hipFree(c->dir[d].cells[i]);
+            c->dir[d].cells[i] = nullptr;
         }
         if (c->img[d]) (void)hipFree(c->img[d]);
         if (c->stats[d]) (void)hipFree(c->stats[d]);
@@ -128,7 +126,7 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     shard_rows(c, lh1, &p.row0, &p.row1);
 
     const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
-    if (!first_pass) launch_search_range(p, c->stats[a], ds.xy[prev], c->range, s);
+    if (!first_pass) launch_search_range(p, c->stats[a], ds.cells[prev], c->range, s);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->time_kernels) {
@@ -143,7 +141,7 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         c->events_used++;
         CVHIP_TRY_HIP(hipEventRecord(e0, s));
     }
-    launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.xy[next], ds.corr[next],
+    launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.cells[next],
                   c->count_candidates ? c->d_cand : nullptr, s);
     if (c->time_kernels) CVHIP_TRY_HIP(hipEventRecord(e1, s));
     CVHIP_TRY_HIP(hipGetLastError());
@@ -163,7 +161,7 @@ static int cross_check_pass(cvhip_ctx *c, int k, int dir)
     if (!own.valid || !other.valid) return fail(CVHIP_ERR_INVALID, "cross_check_filter before both passes ran");
     if ((int)own.k != k || (int)other.k != k)
         return fail(CVHIP_ERR_INVALID, "cross_check_filter scale does not match the grids' current level");
-    launch_cross_check(own.xy[own.cur], own.corr[own.cur], other.xy[other.cur], own.lw, own.lh, other.lw, other.lh,
+    launch_cross_check(own.cells[own.cur], other.cells[other.cur], own.lw, own.lh, other.lw, other.lh,
                        c->dev->d.stream);
     CVHIP_TRY_HIP(hipGetLastError());
     return CVHIP_OK;
@@ -200,7 +198,14 @@ extern "C" {
 const char *cvhip_last_error(void) { return g_last_error.c_str(); }
 uint32_t cvhip_abi_version(void) { return 1; }
 
+int cvhip_device_create_on_stream(int low_power, int ordinal, void *hip_stream, cvhip_device **out);
+
 int cvhip_device_create(int low_power, int ordinal, cvhip_device **out)
+{
+    return cvhip_device_create_on_stream(low_power, ordinal, nullptr, out);
+}
+
+int cvhip_device_create_on_stream(int low_power, int ordinal, void *hip_stream, cvhip_device **out)
 {
     if (!out) return fail(CVHIP_ERR_INVALID, "out is null");
     *out = nullptr;
@@ -217,10 +222,15 @@ int cvhip_device_create(int low_power, int ordinal, cvhip_device **out)
     dev->d.ordinal = ordinal;
     dev->d.low_power = low_power;
     dev->d.name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-    hipError_t e = hipStreamCreateWithFlags(&dev->d.stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete dev;
-        return fail(CVHIP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    if (hip_stream) { // caller's stream (e.g. torch's current stream): work is ordered with the caller's
+        dev->d.stream = reinterpret_cast<hipStream_t>(hip_stream);
+        dev->d.owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&dev->d.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete dev;
+            return fail(CVHIP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
     }
     *out = dev;
     return CVHIP_OK;
@@ -232,7 +242,7 @@ void cvhip_device_destroy(cvhip_device *dev)
     (void)hipSetDevice(dev->d.ordinal);
     if (dev->d.stream) {
         (void)hipStreamSynchronize(dev->d.stream);
-        (void)hipStreamDestroy(dev->d.stream);
+        if (dev->d.owns_stream) (void)hipStreamDestroy(dev->d.stream);
     }
     delete dev;
 }
@@ -292,10 +302,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     hipError_t e = hipSuccess;
     for (int d = 0; d < 2 && e == hipSuccess; d++) {
         const size_t ge = grid_elems(c->dir[d].gw, c->dir[d].gh);
-        for (int i = 0; i < 2 && e == hipSuccess; i++) {
-            e = hipMalloc(&c->dir[d].xy[i], ge * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMalloc(&c->dir[d].corr[i], ge * sizeof(float));
-        }
+        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
         if (e == hipSuccess) e = hipMalloc(&c->stats[d], c->max_px * sizeof(float2));
     }
@@ -361,8 +368,13 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
 {
     int k = 0;
     CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
-    if (ctx->shard_den != 1)
-        return fail(CVHIP_ERR_UNSUPPORTED, "cvhip_correlate_level on a row-sharded context: use the per-pass calls");
+    // Shard this level only if every rank gets a useful band; tiny levels are computed whole on
+    // every rank (identical results, no collective).  The rule depends on level dims only, so all
+    // ranks take the same branch.
+    const uint32_t den = ctx->shard_den, num = ctx->shard_num;
+    const bool sharded = den > 1 && std::min(h1, h2) / den >= 64;
+    if (sharded && !ctx->gather)
+        return fail(CVHIP_ERR_INVALID, "row-sharded context without an all-gather hook (cvhip_ctx_set_row_shard)");
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s));
@@ -370,9 +382,28 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     launch_window_stats(ctx->img[0], w1, h1, ctx->stats[0], s);
     launch_window_stats(ctx->img[1], w2, h2, ctx->stats[1], s);
     report(progress, user, 0, 0.20f);
-    CVHIP_TRY(search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0)); // mod.rs:224-230
+    if (!sharded) {
+        ctx->shard_num = 0;
+        ctx->shard_den = 1;
+    }
+    int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0); // mod.rs:224-230
+    if (rc == CVHIP_OK && sharded) {
+        const DirState &ds = ctx->dir[0];
+        const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);
+        if (ctx->gather(ctx->gather_user, ds.cells[ds.cur], shard_bytes, den, 0) != 0)
+            rc = fail(CVHIP_ERR_DEVICE, "all-gather hook failed (forward grid)");
+    }
     report(progress, user, 0, 1.0f);
-    CVHIP_TRY(search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1)); // mod.rs:231-237
+    if (rc == CVHIP_OK) rc = search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1); // mod.rs:231-237
+    if (rc == CVHIP_OK && sharded) {
+        const DirState &ds = ctx->dir[1];
+        const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);
+        if (ctx->gather(ctx->gather_user, ds.cells[ds.cur], shard_bytes, den, 1) != 0)
+            rc = fail(CVHIP_ERR_DEVICE, "all-gather hook failed (reverse grid)");
+    }
+    ctx->shard_num = num;
+    ctx->shard_den = den;
+    CVHIP_TRY(rc);
     report(progress, user, 1, 1.0f);
     CVHIP_TRY(cross_check_pass(ctx, k, 0)); // mod.rs:239
     CVHIP_TRY(cross_check_pass(ctx, k, 1)); // mod.rs:240
@@ -401,7 +432,7 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
         }
     }
     if (ds.valid) {
-        launch_expand_grid(ds.xy[ds.cur], ds.corr[ds.cur], ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy, d_corr, s);
+        launch_expand_grid(ds.cells[ds.cur], ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy, d_corr, s);
     } else { // nothing computed: all None, like a fresh Grid (mod.rs:183-184)
         launch_fill_u32(reinterpret_cast<uint32_t *>(d_xy), 0xFFFFFFFFu, n * 2, s);
         if (d_corr) launch_fill_u32(reinterpret_cast<uint32_t *>(d_corr), 0x7FC00000u, n, s);
@@ -422,30 +453,32 @@ int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr)
     return cvhip_complete_dir(ctx, 0, out_xy, out_corr);
 }
 
-int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den)
+int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_allgather_fn gather, void *user)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
     if (den == 0 || den > 64 || num >= den) return fail(CVHIP_ERR_INVALID, "need 0 <= num < den <= 64");
     ctx->shard_num = num;
     ctx->shard_den = den;
+    ctx->gather = gather;
+    ctx->gather_user = user;
     return CVHIP_OK;
 }
 
-int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **xy, void **corr, uint32_t *lw, uint32_t *lh,
-                         uint32_t *row0, uint32_t *row1)
+int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, uint32_t *lh, uint32_t *row0,
+                         uint32_t *row1, uint32_t *rows_per_shard)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
     DirState &ds = ctx->dir[dir];
     if (!ds.valid) return fail(CVHIP_ERR_INVALID, "no level computed yet");
-    if (xy) *xy = ds.xy[ds.cur];
-    if (corr) *corr = ds.corr[ds.cur];
+    if (cells) *cells = ds.cells[ds.cur];
     if (lw) *lw = ds.lw;
     if (lh) *lh = ds.lh;
     uint32_t r0, r1;
     shard_rows(ctx, ds.lh, &r0, &r1);
     if (row0) *row0 = r0;
     if (row1) *row1 = r1;
+    if (rows_per_shard) *rows_per_shard = (ds.lh + ctx->shard_den - 1) / ctx->shard_den;
     return CVHIP_OK;
 }
 

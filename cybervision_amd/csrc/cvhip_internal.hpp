@@ -36,7 +36,8 @@ constexpr int KERNEL_POINT_COUNT = 121;
 constexpr int NEIGHBOR_DISTANCE = 10;
 constexpr int CROSS_CHECK_SEARCH_AREA = 4;
 
-constexpr uint32_t CELL_NONE = 0xFFFFFFFFu;  // packed level-grid cell: x | y << 16, or None
+// Level-grid cell = uint2 {x | y << 16 in LEVEL coordinates (or CELL_NONE), f32 score bits}.
+constexpr uint32_t CELL_NONE = 0xFFFFFFFFu;
 constexpr uint32_t RANGE_NONE = 0xFFFFFFFFu; // packed corridor range: start | end << 16, or None
 constexpr size_t IMG_PAD = 64;               // bytes readable past the end of every image buffer
 
@@ -57,28 +58,28 @@ struct CorrParams {
 
 // ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------
 void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float2 *stats, hipStream_t s);
-void launch_search_range(const CorrParams &p, const float2 *stats1, const uint32_t *prev_xy, uint32_t *range,
+void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
                          hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                   const float2 *stats2, const uint32_t *range, uint32_t *out_xy, float *out_corr,
-                   unsigned long long *cand_counter, hipStream_t s);
-void launch_cross_check(uint32_t *own_xy, float *own_corr, const uint32_t *other_xy, uint32_t ow, uint32_t oh,
-                        uint32_t rw, uint32_t rh, hipStream_t s);
-void launch_expand_grid(const uint32_t *xy, const float *corr, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw,
-                        uint32_t gh, int32_t *out_xy, float *out_corr, hipStream_t s);
+                   const float2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
+                   hipStream_t s);
+void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
+                        hipStream_t s);
+void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+                        int32_t *out_xy, float *out_corr, hipStream_t s);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 
 // ---- handles --------------------------------------------------------------------------------
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     std::string name;
     int low_power = 0;
 };
 
 struct DirState {
-    uint32_t *xy[2] = {nullptr, nullptr}; // ping-pong level grids (packed cells)
-    float *corr[2] = {nullptr, nullptr};
+    uint2 *cells[2] = {nullptr, nullptr}; // ping-pong compact level grids
     int cur = 0;        // index of the grid holding the most recent level
     bool valid = false; // a level has been computed
     uint32_t lw = 0, lh = 0, k = 0;
@@ -108,6 +109,8 @@ struct cvhip_ctx {
     size_t max_px = 0;
 
     uint32_t shard_num = 0, shard_den = 1;
+    cvhip_allgather_fn gather = nullptr;
+    void *gather_user = nullptr;
 
     int time_kernels = 0, count_candidates = 0;
     unsigned long long *d_cand = nullptr;

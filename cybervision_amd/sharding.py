@@ -1,0 +1,66 @@
+"""Row sharding of the dense-correlation level grids across ranks (one process per GPU).
+
+Every (level, direction) search pass is embarrassingly parallel over rows of the searched
+image (reference: each closure of the rayon loop writes only its own cell,
+correlation/mod.rs:288-304), so rank r searches rows [r*rps, (r+1)*rps) and the bands are
+all-gathered in place; cross-checks then run redundantly on the full grid.  There is no
+reduction across ranks, so the N-rank result is bit-identical to the 1-rank result.
+
+The collective is torch.distributed's all-gather: backend "nccl" (= RCCL over xGMI) for device
+memory, "gloo" for the CPU tests.  The library hands us a raw pointer; we alias it as a tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+
+def rows_per_shard(lh: int, den: int) -> int:
+    return (lh + den - 1) // den
+
+
+def shard_rows(lh: int, num: int, den: int):
+    """Same rule as cvhip_ctx_set_row_shard (include/cvhip.h)."""
+    rps = rows_per_shard(lh, den)
+    r0 = min(lh, num * rps)
+    return r0, min(lh, r0 + rps)
+
+
+def level_is_sharded(h1: int, h2: int, den: int) -> bool:
+    """cvhip_correlate_level shards a level only if every rank gets >= 64 rows."""
+    return den > 1 and min(h1, h2) // den >= 64
+
+
+class _DeviceBytes:
+    """Expose [ptr, ptr + nbytes) of device memory through __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def alias_bytes(ptr: int, nbytes: int, device: bool):
+    """A uint8 torch tensor aliasing raw memory (device or host)."""
+    import torch
+
+    if device:
+        return torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return torch.from_numpy(np.ctypeslib.as_array(buf))
+
+
+def make_allgather(rank: int, world: int, group=None, device: bool = True):
+    """gather(cells_ptr, shard_bytes, n_shards, direction) for PointCorrelations.set_row_shard."""
+    import torch.distributed as dist
+
+    def gather(cells_ptr: int, shard_bytes: int, n_shards: int, direction: int):
+        assert n_shards == world
+        full = alias_bytes(cells_ptr, shard_bytes * n_shards, device)
+        mine = full[rank * shard_bytes:(rank + 1) * shard_bytes]
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(full, mine, group=group)  # in place: mine is full's rank-th chunk
+        else:
+            outs = [full[r * shard_bytes:(r + 1) * shard_bytes] for r in range(n_shards)]
+            dist.all_gather(outs, mine.clone(), group=group)
+
+    return gather

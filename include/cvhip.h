@@ -59,6 +59,10 @@ uint32_t cvhip_abi_version(void);
 /* low_power mirrors HardwareMode::GpuLowPower (mod.rs:50-54); accepted and ignored (no
  * dispatch segmenting is needed on MI355X).  ordinal < 0 = HIP's current device. */
 int cvhip_device_create(int low_power, int ordinal, cvhip_device **out);
+/* Same, but all work is submitted to the caller's HIP stream (a hipStream_t passed as void*,
+ * e.g. torch.cuda.current_stream().cuda_stream) so it is ordered with the caller's own work
+ * (collectives between passes when row-sharding).  The stream is not owned by the library. */
+int cvhip_device_create_on_stream(int low_power, int ordinal, void *hip_stream, cvhip_device **out);
 void cvhip_device_destroy(cvhip_device *dev);
 /* DeviceContext::get_device_name (gpu/mod.rs:70). Valid until cvhip_device_destroy. */
 const char *cvhip_device_name(const cvhip_device *dev);
@@ -105,16 +109,29 @@ int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr);
 /* Same for either direction (dir 1 = correlated_points_reverse, mod.rs:65); test hook. */
 int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr);
 
-/* Row sharding (multi-GPU): restrict the search passes of this context to level rows
- * [floor(h_level*num/den), floor(h_level*(num+1)/den)) of the searched image.  Rows outside
- * the band keep whatever the level grid holds (the host fills them with an all-gather).
- * num = 0, den = 1 (default) = all rows. */
-int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den);
-/* Device pointers + geometry of direction `dir`'s current level grid, for collectives done
- * by the host (RCCL all-gather of row bands).  xy: packed u32 per level pixel
- * (x | y << 16 in LEVEL coordinates, 0xFFFFFFFF = None), corr: float per level pixel. */
-int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **xy, void **corr, uint32_t *lw, uint32_t *lh,
-                         uint32_t *row0, uint32_t *row1);
+/* All-gather hook for row sharding: called by cvhip_correlate_level after each sharded search
+ * pass, on the calling thread.  `cells` is the device pointer of the level grid of direction
+ * `dir`; shard r (0 <= r < n_shards) owns bytes [r*shard_bytes, (r+1)*shard_bytes).  The hook
+ * must all-gather in place (e.g. ncclAllGather / torch.distributed.all_gather_into_tensor on
+ * the stream given to cvhip_device_create_on_stream) and return 0, or non-zero to abort. */
+typedef int (*cvhip_allgather_fn)(void *user, void *cells, uint64_t shard_bytes, uint32_t n_shards, int dir);
+
+/* Row sharding (multi-GPU): restrict the SEARCH passes of this context to shard `num` of `den`
+ * equal row chunks of the searched level image: rows [num*rps, min((num+1)*rps, h_level)) with
+ * rps = ceil(h_level / den).  Rows outside the band keep whatever the level grid holds until
+ * the bands are all-gathered; the cross-checks then run on the whole grid on every rank, so
+ * every rank ends with the complete, identical result (no reduction across ranks: N-GPU output
+ * is bit-identical to 1-GPU output).  cvhip_correlate_level calls `gather` itself (levels with
+ * fewer than 64 rows per shard are simply computed whole on every rank); with the per-pass
+ * calls the host gathers between passes (cvhip_ctx_level_grid).  num = 0, den = 1 (default) =
+ * all rows; den <= 64; gather may be NULL when only the per-pass calls are used. */
+int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_allgather_fn gather, void *user);
+/* Device pointer + geometry of direction `dir`'s current level grid, for the host's
+ * collectives.  One 8-byte cell per level pixel, row-major lw x lh: u32 x | y << 16 in LEVEL
+ * coordinates (0xFFFFFFFF = None) followed by the f32 score.  The buffer always has room for
+ * den * rows_per_shard rows, so bands can be gathered in equal chunks. */
+int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, uint32_t *lh, uint32_t *row0,
+                         uint32_t *row1, uint32_t *rows_per_shard);
 
 /* Measurement hooks (bench.py): when enabled, every search-kernel launch is bracketed by HIP
  * events on the context's stream and evaluated candidates are counted on the device. */
