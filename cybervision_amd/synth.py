@@ -86,13 +86,13 @@ def make_pair(width: int, height: int | None = None, seed: int = 1234, sem_style
     t1 = texture(xs, ys, seed)
     t2 = texture(xs + d, ys + 0 * xs, seed)
     if sem_style:
-        # linear shading ramp of +-16 grey levels and 2 % salt noise, both integer
+        # linear shading ramp of +-16 grey levels and 0.2 % salt noise (independent per image), both integer
         ramp = ((xs * 32) // max(width, 1)) - 16
         t1 = t1 + ramp
         t2 = t2 + ramp
         for t, s in ((t1, seed + 1), (t2, seed + 2)):
             h = hash32(xs + 0 * ys, ys + 0 * xs, s)
-            salt = (h % np.uint64(50)) == 0
+            salt = (h % np.uint64(500)) == 0
             t[salt] = 255
     img1 = np.clip(t1, 0, 255).astype(np.uint8)
     img2 = np.clip(t2, 0, 255).astype(np.uint8)
