@@ -1,13 +1,798 @@
-// orb_kernels.hip — placeholder until the ORB / matcher kernels land (next commits).
+// orb_kernels.hip — ORB keypoint extraction and brute-force descriptor matching for gfx950.
+//
+// Replaces orb::extract_points (zlogic/cybervision src/orb.rs:50-84) and
+// KeypointMatching::match_points (src/pointmatching.rs:43-77).  Stage by stage:
+//
+//   minmax + contrast    adjust_contrast            orb.rs:455-472   (u8, one f32 multiply + round)
+//   fast_score           find_fast_keypoints        orb.rs:86-135    FAST-9 + score, closed form
+//   nms + compaction     find_fast_keypoints        orb.rs:138-187   3x3 NMS, scan-ordered list
+//   harris               harris_response            orb.rs:230-269   f64, incl. the 7-wide Sobel quirk
+//   sort (stable, desc)  extract_points             orb.rs:76-81     radix sort on ordered f64 bits
+//   blur                 gaussian_blur<11>          orb.rs:271-314   separable f64, serial tap order
+//   moments              get_brief_orientation      orb.rs:316-344   integer moments (exact)
+//   (host)               atan2 / sin / cos          orb.rs:341,365   libm, exactly as the reference
+//   brief                extract_brief_descriptors  orb.rs:346-405   f64 rotation, ballot-packed bits
+//
+// Integer stages are exact by construction; every f64 stage keeps the reference's serial
+// operation order with contraction off, so keypoint coordinates AND descriptors are
+// bit-identical to --mode=cpu.  Transcendentals stay on the host because device libm is not
+// bit-identical to glibc.
 #include "cvhip_internal.hpp"
-using namespace cvhip;
-extern "C" int cvhip_orb_extract(cvhip_device *, const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t *,
-                                 uint32_t *, uint32_t *)
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <vector>
+
+#include "orb_pattern.inc"
+
+namespace cvhip {
+
+constexpr int FAST_KERNEL_SIZE = 3;
+constexpr int FAST_THRESHOLD = 15;
+constexpr int HARRIS_KERNEL_SIZE = 3;
+constexpr int HARRIS_KERNEL_WIDTH = 7;
+constexpr double HARRIS_K = 0.04;
+constexpr int ORB_GAUSS_KERNEL_WIDTH = 11;
+constexpr int ORB_PATCH_WIDTH = 31;
+constexpr int ORB_PATCH_SIZE = 15;
+constexpr uint32_t MAX_KEYPOINTS = 10000;
+
+struct Taps7 {
+    double k[7];
+};
+struct Taps11 {
+    double k[11];
+};
+
+// ---------------------------------------------------------------------------------------------
+// adjust_contrast (orb.rs:455-472)
+// ---------------------------------------------------------------------------------------------
+__global__ void minmax_kernel(const uint8_t *__restrict__ img, size_t n, uint32_t *__restrict__ mm)
 {
-    return fail(CVHIP_ERR_UNSUPPORTED, "cvhip_orb_extract: not implemented yet");
+    uint32_t lo = 255, hi = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = img[i];
+        lo = min(lo, v);
+        hi = max(hi, v);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_down(lo, s, 64));
+        hi = max(hi, (uint32_t)__shfl_down(hi, s, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
 }
-extern "C" int cvhip_match_points(cvhip_device *, const uint32_t *, const uint32_t *, uint32_t, const uint32_t *,
-                                  const uint32_t *, uint32_t, uint32_t, uint32_t *, uint32_t *, uint32_t *)
+
+__global__ void contrast_kernel(const uint8_t *__restrict__ img, size_t n, const uint32_t *__restrict__ mm,
+                                uint8_t *__restrict__ out)
 {
-    return fail(CVHIP_ERR_UNSUPPORTED, "cvhip_match_points: not implemented yet");
+    const uint32_t lo = mm[0], hi = mm[1];
+    const bool identity = lo >= hi;
+    const float coeff = identity ? 1.0f : 255.0f / (float)(hi - lo);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t v = img[i];
+        uint32_t o = v;
+        if (!identity) {
+            const float r = roundf(coeff * (float)(v - lo));
+            o = r >= 255.0f ? 255u : (r > 0.0f ? (uint32_t)r : 0u); // `as u8` saturates
+        }
+        out[i] = (uint8_t)o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9 score (orb.rs:86-135, is_keypoint :424-453).
+// is_keypoint(t) <=> some circular run of >= 9 ring pixels is brighter than v + t, or darker
+// than v - t.  With d_i = c_i - v:  brighter run at t  <=>  max_s min_{j<9} d_{s+j} > t, and
+// symmetrically for darker.  The reference's bisection (orb.rs:122-133) returns the largest t in
+// [15, 254] for which is_keypoint holds (is_keypoint is monotone in t), i.e. M - 1 with
+// M = max(best_brighter, best_darker).  score plane: 0 = not a corner, else that threshold.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ring_best_min9(const int (&d)[16])
+{
+    int m1[16], m2[16], m4[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m1[i] = min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) m2[i] = min(m1[i], m1[(i + 2) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) m4[i] = min(m2[i], m2[(i + 4) & 15]);
+    int best = -1000;
+#pragma unroll
+    for (int i = 0; i < 16; i++) best = max(best, min(m4[i], d[(i + 8) & 15]));
+    return best;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+                                                          uint8_t *__restrict__ score)
+{
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    uint32_t out = 0;
+    if (x >= FAST_KERNEL_SIZE && y >= FAST_KERNEL_SIZE && x + FAST_KERNEL_SIZE < w && y + FAST_KERNEL_SIZE < h) {
+        const int ox[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+        const int oy[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+        const int v = img[(size_t)y * w + x];
+        int d[16], nd[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            d[i] = (int)img[(size_t)(y + oy[i]) * w + (x + ox[i])] - v;
+            nd[i] = -d[i];
+        }
+        const int m = max(ring_best_min9(d), ring_best_min9(nd));
+        if (m - 1 >= FAST_THRESHOLD) out = (uint32_t)min(m - 1, 254);
+    }
+    score[(size_t)y * w + x] = (uint8_t)out;
+}
+
+// 3x3 non-maximum suppression (orb.rs:138-187): a corner is dropped when any of its eight
+// neighbours is a corner with score >= its own.
+__device__ __forceinline__ bool nms_survives(const uint8_t *__restrict__ score, uint32_t w, uint32_t h, uint32_t x,
+                                             uint32_t y)
+{
+    const uint32_t s = score[(size_t)y * w + x];
+    if (s == 0) return false;
+    // corners only exist for 3 <= x < w-3, 3 <= y < h-3, so the 3x3 neighbourhood is in bounds
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            if (score[(size_t)(y + dy) * w + (x + dx)] >= s) return false;
+        }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ordered (scan-order) stream compaction helpers: block counts -> exclusive scan -> write
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_count_kernel(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
+                                                         uint32_t *__restrict__ block_counts)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)w * h;
+    bool f = false;
+    if (i < n) f = nms_survives(score, w, h, (uint32_t)(i % w), (uint32_t)(i / w));
+    __shared__ uint32_t wsum[4];
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// single-block exclusive scan over n values (in place); total written to *total
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(uint32_t *__restrict__ data, uint32_t n,
+                                                               uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? data[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t t = __shfl_up(incl, s, 64);
+            if ((int)(threadIdx.x & 63) >= s) incl += t;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < n) data[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void nms_write_kernel(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
+                                                         const uint32_t *__restrict__ block_offsets, uint32_t cap,
+                                                         uint32_t *__restrict__ out_xy)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)w * h;
+    bool f = false;
+    uint32_t x = 0, y = 0;
+    if (i < n) {
+        x = (uint32_t)(i % w);
+        y = (uint32_t)(i / w);
+        f = nms_survives(score, w, h, x, y);
+    }
+    __shared__ uint32_t wsum[4];
+    const unsigned long long b = __ballot(f);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (f) {
+        uint32_t off = block_offsets[blockIdx.x];
+        for (uint32_t k = 0; k < wv; k++) off += wsum[k];
+        off += (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (off < cap) {
+            out_xy[2 * (size_t)off] = x;
+            out_xy[2 * (size_t)off + 1] = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Harris response (orb.rs:204-269), one thread per FAST corner, on the ORIGINAL image.
+// Keeps the reference's quirk: convolve_kernel::<7, 9> indexes the nine Sobel taps with width 7,
+// so they sample (x-3..x+3, y-3), (x-3, y-2), (x-2, y-2).  key = order-preserving u64 of the f64
+// response (for a descending stable radix sort); None (too close to the edge) -> key 0, which
+// sorts after every real response.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long f64_order_key(double v)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(64) void harris_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+                                                     const uint32_t *__restrict__ kp_xy,
+                                                     const uint32_t *__restrict__ n_ptr, uint32_t cap, Taps7 kg,
+                                                     unsigned long long *__restrict__ keys,
+                                                     uint32_t *__restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n = min(*n_ptr, cap);
+    if (i >= cap) return;
+    if (i >= n) {
+        keys[i] = 0ull;
+        idx[i] = 0xFFFFFFFFu;
+        return;
+    }
+    const double sobel_x[9] = {-1.0, 0.0, 1.0, -2.0, 0.0, 2.0, -1.0, 0.0, 1.0};
+    const double sobel_y[9] = {-1.0, -2.0, -1.0, 0.0, 0.0, 0.0, 1.0, 2.0, 1.0};
+    const uint32_t x = kp_xy[2 * (size_t)i], y = kp_xy[2 * (size_t)i + 1];
+    const uint32_t ks = HARRIS_KERNEL_WIDTH / 2;
+    // every sample point (x + k_x - 3, y + k_y - 3) must itself pass convolve_kernel's bounds check
+    bool ok = x >= 2 * ks && y >= 2 * ks && x + 2 * ks < w && y + 2 * ks < h;
+    unsigned long long key = 0ull;
+    if (ok) {
+        double g_dx2 = 0.0, g_dy2 = 0.0, g_dx_dy = 0.0;
+        for (int k_y = 0; k_y < HARRIS_KERNEL_WIDTH; k_y++) {
+            for (int k_x = 0; k_x < HARRIS_KERNEL_WIDTH; k_x++) {
+                const uint32_t px = x + k_x - HARRIS_KERNEL_SIZE, py = y + k_y - HARRIS_KERNEL_SIZE;
+                double dx = 0.0, dy = 0.0;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    const int tx = t % HARRIS_KERNEL_WIDTH, ty = t / HARRIS_KERNEL_WIDTH;
+                    const double v = (double)img[(size_t)(py + ty - ks) * w + (px + tx - ks)];
+                    dx += sobel_x[t] * v / 255.0;
+                    dy += sobel_y[t] * v / 255.0;
+                }
+                const double gauss_mul = kg.k[k_x] * kg.k[k_y];
+                g_dx2 += dx * dx * gauss_mul;
+                g_dy2 += dy * dy * gauss_mul;
+                g_dx_dy += dx * dy * gauss_mul;
+            }
+        }
+        const double det = g_dx2 * g_dy2 - g_dx_dy * g_dx_dy;
+        const double trace = g_dx2 + g_dy2;
+        key = f64_order_key(det - HARRIS_K * (trace * trace));
+    }
+    keys[i] = key;
+    idx[i] = ok ? i : 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gaussian_blur<11> (orb.rs:271-314): horizontal then vertical, f64, taps added in index order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+                                                      Taps11 kg, double *__restrict__ out)
+{
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const uint32_t ks = ORB_GAUSS_KERNEL_WIDTH / 2;
+    double sum = 0.0;
+    if (x >= ks && x + ks < w && y >= ks && y + ks < h) {
+#pragma unroll
+        for (int i = 0; i < ORB_GAUSS_KERNEL_WIDTH; i++) sum += kg.k[i] * (double)img[(size_t)y * w + (x + i - ks)];
+    }
+    out[(size_t)y * w + x] = sum;
+}
+__global__ __launch_bounds__(256) void blur_v_kernel(const double *__restrict__ in, uint32_t w, uint32_t h, Taps11 kg,
+                                                      double *__restrict__ out)
+{
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const uint32_t ks = ORB_GAUSS_KERNEL_WIDTH / 2;
+    double sum = 0.0;
+    if (x >= ks && x + ks < w && y >= 2 * ks && y + 2 * ks < h) {
+#pragma unroll
+        for (int i = 0; i < ORB_GAUSS_KERNEL_WIDTH; i++) sum += kg.k[i] * in[(size_t)(y + i - ks) * w + x];
+    }
+    out[(size_t)y * w + x] = sum;
+}
+// Some(...) cells of the blurred grid.  QUIRK (orb.rs:293): the second grid is allocated
+// width x width, so rows >= width do not exist.
+__device__ __forceinline__ bool blur_valid(uint32_t w, uint32_t h, uint32_t x, uint32_t y)
+{
+    const uint32_t ks = ORB_GAUSS_KERNEL_WIDTH / 2;
+    return x >= ks && x + ks < w && y >= 2 * ks && y + 2 * ks < h && y < w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// patch moments (orb.rs:316-339): one wave per ranked keypoint.  Integer sums are exact, so the
+// wave-parallel reduction equals the reference's serial loop.  out = (m00, m10, m01, valid).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void moments_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
+                                                      const uint32_t *__restrict__ kp_xy,
+                                                      const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                      unsigned long long *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= count) return;
+    const uint32_t src = sorted_idx[r];
+    const uint32_t lane = threadIdx.x;
+    unsigned long long m00 = 0, m10 = 0, m01 = 0;
+    bool ok = src != 0xFFFFFFFFu;
+    uint32_t x = 0, y = 0;
+    if (ok) {
+        x = kp_xy[2 * (size_t)src];
+        y = kp_xy[2 * (size_t)src + 1];
+        const uint32_t bh = w; // blurred grid height (quirk)
+        ok = x >= ORB_PATCH_SIZE && y >= ORB_PATCH_SIZE && x + ORB_PATCH_SIZE < w && y + ORB_PATCH_SIZE < bh;
+    }
+    if (ok) {
+        bool all_some = true;
+        for (uint32_t c = lane; c < ORB_PATCH_WIDTH * ORB_PATCH_WIDTH; c += 64) {
+            const uint32_t m_x = c % ORB_PATCH_WIDTH, m_y = c / ORB_PATCH_WIDTH;
+            const uint32_t s_x = x + m_x - ORB_PATCH_SIZE, s_y = y + m_y - ORB_PATCH_SIZE;
+            if (!blur_valid(w, h, s_x, s_y)) {
+                all_some = false;
+                continue;
+            }
+            const double v = blur[(size_t)s_y * w + s_x];
+            const double cl = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+            const unsigned long long val = (unsigned long long)cl; // truncation, `as usize`
+            m00 += val;
+            m10 += (unsigned long long)s_x * val;
+            m01 += (unsigned long long)s_y * val;
+        }
+        ok = __all(all_some);
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            m00 += __shfl_down(m00, s, 64);
+            m10 += __shfl_down(m10, s, 64);
+            m01 += __shfl_down(m01, s, 64);
+        }
+    }
+    if (lane == 0) {
+        out[4 * (size_t)r + 0] = m00;
+        out[4 * (size_t)r + 1] = m10;
+        out[4 * (size_t)r + 2] = m01;
+        out[4 * (size_t)r + 3] = ok ? 1ull : 0ull;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rotated BRIEF (orb.rs:363-402): one wave per ranked keypoint, four pair tests per lane; the
+// 64-bit ballot of test j*64+lane yields descriptor words 2j and 2j+1 directly.
+// ---------------------------------------------------------------------------------------------
+struct Pattern {
+    signed char v[1024];
+};
+__device__ __forceinline__ long long f64_to_i64_sat(double v)
+{
+    if (v != v) return 0;
+    if (v >= 9.2e18) return 0x7FFFFFFFFFFFFFFFll;
+    if (v <= -9.2e18) return (long long)0x8000000000000000ull;
+    return (long long)v;
+}
+__device__ __forceinline__ unsigned long long sat_add_signed(unsigned long long a, long long b)
+{
+    if (b >= 0) {
+        const unsigned long long r = a + (unsigned long long)b;
+        return r < a ? ~0ull : r;
+    }
+    const unsigned long long nb = (unsigned long long)(-(b + 1)) + 1ull;
+    return a > nb ? a - nb : 0ull;
+}
+
+__global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
+                                                    const uint32_t *__restrict__ kp_xy,
+                                                    const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                    const double *__restrict__ sincos,
+                                                    const signed char *__restrict__ pattern,
+                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ flags)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= count) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t src = sorted_idx[r];
+    const double angle_sin = sincos[3 * (size_t)r + 0], angle_cos = sincos[3 * (size_t)r + 1];
+    bool ok = src != 0xFFFFFFFFu && sincos[3 * (size_t)r + 2] != 0.0;
+    uint32_t cx = 0, cy = 0;
+    if (ok) {
+        cx = kp_xy[2 * (size_t)src];
+        cy = kp_xy[2 * (size_t)src + 1];
+    }
+    const uint32_t bh = w; // blurred grid height (quirk)
+    bool fail = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = j * 64 + (int)lane;
+        const double o1x = (double)pattern[4 * i + 0], o1y = (double)pattern[4 * i + 1];
+        const double o2x = (double)pattern[4 * i + 2], o2y = (double)pattern[4 * i + 3];
+        // x/y roles as in the reference (orb.rs:371-378)
+        const long long off1x = f64_to_i64_sat(round(o1y * angle_cos - o1x * angle_sin));
+        const long long off1y = f64_to_i64_sat(round(o1y * angle_sin + o1x * angle_cos));
+        const long long off2x = f64_to_i64_sat(round(o2y * angle_cos - o2x * angle_sin));
+        const long long off2y = f64_to_i64_sat(round(o2y * angle_sin + o2x * angle_cos));
+        const unsigned long long p1x = sat_add_signed(cx, off1x), p1y = sat_add_signed(cy, off1y);
+        const unsigned long long p2x = sat_add_signed(cx, off2x), p2y = sat_add_signed(cy, off2y);
+        bool bad = p1x == 0 || p2x == 0 || p1x + 1 >= w || p2x + 1 >= w || p1y + 1 >= bh || p2y + 1 >= bh;
+        bool tau = false;
+        if (ok && !bad) {
+            if (!blur_valid(w, h, (uint32_t)p1x, (uint32_t)p1y) || !blur_valid(w, h, (uint32_t)p2x, (uint32_t)p2y)) {
+                bad = true;
+            } else {
+                const double v1 = blur[(size_t)p1y * w + p1x], v2 = blur[(size_t)p2y * w + p2x];
+                tau = v1 < v2;
+            }
+        }
+        fail = fail || bad;
+        const unsigned long long bits = __ballot(tau);
+        if (lane == 0) {
+            desc[8 * (size_t)r + 2 * j] = (uint32_t)(bits & 0xFFFFFFFFull);
+            desc[8 * (size_t)r + 2 * j + 1] = (uint32_t)(bits >> 32);
+        }
+    }
+    const bool any_fail = __any(fail);
+    if (lane == 0) flags[r] = (ok && !any_fail) ? 1u : 0u;
+}
+
+// ordered compaction of <= 10240 ranked keypoints by flag (single block)
+__global__ __launch_bounds__(1024) void final_compact_kernel(const uint32_t *__restrict__ flags,
+                                                              const uint32_t *__restrict__ kp_xy,
+                                                              const uint32_t *__restrict__ sorted_idx,
+                                                              const uint32_t *__restrict__ desc, uint32_t count,
+                                                              uint32_t cap, uint32_t *__restrict__ out_xy,
+                                                              uint32_t *__restrict__ out_desc,
+                                                              uint32_t *__restrict__ out_n)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < count; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const bool f = i < count && flags[i] != 0;
+        const unsigned long long b = __ballot(f);
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) wtot[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (uint32_t k = 0; k < wv; k++) off += wtot[k];
+        off += (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (f && off < cap) {
+            const uint32_t src = sorted_idx[i];
+            out_xy[2 * (size_t)off] = kp_xy[2 * (size_t)src];
+            out_xy[2 * (size_t)off + 1] = kp_xy[2 * (size_t)src + 1];
+#pragma unroll
+            for (int k = 0; k < 8; k++) out_desc[8 * (size_t)off + k] = desc[8 * (size_t)i + k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int k = 0; k < 16; k++) t += wtot[k];
+            carry_s += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_n = min(carry_s, cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// matcher (pointmatching.rs:43-77): one thread per query keypoint, the train descriptors stream
+// through LDS in tiles read at a wave-uniform address (broadcast).  First minimum wins
+// (Iterator::min_by keeps the first of equal elements).
+// ---------------------------------------------------------------------------------------------
+constexpr int MATCH_TILE = 512;
+__global__ __launch_bounds__(256) void match_kernel(const uint32_t *__restrict__ desc1, uint32_t n1,
+                                                     const uint32_t *__restrict__ desc2, uint32_t n2,
+                                                     uint32_t threshold, uint32_t *__restrict__ best_j,
+                                                     uint32_t *__restrict__ best_d)
+{
+    __shared__ uint4 tile[MATCH_TILE * 2];
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (q < n1) {
+        a0 = reinterpret_cast<const uint4 *>(desc1)[2 * (size_t)q];
+        a1 = reinterpret_cast<const uint4 *>(desc1)[2 * (size_t)q + 1];
+    }
+    uint32_t bd = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < n2; base += MATCH_TILE) {
+        const uint32_t n = min((uint32_t)MATCH_TILE, n2 - base);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 2 * n; i += 256)
+            tile[i] = reinterpret_cast<const uint4 *>(desc2)[2 * (size_t)base + i];
+        __syncthreads();
+        for (uint32_t j = 0; j < n; j++) {
+            const uint4 b0 = tile[2 * j], b1 = tile[2 * j + 1];
+            const uint32_t d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                               __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            if (d <= threshold && d < bd) {
+                bd = d;
+                bj = base + j;
+            }
+        }
+    }
+    if (q < n1) {
+        best_j[q] = bj;
+        best_d[q] = bd; // 0xFFFFFFFF = no match; sorts last
+    }
+}
+
+__global__ void iota_kernel(uint32_t *p, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+__global__ void match_gather_kernel(const uint32_t *__restrict__ sorted_q, const uint32_t *__restrict__ sorted_d,
+                                    const uint32_t *__restrict__ best_j, const uint32_t *__restrict__ xy1,
+                                    const uint32_t *__restrict__ xy2, uint32_t n1, uint32_t *__restrict__ out_matches,
+                                    uint32_t *__restrict__ out_dist, uint32_t *__restrict__ out_n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const uint32_t d = sorted_d[i];
+    if (d == 0xFFFFFFFFu) {
+        // first unmatched entry marks the count (distances are sorted ascending)
+        if (i == 0 || sorted_d[i - 1] != 0xFFFFFFFFu) *out_n = i;
+        return;
+    }
+    if (i == n1 - 1) *out_n = n1;
+    const uint32_t q = sorted_q[i], j = best_j[q];
+    out_matches[4 * (size_t)i + 0] = xy1[2 * (size_t)q];
+    out_matches[4 * (size_t)i + 1] = xy1[2 * (size_t)q + 1];
+    out_matches[4 * (size_t)i + 2] = xy2[2 * (size_t)j];
+    out_matches[4 * (size_t)i + 3] = xy2[2 * (size_t)j + 1];
+    if (out_dist) out_dist[i] = d;
+}
+
+// gaussian_kernel (orb.rs:190-202), host side with libm exp like the reference
+static void gaussian_kernel_host(int width, double *kernel)
+{
+    const double sigma = (double)(width - 1) / 6.0;
+    const double sigma_2 = sigma * sigma;
+    const double divider = std::sqrt(2.0 * M_PI) * sigma;
+    const double center = (double)(width / 2);
+    for (int i = 0; i < width; i++) {
+        const double d = (double)i - center;
+        kernel[i] = std::exp(-(d * d) / (2.0 * sigma_2)) / divider;
+    }
+}
+
+static bool dev_ptr(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// RAII bag of device allocations so every error path frees them
+struct DevAllocs {
+    std::vector<void *> ptrs;
+    ~DevAllocs()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T> hipError_t alloc(T **out, size_t count)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+};
+
+} // namespace cvhip
+
+using namespace cvhip;
+
+extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
+                                 uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n)
+{
+    if (!dev || !img || !out_xy || !out_desc || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (w < 2 * FAST_KERNEL_SIZE + 1 || h < 2 * FAST_KERNEL_SIZE + 1)
+        return fail(CVHIP_ERR_INVALID, "image smaller than the FAST ring");
+    if (w > 65535 || h > 65535) return fail(CVHIP_ERR_UNSUPPORTED, "image dimension above 65535");
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    const size_t n = (size_t)w * h;
+    DevAllocs mem;
+
+    uint8_t *d_img = nullptr, *d_adj = nullptr, *d_score = nullptr;
+    uint32_t *d_mm = nullptr, *d_counts = nullptr, *d_total = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_img, n + IMG_PAD));
+    CVHIP_TRY_HIP(mem.alloc(&d_adj, n + IMG_PAD));
+    CVHIP_TRY_HIP(mem.alloc(&d_score, n));
+    CVHIP_TRY_HIP(mem.alloc(&d_mm, 2));
+    const uint32_t nblocks = (uint32_t)((n + 255) / 256);
+    CVHIP_TRY_HIP(mem.alloc(&d_counts, nblocks));
+    CVHIP_TRY_HIP(mem.alloc(&d_total, 1));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_img, img, n, dev_ptr(img) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    const uint32_t mm_init[2] = {255u, 0u};
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_mm, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, s));
+
+    // 1. contrast stretch, FAST score, NMS, scan-ordered corner list
+    const unsigned rblocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(minmax_kernel, dim3(rblocks), dim3(256), 0, s, d_img, n, d_mm);
+    hipLaunchKernelGGL(contrast_kernel, dim3(rblocks), dim3(256), 0, s, d_img, n, d_mm, d_adj);
+    dim3 grid2d((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, d_adj, w, h, d_score);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(nblocks), dim3(256), 0, s, d_score, w, h, d_counts);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, nblocks, d_total);
+    uint32_t n_fast = 0;
+    CVHIP_TRY_HIP(hipMemcpyAsync(&n_fast, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    CVHIP_TRY_HIP(hipGetLastError());
+    if (n_fast == 0) {
+        *out_n = 0;
+        return CVHIP_OK;
+    }
+    uint32_t *d_kp = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_kp, (size_t)n_fast * 2));
+    hipLaunchKernelGGL(nms_write_kernel, dim3(nblocks), dim3(256), 0, s, d_score, w, h, d_counts, n_fast, d_kp);
+
+    // 2. Harris on the original image, stable descending sort, top MAX_KEYPOINTS
+    Taps7 k7;
+    gaussian_kernel_host(HARRIS_KERNEL_WIDTH, k7.k);
+    unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
+    uint32_t *d_idx = nullptr, *d_idx_sorted = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_keys, n_fast));
+    CVHIP_TRY_HIP(mem.alloc(&d_keys_sorted, n_fast));
+    CVHIP_TRY_HIP(mem.alloc(&d_idx, n_fast));
+    CVHIP_TRY_HIP(mem.alloc(&d_idx_sorted, n_fast));
+    hipLaunchKernelGGL(harris_kernel, dim3((n_fast + 63) / 64), dim3(64), 0, s, d_img, w, h, d_kp, d_total, n_fast, k7,
+                       d_keys, d_idx);
+    size_t tmp_bytes = 0;
+    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_idx,
+                                                               d_idx_sorted, (int)n_fast, 0, 64, s));
+    uint8_t *d_tmp = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_tmp, tmp_bytes));
+    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx,
+                                                               d_idx_sorted, (int)n_fast, 0, 64, s));
+    const uint32_t count = std::min(n_fast, MAX_KEYPOINTS); // entries past the Some(...) ones carry idx = ~0
+
+    // 3. blur of the original image, patch moments
+    Taps11 k11;
+    gaussian_kernel_host(ORB_GAUSS_KERNEL_WIDTH, k11.k);
+    double *d_blur_h = nullptr, *d_blur = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_blur_h, n));
+    CVHIP_TRY_HIP(mem.alloc(&d_blur, n));
+    hipLaunchKernelGGL(blur_h_kernel, grid2d, dim3(256), 0, s, d_img, w, h, k11, d_blur_h);
+    hipLaunchKernelGGL(blur_v_kernel, grid2d, dim3(256), 0, s, d_blur_h, w, h, k11, d_blur);
+    unsigned long long *d_mom = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_mom, (size_t)count * 4));
+    hipLaunchKernelGGL(moments_kernel, dim3(count), dim3(64), 0, s, d_blur, w, h, d_kp, d_idx_sorted, count, d_mom);
+    std::vector<unsigned long long> h_mom((size_t)count * 4);
+    std::vector<uint32_t> h_idx(count), h_kp;
+    CVHIP_TRY_HIP(hipMemcpyAsync(h_mom.data(), d_mom, h_mom.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(h_idx.data(), d_idx_sorted, count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    h_kp.resize((size_t)n_fast * 2);
+    CVHIP_TRY_HIP(hipMemcpyAsync(h_kp.data(), d_kp, h_kp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    CVHIP_TRY_HIP(hipGetLastError());
+
+    // 4. orientation on the host with libm, exactly as the reference (orb.rs:337-341, 365-366)
+    std::vector<double> h_sc((size_t)count * 3, 0.0);
+    for (uint32_t r = 0; r < count; r++) {
+        if (!h_mom[4 * (size_t)r + 3] || h_idx[r] == 0xFFFFFFFFu) continue;
+        const double x = (double)h_kp[2 * (size_t)h_idx[r]], y = (double)h_kp[2 * (size_t)h_idx[r] + 1];
+        const double m00 = (double)h_mom[4 * (size_t)r + 0];
+        const double centroid_x = (double)h_mom[4 * (size_t)r + 1] / m00;
+        const double centroid_y = (double)h_mom[4 * (size_t)r + 2] / m00;
+        const double angle = std::atan2(centroid_y - y, centroid_x - x);
+        h_sc[3 * (size_t)r + 0] = std::sin(angle);
+        h_sc[3 * (size_t)r + 1] = std::cos(angle);
+        h_sc[3 * (size_t)r + 2] = 1.0;
+    }
+
+    // 5. descriptors + ordered compaction
+    double *d_sc = nullptr;
+    signed char *d_pat = nullptr;
+    uint32_t *d_desc = nullptr, *d_flags = nullptr, *d_out_xy = out_xy, *d_out_desc = out_desc, *d_out_n = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_sc, h_sc.size()));
+    CVHIP_TRY_HIP(mem.alloc(&d_pat, 1024));
+    CVHIP_TRY_HIP(mem.alloc(&d_desc, (size_t)count * 8));
+    CVHIP_TRY_HIP(mem.alloc(&d_flags, count));
+    CVHIP_TRY_HIP(mem.alloc(&d_out_n, 1));
+    const bool xy_dev = dev_ptr(out_xy), desc_dev = dev_ptr(out_desc);
+    const uint32_t out_cap = std::min(cap, count);
+    if (!xy_dev) CVHIP_TRY_HIP(mem.alloc(&d_out_xy, (size_t)out_cap * 2));
+    if (!desc_dev) CVHIP_TRY_HIP(mem.alloc(&d_out_desc, (size_t)out_cap * 8));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_sc, h_sc.data(), h_sc.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_pat, CVHIP_ORB_PATTERN, 1024, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(brief_kernel, dim3(count), dim3(64), 0, s, d_blur, w, h, d_kp, d_idx_sorted, count, d_sc, d_pat,
+                       d_desc, d_flags);
+    hipLaunchKernelGGL(final_compact_kernel, dim3(1), dim3(1024), 0, s, d_flags, d_kp, d_idx_sorted, d_desc, count,
+                       out_cap, d_out_xy, d_out_desc, d_out_n);
+    uint32_t n_out = 0;
+    CVHIP_TRY_HIP(hipMemcpyAsync(&n_out, d_out_n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    CVHIP_TRY_HIP(hipGetLastError());
+    if (!xy_dev && n_out)
+        CVHIP_TRY_HIP(hipMemcpy(out_xy, d_out_xy, (size_t)n_out * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (!desc_dev && n_out)
+        CVHIP_TRY_HIP(hipMemcpy(out_desc, d_out_desc, (size_t)n_out * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_n = n_out;
+    return CVHIP_OK;
+}
+
+extern "C" int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const uint32_t *desc1, uint32_t n1,
+                                  const uint32_t *xy2, const uint32_t *desc2, uint32_t n2, uint32_t threshold,
+                                  uint32_t *out_matches, uint32_t *out_dist, uint32_t *out_n)
+{
+    if (!dev || !out_matches || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
+    *out_n = 0;
+    if (n1 == 0 || n2 == 0) return CVHIP_OK;
+    if (!xy1 || !desc1 || !xy2 || !desc2) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    DevAllocs mem;
+    uint32_t *d_xy1, *d_xy2, *d_desc1, *d_desc2, *d_bj, *d_bd, *d_bd_sorted, *d_q, *d_q_sorted, *d_om, *d_od, *d_n;
+    CVHIP_TRY_HIP(mem.alloc(&d_xy1, (size_t)n1 * 2));
+    CVHIP_TRY_HIP(mem.alloc(&d_xy2, (size_t)n2 * 2));
+    CVHIP_TRY_HIP(mem.alloc(&d_desc1, (size_t)n1 * 8));
+    CVHIP_TRY_HIP(mem.alloc(&d_desc2, (size_t)n2 * 8));
+    CVHIP_TRY_HIP(mem.alloc(&d_bj, n1));
+    CVHIP_TRY_HIP(mem.alloc(&d_bd, n1));
+    CVHIP_TRY_HIP(mem.alloc(&d_bd_sorted, n1));
+    CVHIP_TRY_HIP(mem.alloc(&d_q, n1));
+    CVHIP_TRY_HIP(mem.alloc(&d_q_sorted, n1));
+    CVHIP_TRY_HIP(mem.alloc(&d_om, (size_t)n1 * 4));
+    CVHIP_TRY_HIP(mem.alloc(&d_od, n1));
+    CVHIP_TRY_HIP(mem.alloc(&d_n, 1));
+    auto kind = [](const void *p) { return dev_ptr(p) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; };
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_xy1, xy1, (size_t)n1 * 8, kind(xy1), s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_xy2, xy2, (size_t)n2 * 8, kind(xy2), s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_desc1, desc1, (size_t)n1 * 32, kind(desc1), s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_desc2, desc2, (size_t)n2 * 32, kind(desc2), s));
+    CVHIP_TRY_HIP(hipMemsetAsync(d_n, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(match_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, d_desc1, n1, d_desc2, n2, threshold, d_bj,
+                       d_bd);
+    hipLaunchKernelGGL(iota_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, d_q, n1);
+    // stable ascending sort by distance (sort_by_key, pointmatching.rs:74); unmatched = ~0 go last
+    size_t tmp_bytes = 0;
+    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_bd, d_bd_sorted, d_q, d_q_sorted, (int)n1, 0,
+                                                     32, s));
+    uint8_t *d_tmp = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_tmp, tmp_bytes));
+    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_bd, d_bd_sorted, d_q, d_q_sorted, (int)n1, 0, 32,
+                                                     s));
+    hipLaunchKernelGGL(match_gather_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, d_q_sorted, d_bd_sorted, d_bj, d_xy1,
+                       d_xy2, n1, d_om, d_od, d_n);
+    uint32_t n = 0;
+    CVHIP_TRY_HIP(hipMemcpyAsync(&n, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    CVHIP_TRY_HIP(hipGetLastError());
+    if (n) {
+        CVHIP_TRY_HIP(hipMemcpy(out_matches, d_om, (size_t)n * 16,
+                                dev_ptr(out_matches) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+        if (out_dist)
+            CVHIP_TRY_HIP(hipMemcpy(out_dist, d_od, (size_t)n * 4,
+                                    dev_ptr(out_dist) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    }
+    *out_n = n;
+    return CVHIP_OK;
 }
