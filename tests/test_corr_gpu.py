@@ -213,3 +213,75 @@ def test_full_size_properties_1024(gpu_device):
         win = rxy[max(my - 4, 0):my + 5, max(mx - 4, 0):mx + 5].reshape(-1, 2)
         win = win[win[:, 0] >= 0]
         assert ((np.abs(win[:, 0] - x) <= 4) & (np.abs(win[:, 1] - y) <= 4)).any()
+
+
+def test_row_sharded_equals_unsharded(gpu_device, oracle):
+    """Two row-sharded contexts (shard 0/2 and 1/2) on one GPU, bands exchanged between their
+    level grids after every search pass exactly as the RCCL all-gather would: the result must be
+    bit-identical to the unsharded run (and so to the oracle)."""
+    import torch
+
+    from cybervision_amd import sharding
+
+    c = cases.make_case("tilt3_200x150")
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    F, R = correlation.CorrelationDirection.Forward, correlation.CorrelationDirection.Reverse
+    ctxs = [correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"]) for _ in range(2)]
+    try:
+        for r, pc in enumerate(ctxs):
+            pc.set_row_shard(r, 2)
+
+        def exchange(direction):
+            grids = [pc.level_grid(direction) for pc in ctxs]
+            gpu_device.synchronize()
+            for r, g in enumerate(grids):
+                assert (g["row0"], g["row1"]) == sharding.shard_rows(g["lh"], r, 2)
+                nbytes = g["rows_per_shard"] * g["lw"] * 8
+                src = sharding.alias_bytes(g["cells"] + r * nbytes, nbytes, device=True)
+                dst = sharding.alias_bytes(grids[1 - r]["cells"] + r * nbytes, nbytes, device=True)
+                dst.copy_(src)
+            torch.cuda.synchronize()
+
+        for i in range(c["steps"] + 1):
+            k = c["steps"] - i
+            s = 1.0 / float(1 << k)
+            for pc in ctxs:
+                pc.correlate_images_step(p1[k], p2[k], s, F)
+            exchange(F)
+            for pc in ctxs:
+                pc.correlate_images_step(p2[k], p1[k], s, R)
+            exchange(R)
+            for pc in ctxs:
+                pc.cross_check_filter(s, F)
+                pc.cross_check_filter(s, R)
+                pc.first_pass = False
+        want = run_oracle(oracle, c)
+        for r, pc in enumerate(ctxs):
+            assert_same_grid(pc.complete(F), want, f"shard context {r}")
+    finally:
+        for pc in ctxs:
+            pc.close()
+
+
+def test_sharded_level_call_with_gather_hook(gpu_device, oracle):
+    """cvhip_correlate_level on a 1-of-1... n-shard context drives the gather hook itself; with a
+    single participating rank emulated by den=1 semantics the hook must not be needed, and with
+    den=2 but no hook the call must fail loudly on a level large enough to be sharded."""
+    from cybervision_amd._lib import CvhipError
+
+    a, b, _ = synth.make_pair(256, 256)
+    steps = synth.optimal_scale_steps(256, 256)
+    p1, p2 = synth.box_pyramid(a, steps), synth.box_pyramid(b, steps)
+    pc = correlation.PointCorrelations(gpu_device, (256, 256), (256, 256), synth.F_HORIZONTAL)
+    try:
+        pc.set_row_shard(0, 2)                       # no hook
+        pc.correlate_images(p1[2], p2[2], 0.25)      # 64 rows: below the sharding threshold, computed whole
+        pc.correlate_images(p1[1], p2[1], 0.5)       # 128 rows / 2 = 64 per shard: sharded -> needs the hook
+    except CvhipError as e:
+        assert e.code == -1 and "all-gather hook" in str(e)
+    else:
+        raise AssertionError("sharded level without a gather hook must fail")
+    finally:
+        pc.close()
