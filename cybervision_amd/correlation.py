@@ -161,6 +161,15 @@ class PointCorrelations:
                    "cvhip_ctx_get_profile")
         return {"launches": n.value, "search_ms": ms.value, "candidates": cand.value}
 
+    def get_counters(self, reset: bool = True):
+        arr = (C.c_uint64 * 4)()
+        _lib.check(_lib.lib().cvhip_ctx_get_counters(self._h, arr, int(reset)), "cvhip_ctx_get_counters")
+        return {"candidates": arr[0], "exact_evals": arr[1], "multi_contender_pixels": arr[2],
+                "whole_corridor_pixels": arr[3]}
+
+    def set_search_version(self, version: int):
+        _lib.check(_lib.lib().cvhip_ctx_set_search_version(self._h, version), "cvhip_ctx_set_search_version")
+
     def set_row_shard(self, num: int, den: int, gather=None):
         """gather(cells_ptr: int, shard_bytes: int, n_shards: int, direction: int) -> None does the
         in-place all-gather of the level grid (see cybervision_amd.sharding)."""

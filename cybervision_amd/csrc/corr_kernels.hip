@@ -102,17 +102,24 @@ __device__ __forceinline__ uint32_t corridor_end_of(const CorrParams &p, const L
 // avg: the reference sums u8 values in f32; every partial sum is an integer < 2^24, so an
 // integer sum converted once is bit-identical.  stdev: serial row-major f32 sum of squares.
 // ---------------------------------------------------------------------------------------------
+//
+// istats[i] = {window sum s (exact integer) | VALID << 31, f32 bits of 1/sqrt(V)} with
+// V = 121*sum(a^2) - s^2 (exact integer): the inputs of the exact-integer candidate filter of
+// search2_kernel.  VALID mirrors the reference's per-candidate test "stdev finite and >= min_stdev"
+// (mod.rs:439) evaluated on the reference's own f32 stdev.
 __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
-                                                            float2 *__restrict__ stats)
+                                                            float min_stdev, float2 *__restrict__ stats,
+                                                            uint2 *__restrict__ istats)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const float nan = __builtin_nanf("");
     float2 out = make_float2(nan, nan);
+    uint2 iout = make_uint2(0u, 0u);
     if (x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < w && y + KERNEL_SIZE < h) {
         const uint8_t *base = img + (size_t)(y - KERNEL_SIZE) * w + (x - KERNEL_SIZE);
-        uint32_t isum = 0;
+        uint32_t isum = 0, isq = 0;
         Row12 rows[KERNEL_WIDTH];
 #pragma unroll
         for (int r = 0; r < KERNEL_WIDTH; r++) {
@@ -120,6 +127,10 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
             isum += __builtin_amdgcn_udot4(rows[r].a, 0x01010101u, 0u, false);
             isum += __builtin_amdgcn_udot4(rows[r].b, 0x01010101u, 0u, false);
             isum += __builtin_amdgcn_udot4(rows[r].c, 0x00010101u, 0u, false);
+            const uint32_t c3 = rows[r].c & 0x00FFFFFFu;
+            isq = __builtin_amdgcn_udot4(rows[r].a, rows[r].a, isq, false);
+            isq = __builtin_amdgcn_udot4(rows[r].b, rows[r].b, isq, false);
+            isq = __builtin_amdgcn_udot4(c3, c3, isq, false);
         }
         const float avg = (float)isum / (float)KERNEL_POINT_COUNT;
         float sd = 0.0f;
@@ -133,14 +144,20 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
             }
         }
         out = make_float2(avg, sqrtf(sd / (float)KERNEL_POINT_COUNT));
+        const uint32_t v = (uint32_t)KERNEL_POINT_COUNT * isq - isum * isum; // < 2^30, exact
+        const bool valid = finite_f32(out.y) && !(fabsf(out.y) < min_stdev);
+        const float rv = v ? 1.0f / sqrtf((float)v) : 0.0f;
+        iout = make_uint2(isum | (valid ? 0x80000000u : 0u), __float_as_uint(rv));
     }
     stats[(size_t)y * w + x] = out;
+    istats[(size_t)y * w + x] = iout;
 }
 
-void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float2 *stats, hipStream_t s)
+void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float min_stdev, float2 *stats, uint2 *istats,
+                         hipStream_t s)
 {
     dim3 grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, img, w, h, stats);
+    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, img, w, h, min_stdev, stats, istats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,6 +358,359 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
     hipLaunchKernelGGL(search_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, stats2, range, out, cand_counter);
+}
+
+// ---------------------------------------------------------------------------------------------
+// search2: the same correlate_point / correlate_corridor_area (mod.rs:321-384, 411-466) with an
+// exact-integer pre-filter.
+//
+// For every candidate c of a searched pixel the reference computes a float score f(c) through a
+// serial 121-term f32 chain.  The real-valued NCC it approximates is
+//     rho(c) = (121*S12 - s1*s2) / sqrt(V1*V2),   S12 = sum a*b, s = window sum, V = 121*sum a^2 - s^2,
+// all of which are integers < 2^31 for u8 images, so rho's numerator and denominator can be formed
+// EXACTLY with v_dot4_u32_u8 (4 multiply-adds per lane-op instead of 3 ops per term).  g(c) is
+// rho(c) rounded through a handful of f32 operations (relative error < 8 * 2^-24).
+//
+// Error bound |f(c) - g(c)| <= DELTA (derivation in DESIGN.md §4): the reference's rounding of
+// avg (enters only at second order because the true deviations sum to zero), of each delta
+// (<= 2^-17 absolute), of the 121 products and partial sums (gamma_122), of the two f32 stdevs and
+// of the final divide add up to < 764 * 2^-24 = 4.6e-5 when both stdevs are >= min_stdev = 1.
+//
+// Decision rule: the reference keeps the FIRST candidate (in stripe, i order) that maximises f
+// among those with f >= threshold.  Such a candidate c* satisfies g(c*) >= max g - 2*DELTA and
+// g(c*) >= threshold - DELTA, and so does every candidate that ties with it.  The filter therefore
+// records, in order, the (few) candidates inside that band, and only those are re-evaluated with the
+// reference's exact serial f32 arithmetic; the winner among them under the reference's own rule
+// (mod.rs:456-457) is the reference's winner, with the reference's exact score.  Pixels whose band
+// holds more than S2_K candidates re-evaluate their whole corridor exactly.
+//
+// Memory plan: one 256-thread workgroup = a 64x4 tile of searched pixels.  The bounding box of
+// all 11x11 candidate windows of the tile is staged ONCE from HBM into LDS as eight byte-shifted
+// copies, so that any window row (11 bytes at an arbitrary byte address) is one aligned
+// ds_read_b64 + ds_read_b32 from the copy selected by (address & 7); copies are 32 B (mod 256 B)
+// apart, so 64 lanes reading consecutive candidates hit 64 distinct bank pairs.
+// ---------------------------------------------------------------------------------------------
+constexpr int S2_K = 4;                 // contenders kept per pixel before falling back to the full corridor
+constexpr int S2_LDS_BYTES = 40960;     // 8 copies of the target tile; 4 workgroups per CU
+constexpr float S2_DELTA = 5.0e-5f;     // >= 764 * 2^-24 + filter rounding (see above)
+
+struct CandXY {
+    uint32_t x, y;
+};
+__device__ __forceinline__ CandXY candidate_xy(const Line &e, uint32_t i, int off)
+{
+    // mod.rs:424-429
+    const double x2d = (e.cx * (double)i + e.ax) + (double)(off * e.ox);
+    const double y2d = (e.cy * (double)i + e.ay) + (double)(off * e.oy);
+    CandXY c;
+    c.x = f64_to_u32_sat(floor(x2d));
+    c.y = f64_to_u32_sat(floor(y2d));
+    return c;
+}
+__device__ __forceinline__ bool candidate_in_bounds(const CorrParams &p, const CandXY &c)
+{
+    return !(c.x < KERNEL_SIZE || c.x >= p.w2 - KERNEL_SIZE || c.y < KERNEL_SIZE || c.y >= p.h2 - KERNEL_SIZE);
+}
+
+// Exact f32 score of one candidate from GLOBAL memory (also the v1 inner loop): mod.rs:442-454.
+__device__ __forceinline__ float exact_corr_global(const uint8_t *__restrict__ img2, uint32_t w2, uint32_t x2,
+                                                   uint32_t y2, const Row12 (&a)[KERNEL_WIDTH], float avg1,
+                                                   float stdev1, float avg2, float stdev2)
+{
+    float corr = 0.0f;
+    const uint8_t *base = img2 + (size_t)(y2 - KERNEL_SIZE) * w2 + (x2 - KERNEL_SIZE);
+#pragma unroll
+    for (int r = 0; r < KERNEL_WIDTH; r++) {
+        const Row12 row = load_row12(base + (size_t)r * w2);
+#pragma unroll
+        for (int c = 0; c < KERNEL_WIDTH; c++) {
+            const uint32_t wa = c < 4 ? a[r].a : (c < 8 ? a[r].b : a[r].c);
+            const uint32_t wb = c < 4 ? row.a : (c < 8 ? row.b : row.c);
+            const float delta1 = byte_f32(wa, c & 3) - avg1;
+            const float delta2 = byte_f32(wb, c & 3) - avg2;
+            corr += delta1 * delta2;
+        }
+    }
+    return corr / (stdev1 * stdev2 * (float)KERNEL_POINT_COUNT);
+}
+
+__global__ __launch_bounds__(256, 3) void search2_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                          const uint8_t *__restrict__ img2,
+                                                          const float2 *__restrict__ stats1,
+                                                          const float2 *__restrict__ stats2,
+                                                          const uint2 *__restrict__ istats1,
+                                                          const uint2 *__restrict__ istats2,
+                                                          const uint32_t *__restrict__ range,
+                                                          uint2 *__restrict__ out,
+                                                          unsigned long long *__restrict__ counters)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[S2_LDS_BYTES];
+    __shared__ int bb[4]; // min x, min y, max x, max y of in-bounds candidate centres
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t x = blockIdx.x * 64 + lane;
+    const uint32_t y = p.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool in_image = x < p.w1 && y < p.row1;
+    if (threadIdx.x == 0) {
+        bb[0] = 0x7FFFFFFF;
+        bb[1] = 0x7FFFFFFF;
+        bb[2] = -1;
+        bb[3] = -1;
+    }
+
+    // ---- per-pixel setup: mod.rs:321-364 ---------------------------------------------------------
+    const bool interior =
+        in_image && x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
+    float2 st1 = make_float2(0.0f, 0.0f);
+    Line e;
+    e.cx = e.cy = e.ax = e.ay = 0.0;
+    e.ox = e.oy = 0;
+    uint32_t r0 = 0, r1 = 0;
+    bool active = false;
+    if (interior) {
+        st1 = stats1[(size_t)y * p.w1 + x];
+        e = epipolar_line(p, x, y);
+        active = finite_f32(st1.y) && !(fabsf(st1.y) < p.min_stdev) && line_finite(e);
+        r0 = KERNEL_SIZE;
+        r1 = corridor_end_of(p, e);
+        if (active && !p.first_pass) {
+            const uint32_t rg = range[(size_t)y * p.w1 + x];
+            active = rg != RANGE_NONE;
+            r0 = rg & 0xFFFFu;
+            r1 = rg >> 16;
+        }
+        active = active && r0 < r1;
+    }
+    const uint32_t len = active ? r1 - r0 : 0u;
+    const int cs = p.corridor_size;
+    const uint32_t ncand = len * (uint32_t)(2 * cs + 1);
+
+    // ---- bounding box of the in-bounds candidate centres (corners of the monotone corridor) -------
+    int lminx = 0x7FFFFFFF, lminy = 0x7FFFFFFF, lmaxx = -1, lmaxy = -1;
+    if (active) {
+        const int xlo = KERNEL_SIZE, xhi = (int)p.w2 - KERNEL_SIZE - 1, ylo = KERNEL_SIZE, yhi = (int)p.h2 - KERNEL_SIZE - 1;
+#pragma unroll
+        for (int corner = 0; corner < 4; corner++) {
+            const CandXY c = candidate_xy(e, (corner & 1) ? r1 - 1 : r0, (corner & 2) ? cs : -cs);
+            const int cx = min(max((int)min(c.x, 0x7FFFFFFFu), xlo), xhi);
+            const int cy = min(max((int)min(c.y, 0x7FFFFFFFu), ylo), yhi);
+            lminx = min(lminx, cx);
+            lmaxx = max(lmaxx, cx);
+            lminy = min(lminy, cy);
+            lmaxy = max(lmaxy, cy);
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        lminx = min(lminx, __shfl_xor(lminx, sft, 64));
+        lminy = min(lminy, __shfl_xor(lminy, sft, 64));
+        lmaxx = max(lmaxx, __shfl_xor(lmaxx, sft, 64));
+        lmaxy = max(lmaxy, __shfl_xor(lmaxy, sft, 64));
+    }
+    __syncthreads(); // bb initialised
+    if (lane == 0 && lmaxx >= 0) {
+        atomicMin(&bb[0], lminx);
+        atomicMin(&bb[1], lminy);
+        atomicMax(&bb[2], lmaxx);
+        atomicMax(&bb[3], lmaxy);
+    }
+    __syncthreads();
+    const int bx0 = bb[0] - KERNEL_SIZE, by0 = bb[1] - KERNEL_SIZE;
+    const int bwid = bb[2] - bb[0] + 2 * KERNEL_SIZE + 2; // + 1 for the 12th byte of a row read
+    const int bhei = bb[3] - bb[1] + 2 * KERNEL_SIZE + 1;
+    const bool any_active = bb[2] >= 0;
+    const uint32_t P = any_active ? (uint32_t)((bwid + 7) & ~7) : 8u;                 // row pitch, multiple of 8
+    const uint32_t CS = any_active ? ((P * (uint32_t)bhei + 16u + 255u) & ~255u) + 32u : 0u; // copy stride
+    const bool use_lds = any_active && 8u * CS <= (uint32_t)S2_LDS_BYTES;
+
+    // ---- stage the target tile: 8 byte-shifted copies ---------------------------------------------
+    if (use_lds) {
+        const uint32_t cols4 = P >> 2;
+        const uint32_t units = cols4 * (uint32_t)bhei;
+        for (uint32_t u = threadIdx.x; u < units; u += 256) {
+            const uint32_t row = u / cols4, c4 = (u - row * cols4) << 2;
+            const Row12 g = load_row12(img2 + (size_t)(by0 + (int)row) * p.w2 + (size_t)(bx0 + (int)c4));
+            const uint32_t o = row * P + c4;
+            *reinterpret_cast<uint32_t *>(tile + 0 * CS + o) = g.a;
+            *reinterpret_cast<uint32_t *>(tile + 1 * CS + o) = __builtin_amdgcn_alignbyte(g.b, g.a, 1);
+            *reinterpret_cast<uint32_t *>(tile + 2 * CS + o) = __builtin_amdgcn_alignbyte(g.b, g.a, 2);
+            *reinterpret_cast<uint32_t *>(tile + 3 * CS + o) = __builtin_amdgcn_alignbyte(g.b, g.a, 3);
+            *reinterpret_cast<uint32_t *>(tile + 4 * CS + o) = g.b;
+            *reinterpret_cast<uint32_t *>(tile + 5 * CS + o) = __builtin_amdgcn_alignbyte(g.c, g.b, 1);
+            *reinterpret_cast<uint32_t *>(tile + 6 * CS + o) = __builtin_amdgcn_alignbyte(g.c, g.b, 2);
+            *reinterpret_cast<uint32_t *>(tile + 7 * CS + o) = __builtin_amdgcn_alignbyte(g.c, g.b, 3);
+        }
+    }
+    __syncthreads();
+
+    // ---- searched window, packed bytes (12th byte zero so a 12-byte target row can be used whole) ---
+    Row12 a[KERNEL_WIDTH];
+    int s1 = 0;
+    float rv1 = 0.0f;
+    if (active) {
+        const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
+#pragma unroll
+        for (int r = 0; r < KERNEL_WIDTH; r++) {
+            a[r] = load_row12(base + (size_t)r * p.w1);
+            a[r].c &= 0x00FFFFFFu;
+        }
+        const uint2 is1 = istats1[(size_t)y * p.w1 + x];
+        s1 = (int)(is1.x & 0x7FFFFFFFu);
+        rv1 = __uint_as_float(is1.y);
+    } else {
+#pragma unroll
+        for (int r = 0; r < KERNEL_WIDTH; r++) a[r].a = a[r].b = a[r].c = 0u;
+    }
+
+    uint32_t evaluated = 0, exact_evals = 0;
+    bool have = false;
+    float bcorr = 0.0f;
+    uint32_t bx = 0, by = 0;
+
+    // exact score of candidate (x2, y2) with the tile in LDS (mod.rs:442-454, serial f32 chain)
+    auto exact_corr_lds = [&](uint32_t x2, uint32_t y2, float avg2, float stdev2) -> float {
+        const uint32_t a0 = (uint32_t)((int)y2 - KERNEL_SIZE - by0) * P + (uint32_t)((int)x2 - KERNEL_SIZE - bx0);
+        const uint32_t phi = a0 & 7u;
+        const uint8_t *src = tile + phi * CS + (a0 - phi);
+        float corr = 0.0f;
+#pragma unroll
+        for (int r = 0; r < KERNEL_WIDTH; r++) {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
+            const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
+#pragma unroll
+            for (int c = 0; c < KERNEL_WIDTH; c++) {
+                const uint32_t wa = c < 4 ? a[r].a : (c < 8 ? a[r].b : a[r].c);
+                const uint32_t wb = c < 4 ? lo.x : (c < 8 ? lo.y : hi);
+                const float delta1 = byte_f32(wa, c & 3) - st1.x;
+                const float delta2 = byte_f32(wb, c & 3) - avg2;
+                corr += delta1 * delta2;
+            }
+        }
+        return corr / (st1.y * stdev2 * (float)KERNEL_POINT_COUNT);
+    };
+    // the reference's acceptance rule, mod.rs:456-464
+    auto consider = [&](float corr, uint32_t x2, uint32_t y2) {
+        if (corr >= p.threshold && (!have || corr > bcorr)) {
+            have = true;
+            bcorr = corr;
+            bx = x2;
+            by = y2;
+        }
+    };
+    // exact evaluation of candidate number t (stripe-major order), with all the reference's skips
+    auto exact_candidate = [&](uint32_t t, bool count_it) {
+        const int off = (int)(t / len) - cs;
+        const uint32_t i = r0 + (t % len);
+        const CandXY c = candidate_xy(e, i, off);
+        if (!candidate_in_bounds(p, c)) return;
+        const float2 st2 = stats2[(size_t)c.y * p.w2 + c.x];
+        if (!finite_f32(st2.y) || fabsf(st2.y) < p.min_stdev) return;
+        if (count_it) evaluated++;
+        exact_evals++;
+        const float corr = use_lds ? exact_corr_lds(c.x, c.y, st2.x, st2.y)
+                                   : exact_corr_global(img2, p.w2, c.x, c.y, a, st1.x, st1.y, st2.x, st2.y);
+        consider(corr, c.x, c.y);
+    };
+
+    uint32_t multi = 0, fallback = 0;
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, count = 0;
+    if (use_lds) {
+        // ---- filter: exact integer numerator, f32 normalisation --------------------------------------
+        float runmax = -__builtin_inff();
+        const float thr_lo = p.threshold - S2_DELTA;
+        const bool major_x = e.ox == 0; // candidates advance along x (x2 == i exactly), stripes shift y
+        for (int off = -cs; off <= cs; off++) {
+            if (!active) break;
+            // The minor coordinate is monotone in i; if it is the same at both ends of the interval it
+            // is the same everywhere and the per-candidate f64 evaluation can be skipped.
+            const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
+            const bool minor_const = major_x ? (cf.y == cl.y) : (cf.x == cl.x);
+            const uint32_t tbase = (uint32_t)(off + cs) * len;
+            for (uint32_t i = r0; i < r1; i++) {
+                CandXY c;
+                if (minor_const) {
+                    c.x = major_x ? i : cf.x;
+                    c.y = major_x ? cf.y : i;
+                } else {
+                    c = candidate_xy(e, i, off);
+                }
+                if (!candidate_in_bounds(p, c)) continue;
+                const uint2 is2 = istats2[(size_t)c.y * p.w2 + c.x];
+                if (!(is2.x & 0x80000000u)) continue; // stdev2 non-finite or < min_stdev (mod.rs:439)
+                evaluated++;
+                const uint32_t a0 =
+                    (uint32_t)((int)c.y - KERNEL_SIZE - by0) * P + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
+                const uint32_t phi = a0 & 7u;
+                const uint8_t *src = tile + phi * CS + (a0 - phi);
+                uint32_t s12 = 0;
+#pragma unroll
+                for (int r = 0; r < KERNEL_WIDTH; r++) {
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
+                    const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
+                    s12 = __builtin_amdgcn_udot4(a[r].a, lo.x, s12, false);
+                    s12 = __builtin_amdgcn_udot4(a[r].b, lo.y, s12, false);
+                    s12 = __builtin_amdgcn_udot4(a[r].c, hi, s12, false);
+                }
+                const int num = (int)(KERNEL_POINT_COUNT * s12) - s1 * (int)(is2.x & 0x7FFFFFFFu);
+                const float g = (float)num * (rv1 * __uint_as_float(is2.y));
+                const float lim = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo);
+                if (g >= lim) {
+                    if (g > runmax + 2.0f * S2_DELTA) count = 0; // everything recorded so far is out of the band
+                    runmax = fmaxf(runmax, g);
+                    const uint32_t t = tbase + (i - r0);
+                    if (count == 0) l0 = t;
+                    else if (count == 1) l1 = t;
+                    else if (count == 2) l2 = t;
+                    else if (count == 3) l3 = t;
+                    count = min(count + 1u, (uint32_t)S2_K + 1u);
+                }
+            }
+        }
+    }
+    // ---- exact re-evaluation, in corridor order: the contenders, or the whole corridor when the tile
+    // did not fit in LDS or more than S2_K candidates fell inside the band ---------------------------
+    if (active) {
+        const bool whole = !use_lds || count > (uint32_t)S2_K;
+        fallback = whole ? 1u : 0u;
+        multi = (!whole && count > 1) ? 1u : 0u;
+        const uint32_t n_exact = whole ? ncand : count;
+        for (uint32_t j = 0; j < n_exact; j++) {
+            const uint32_t t = whole ? j : (j == 0 ? l0 : (j == 1 ? l1 : (j == 2 ? l2 : l3)));
+            exact_candidate(t, !use_lds);
+        }
+    }
+
+    if (in_image) {
+        uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
+        if (have) cell = make_uint2(bx | (by << 16), __float_as_uint(bcorr));
+        out[(size_t)y * p.w1 + x] = cell;
+    }
+    if (counters) {
+        uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = fallback;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            v0 += __shfl_down(v0, sft, 64);
+            v1 += __shfl_down(v1, sft, 64);
+            v2 += __shfl_down(v2, sft, 64);
+            v3 += __shfl_down(v3, sft, 64);
+        }
+        if (lane == 0) {
+            if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
+            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
+            if (v2) atomicAdd(&counters[2], (unsigned long long)v2);
+            if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
+        }
+    }
+}
+
+void launch_search2(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                    const float2 *stats2, const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                    uint2 *out, unsigned long long *counters, hipStream_t s)
+{
+    if (p.row1 <= p.row0) return;
+    dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
+    hipLaunchKernelGGL(search2_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, stats2, istats1, istats2, range,
+                       out, counters);
 }
 
 // ---------------------------------------------------------------------------------------------

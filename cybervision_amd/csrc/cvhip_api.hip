@@ -4,6 +4,7 @@
 #include "cvhip_internal.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -65,6 +66,8 @@ static void free_ctx_buffers(cvhip_ctx *c)
         }
         if (c->img[d]) (void)hipFree(c->img[d]);
         if (c->stats[d]) (void)hipFree(c->stats[d]);
+        if (c->istats[d]) (void)hipFree(c->istats[d]);
+        c->istats[d] = nullptr;
         c->img[d] = nullptr;
         c->stats[d] = nullptr;
     }
@@ -141,8 +144,12 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         c->events_used++;
         CVHIP_TRY_HIP(hipEventRecord(e0, s));
     }
-    launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.cells[next],
-                  c->count_candidates ? c->d_cand : nullptr, s);
+    if (c->search_version == 1)
+        launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.cells[next],
+                      c->count_candidates ? c->d_cand : nullptr, s);
+    else
+        launch_search2(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->istats[a], c->istats[b], c->range,
+                       ds.cells[next], c->count_candidates ? c->d_cand : nullptr, s);
     if (c->time_kernels) CVHIP_TRY_HIP(hipEventRecord(e1, s));
     CVHIP_TRY_HIP(hipGetLastError());
 
@@ -294,6 +301,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     c->dir[0].gh = h1;
     c->dir[1].gw = w2;
     c->dir[1].gh = h2;
+    if (const char *v = std::getenv("CVHIP_SEARCH")) c->search_version = (v[0] == '1') ? 1 : 2;
     const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
     c->max_px = std::max(n1, n2);
     // Level grids are gathered in equal row chunks when sharded, so leave room for one padded
@@ -305,10 +313,11 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
         if (e == hipSuccess) e = hipMalloc(&c->stats[d], c->max_px * sizeof(float2));
+        if (e == hipSuccess) e = hipMalloc(&c->istats[d], c->max_px * sizeof(uint2));
     }
     if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->d_cand, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), dev->d.stream);
+    if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
         e = hipMemsetAsync(c->img[d], 0, c->max_px + IMG_PAD, dev->d.stream);
     if (e != hipSuccess) {
@@ -342,8 +351,8 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
     CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s)); // transfer_in_images, gpu/mod.rs:274
     CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
     report(progress, user, dir, 0.02f);
-    launch_window_stats(ctx->img[0], w1, h1, ctx->stats[0], s);
-    launch_window_stats(ctx->img[1], w2, h2, ctx->stats[1], s);
+    launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
+    launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
     report(progress, user, dir, 0.20f);
     CVHIP_TRY(search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, dir));
     // Pageable host sources must not be reused by the caller before the copy has happened.
@@ -379,8 +388,8 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s));
     CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
-    launch_window_stats(ctx->img[0], w1, h1, ctx->stats[0], s);
-    launch_window_stats(ctx->img[1], w2, h2, ctx->stats[1], s);
+    launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
+    launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
     report(progress, user, 0, 0.20f);
     if (!sharded) {
         ctx->shard_num = 0;
@@ -511,8 +520,28 @@ int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms,
     if (reset) {
         ctx->prof_launches = 0;
         ctx->prof_ms = 0.0;
-        CVHIP_TRY_HIP(hipMemset(ctx->d_cand, 0, sizeof(unsigned long long)));
+        CVHIP_TRY_HIP(hipMemset(ctx->d_cand, 0, 4 * sizeof(unsigned long long)));
     }
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset)
+{
+    if (!ctx || !out) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(set_device(ctx->dev));
+    CVHIP_TRY_HIP(hipStreamSynchronize(ctx->dev->d.stream));
+    unsigned long long v[4] = {0, 0, 0, 0};
+    CVHIP_TRY_HIP(hipMemcpy(v, ctx->d_cand, sizeof(v), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out[i] = (uint64_t)v[i];
+    if (reset) CVHIP_TRY_HIP(hipMemset(ctx->d_cand, 0, sizeof(v)));
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (version != 1 && version != 2) return fail(CVHIP_ERR_INVALID, "search version must be 1 or 2");
+    ctx->search_version = version;
     return CVHIP_OK;
 }
 

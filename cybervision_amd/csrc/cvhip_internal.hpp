@@ -57,12 +57,16 @@ struct CorrParams {
 };
 
 // ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------
-void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float2 *stats, hipStream_t s);
+void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float min_stdev, float2 *stats, uint2 *istats,
+                         hipStream_t s);
 void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
                          hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                    const float2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
                    hipStream_t s);
+void launch_search2(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                    const float2 *stats2, const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                    uint2 *out, unsigned long long *counters, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         hipStream_t s);
 void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
@@ -105,6 +109,8 @@ struct cvhip_ctx {
     cvhip::DirState dir[2];
     uint8_t *img[2] = {nullptr, nullptr}; // level image staging (padded), [0]=searched [1]=target of the call
     float2 *stats[2] = {nullptr, nullptr};
+    uint2 *istats[2] = {nullptr, nullptr};
+    int search_version = 2; // 1 = per-candidate exact kernel, 2 = integer filter + exact re-evaluation
     uint32_t *range = nullptr;
     size_t max_px = 0;
 

@@ -141,6 +141,16 @@ int cvhip_ctx_set_profiling(cvhip_ctx *ctx, int time_kernels, int count_candidat
 int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms, uint64_t *candidates,
                           int reset);
 
+/* Device counters of the search kernel since the last reset (needs count_candidates = 1):
+ * out[0] candidates that passed the reference's bounds/stdev tests (== candidates above),
+ * out[1] exact 121-term f32 evaluations, out[2] pixels whose filter band held 2..4 contenders,
+ * out[3] pixels that re-evaluated their whole corridor exactly (tile too large for LDS, or more
+ * than 4 contenders).  Synchronises. */
+int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
+/* Select the search kernel: 1 = every candidate through the exact serial f32 chain, 2 (default) =
+ * exact-integer filter + exact re-evaluation of the contenders.  Both give identical results. */
+int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
+
 /* ------------------------------------------------------------------------------------------
  * ORB — replaces orb::extract_points (orb.rs:50-84).
  * out_xy: 2*cap u32 (x, y), out_desc: 8*cap u32, *out_n = keypoints written (<= cap).

@@ -30,16 +30,22 @@ def assert_same_grid(got, want, what):
     assert np.isnan(gc[~valid]).all()
 
 
-def run_gpu(dev, c, fused=True, both=False):
+def run_gpu(dev, c, fused=True, both=False, version=None, counters=None):
     p1, p2 = cases.pyramids(c)
     h1, w1 = c["img1"].shape
     h2, w2 = c["img2"].shape
     pc = correlation.PointCorrelations(dev, (w1, h1), (w2, h2), c["F"], correlation.ProjectionMode(c["projection"]))
+    if version is not None:
+        pc.set_search_version(version)
+    if counters is not None:
+        pc.set_profiling(False, True)
     try:
         for i in range(c["steps"] + 1):
             k = c["steps"] - i
             pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=fused)
         fwd = pc.complete(correlation.CorrelationDirection.Forward)
+        if counters is not None:
+            counters.update(pc.get_counters())
         if both:
             return fwd, pc.complete(correlation.CorrelationDirection.Reverse)
         return fwd
@@ -74,6 +80,59 @@ def test_matches_oracle_bit_exact(gpu_device, oracle, name):
     want_f, want_r = run_oracle(oracle, c, both=True)
     assert_same_grid(got_f, want_f, f"{name} forward")
     assert_same_grid(got_r, want_r, f"{name} reverse")
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_exact_kernel_v1_matches_oracle(gpu_device, oracle, name):
+    """The plain kernel that sends every candidate through the exact serial f32 chain."""
+    c = cases.make_case(name)
+    assert_same_grid(run_gpu(gpu_device, c, version=1), run_oracle(oracle, c), f"{name} v1")
+
+
+def adversarial_case(kind):
+    """Inputs built to stress the filter's decision rule: exact ties (periodic texture: many
+    candidates with IDENTICAL scores, the first must win), near-threshold scores and windows whose
+    stdev is close to MIN_STDEV (largest relative rounding error of the reference's f32 chain)."""
+    rng = np.random.default_rng(77)
+    h, w = 160, 200
+    if kind == "periodic":
+        base = rng.integers(0, 256, size=(8, 4), dtype=np.uint8)
+        a = np.tile(base, (h // 8, w // 4))
+        b = a.copy()
+    elif kind == "low_contrast":
+        a = (100 + rng.integers(0, 4, size=(h, w))).astype(np.uint8)   # stdev ~ 1.1
+        b = np.roll(a, 3, axis=1)
+    elif kind == "noisy":
+        t, t2, _ = synth.make_pair(w, h, seed=5)
+        n = rng.integers(-40, 41, size=(h, w))
+        a = t
+        b = np.clip(t2.astype(np.int64) + n, 0, 255).astype(np.uint8)  # scores hover around the 0.6 threshold
+    else:
+        raise KeyError(kind)
+    steps = synth.optimal_scale_steps(w, h)
+    return dict(img1=np.ascontiguousarray(a), img2=np.ascontiguousarray(b), F=synth.F_HORIZONTAL, projection=0,
+                steps=steps)
+
+
+@pytest.mark.parametrize("kind", ["periodic", "low_contrast", "noisy"])
+def test_filter_decision_rule_on_adversarial_inputs(gpu_device, oracle, kind):
+    c = adversarial_case(kind)
+    cnt = {}
+    got = run_gpu(gpu_device, c, both=True, counters=cnt)
+    want = run_oracle(oracle, c, both=True)
+    assert_same_grid(got[0], want[0], f"{kind} forward")
+    assert_same_grid(got[1], want[1], f"{kind} reverse")
+    if kind == "periodic":  # ties must actually have been exercised
+        assert cnt["multi_contender_pixels"] + cnt["whole_corridor_pixels"] > 1000, cnt
+
+
+def test_filter_statistics(gpu_device):
+    """On ordinary textured input nearly every pixel needs exactly one exact evaluation."""
+    c = cases.make_case("h256")
+    cnt = {}
+    run_gpu(gpu_device, c, counters=cnt)
+    assert cnt["exact_evals"] < 0.1 * cnt["candidates"], cnt
+    assert cnt["whole_corridor_pixels"] < 0.01 * 256 * 256 * 2 * 3, cnt
 
 
 @pytest.mark.parametrize("name", cases.GOLDEN_CASES)
