@@ -49,6 +49,7 @@ SIGNATURES = {
     "cvhip_ctx_set_profiling": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cvhip_ctx_get_profile": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                         C.c_int]),
+    "cvhip_ctx_get_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32), C.c_int]),
     "cvhip_ctx_get_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int]),
     "cvhip_ctx_set_search_version": (C.c_int, [_vp, C.c_int]),
     "cvhip_orb_extract": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),

@@ -14,6 +14,8 @@
 // (SURVEY.md §8a N3); only the empty cells are skipped.
 #include "cvhip_internal.hpp"
 
+#include <cstdlib>
+
 namespace cvhip {
 
 // ---------------------------------------------------------------------------------------------
@@ -103,10 +105,10 @@ __device__ __forceinline__ uint32_t corridor_end_of(const CorrParams &p, const L
 // integer sum converted once is bit-identical.  stdev: serial row-major f32 sum of squares.
 // ---------------------------------------------------------------------------------------------
 //
-// istats[i] = {window sum s (exact integer) | VALID << 31, f32 bits of 1/sqrt(V)} with
-// V = 121*sum(a^2) - s^2 (exact integer): the inputs of the exact-integer candidate filter of
-// search2_kernel.  VALID mirrors the reference's per-candidate test "stdev finite and >= min_stdev"
-// (mod.rs:439) evaluated on the reference's own f32 stdev.
+// istats[i] = {window sum s (exact integer) | VALID << 31, f32 bits of stdev}: everything
+// search2_kernel needs per candidate in one 8-byte word (avg = (float)s / 121 exactly, see above).
+// VALID mirrors the reference's per-candidate test "stdev finite and >= min_stdev" (mod.rs:439)
+// evaluated on the reference's own f32 stdev.
 __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
                                                             float min_stdev, float2 *__restrict__ stats,
                                                             uint2 *__restrict__ istats)
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
     uint2 iout = make_uint2(0u, 0u);
     if (x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < w && y + KERNEL_SIZE < h) {
         const uint8_t *base = img + (size_t)(y - KERNEL_SIZE) * w + (x - KERNEL_SIZE);
-        uint32_t isum = 0, isq = 0;
+        uint32_t isum = 0;
         Row12 rows[KERNEL_WIDTH];
 #pragma unroll
         for (int r = 0; r < KERNEL_WIDTH; r++) {
@@ -127,10 +129,6 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
             isum += __builtin_amdgcn_udot4(rows[r].a, 0x01010101u, 0u, false);
             isum += __builtin_amdgcn_udot4(rows[r].b, 0x01010101u, 0u, false);
             isum += __builtin_amdgcn_udot4(rows[r].c, 0x00010101u, 0u, false);
-            const uint32_t c3 = rows[r].c & 0x00FFFFFFu;
-            isq = __builtin_amdgcn_udot4(rows[r].a, rows[r].a, isq, false);
-            isq = __builtin_amdgcn_udot4(rows[r].b, rows[r].b, isq, false);
-            isq = __builtin_amdgcn_udot4(c3, c3, isq, false);
         }
         const float avg = (float)isum / (float)KERNEL_POINT_COUNT;
         float sd = 0.0f;
@@ -144,10 +142,8 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
             }
         }
         out = make_float2(avg, sqrtf(sd / (float)KERNEL_POINT_COUNT));
-        const uint32_t v = (uint32_t)KERNEL_POINT_COUNT * isq - isum * isum; // < 2^30, exact
         const bool valid = finite_f32(out.y) && !(fabsf(out.y) < min_stdev);
-        const float rv = v ? 1.0f / sqrtf((float)v) : 0.0f;
-        iout = make_uint2(isum | (valid ? 0x80000000u : 0u), __float_as_uint(rv));
+        iout = make_uint2(isum | (valid ? 0x80000000u : 0u), __float_as_uint(out.y));
     }
     stats[(size_t)y * w + x] = out;
     istats[(size_t)y * w + x] = iout;
@@ -163,13 +159,60 @@ void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float min_s
 // ---------------------------------------------------------------------------------------------
 // search_range: estimate_search_range (mod.rs:468-540) on the compact previous-level grid.
 // One thread per searched pixel; writes start | end << 16, or RANGE_NONE.
+//
+// Exact simplifications (bit-identical to the reference):
+//  * corridor_pos = (scale*m - add) / coeff (mod.rs:508-511) always selects the axis whose
+//    coefficient get_epipolar_line set to exactly 1.0 and whose `add` it set to exactly 0.0
+//    (mod.rs:397-408: the branch taken fixes |other coeff| <= 1 - 2^-53 < 1), so it equals scale*m.
+//  * scale*m = coord_prev << (pk - k) is an integer, so the f64 sum for the mean is exact and can
+//    be an integer sum; only the squared-deviation sum needs f64 in the reference's scan order.
+// The previous-level cells a 64x4 pixel tile can see (<= 44 x 14 for consecutive levels) are staged
+// once in LDS: every cell is visited twice by up to ~100 pixels.
 // ---------------------------------------------------------------------------------------------
+constexpr int SR_TILE_W = 80, SR_TILE_H = 24; // LDS window of previous-level cells per workgroup
+
+__device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x, uint32_t y, uint32_t &xs0,
+                                                uint32_t &xs1, uint32_t &ys0, uint32_t &ys1)
+{
+    // mod.rs:481-491, window in FULL-RES cells, then the occupied (previous-level) cells inside it:
+    // full-res X = x' << pk with x' < pw
+    const float scale = p.scale;
+    uint32_t x_min = f32_to_u32_sat(floorf((float)sat_sub_u32(x, NEIGHBOR_DISTANCE) / scale));
+    uint32_t x_max = f32_to_u32_sat(ceilf((float)(x + NEIGHBOR_DISTANCE) / scale));
+    uint32_t y_min = f32_to_u32_sat(floorf((float)sat_sub_u32(y, NEIGHBOR_DISTANCE) / scale));
+    uint32_t y_max = f32_to_u32_sat(ceilf((float)(y + NEIGHBOR_DISTANCE) / scale));
+    x_min = min(x_min, p.gw);
+    x_max = min(x_max, p.gw);
+    y_min = min(y_min, p.gh);
+    y_max = min(y_max, p.gh);
+    const uint32_t step = 1u << p.pk;
+    xs0 = (x_min + step - 1) >> p.pk;
+    xs1 = min((x_max + step - 1) >> p.pk, p.pw);
+    ys0 = (y_min + step - 1) >> p.pk;
+    ys1 = min((y_max + step - 1) >> p.pk, p.ph);
+}
+
 __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const float2 *__restrict__ stats1,
                                                             const uint2 *__restrict__ prev,
                                                             uint32_t *__restrict__ range)
 {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = p.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t cells[SR_TILE_W * SR_TILE_H];
+    const uint32_t bx = blockIdx.x * 64, by = p.row0 + blockIdx.y * 4;
+    const uint32_t x = bx + (threadIdx.x & 63);
+    const uint32_t y = by + (threadIdx.x >> 6);
+    // window of the whole tile = union of its corner pixels' windows (the bounds are monotone in x, y)
+    uint32_t tx0, tx1, ty0, ty1, ux0, ux1, uy0, uy1;
+    neighbor_window(p, bx, by, tx0, ux1, ty0, uy1);
+    neighbor_window(p, min(bx + 63, p.w1 - 1), min(by + 3, p.h1 - 1), ux0, tx1, uy0, ty1);
+    const uint32_t tw = tx1 > tx0 ? tx1 - tx0 : 0u, th = ty1 > ty0 ? ty1 - ty0 : 0u;
+    const bool staged = tw <= (uint32_t)SR_TILE_W && th <= (uint32_t)SR_TILE_H;
+    if (staged) {
+        for (uint32_t u = threadIdx.x; u < tw * th; u += 256) {
+            const uint32_t r = u / tw, c = u - r * tw;
+            cells[r * SR_TILE_W + c] = prev[(size_t)(ty0 + r) * p.pw + (tx0 + c)].x;
+        }
+    }
+    __syncthreads();
     if (x >= p.w1 || y >= p.row1) return;
     uint32_t out = RANGE_NONE;
     const bool interior = x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
@@ -180,48 +223,32 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
             if (line_finite(e)) {
                 const uint32_t corridor_start = KERNEL_SIZE;
                 const uint32_t corridor_end = corridor_end_of(p, e);
-                const float scale = p.scale;
-                // mod.rs:481-491, window in FULL-RES cells
-                uint32_t x_min = f32_to_u32_sat(floorf((float)sat_sub_u32(x, NEIGHBOR_DISTANCE) / scale));
-                uint32_t x_max = f32_to_u32_sat(ceilf((float)(x + NEIGHBOR_DISTANCE) / scale));
-                uint32_t y_min = f32_to_u32_sat(floorf((float)sat_sub_u32(y, NEIGHBOR_DISTANCE) / scale));
-                uint32_t y_max = f32_to_u32_sat(ceilf((float)(y + NEIGHBOR_DISTANCE) / scale));
-                x_min = min(x_min, p.gw);
-                x_max = min(x_max, p.gw);
-                y_min = min(y_min, p.gh);
-                y_max = min(y_max, p.gh);
-                const bool corridor_vertical = fabs(e.cy) > fabs(e.cx);
-                // occupied cells are the previous level's: full-res X = x' << pk, x' < pw
-                const uint32_t step = 1u << p.pk;
-                const uint32_t xs0 = (x_min + step - 1) >> p.pk, xs1 = min((x_max + step - 1) >> p.pk, p.pw);
-                const uint32_t ys0 = (y_min + step - 1) >> p.pk, ys1 = min((y_max + step - 1) >> p.pk, p.ph);
-                const double dscale = (double)scale;
-
-                double mid_corridor = 0.0;
+                uint32_t xs0, xs1, ys0, ys1;
+                neighbor_window(p, x, y, xs0, xs1, ys0, ys1);
+                // axis of corridor_pos: y for the (1, 0)-offset branch, x otherwise (see header)
+                const uint32_t ash = e.ox == 1 ? 16u : 0u;
+                const uint32_t up = p.pk - p.k; // corridor_pos = coordinate << up, an integer
+                auto cell_at = [&](uint32_t xx, uint32_t yy) -> uint32_t {
+                    return staged ? cells[(yy - ty0) * SR_TILE_W + (xx - tx0)] : prev[(size_t)yy * p.pw + xx].x;
+                };
+                unsigned long long isum = 0;
                 uint32_t neighbor_count = 0;
                 for (uint32_t yy = ys0; yy < ys1; yy++) {
                     for (uint32_t xx = xs0; xx < xs1; xx++) {
-                        const uint32_t cell = prev[(size_t)yy * p.pw + xx].x;
+                        const uint32_t cell = cell_at(xx, yy);
                         if (cell == CELL_NONE) continue;
-                        const double p2x = dscale * (double)((cell & 0xFFFFu) << p.pk);
-                        const double p2y = dscale * (double)((cell >> 16) << p.pk);
-                        const double corridor_pos = corridor_vertical ? (p2y - e.ay) / e.cy : (p2x - e.ax) / e.cx;
                         neighbor_count += 1;
-                        mid_corridor += corridor_pos;
+                        isum += (unsigned long long)(((cell >> ash) & 0xFFFFu) << up);
                     }
                 }
                 if (neighbor_count != 0) {
-                    mid_corridor /= (double)neighbor_count;
+                    const double mid_corridor = (double)isum / (double)neighbor_count; // exact sum, one rounding
                     double range_stdev = 0.0;
                     for (uint32_t yy = ys0; yy < ys1; yy++) {
                         for (uint32_t xx = xs0; xx < xs1; xx++) {
-                            const uint32_t cell = prev[(size_t)yy * p.pw + xx].x;
+                            const uint32_t cell = cell_at(xx, yy);
                             if (cell == CELL_NONE) continue;
-                            const double p2x = dscale * (double)((cell & 0xFFFFu) << p.pk);
-                            const double p2y = dscale * (double)((cell >> 16) << p.pk);
-                            const double corridor_pos =
-                                corridor_vertical ? (p2y - e.ay) / e.cy : (p2x - e.ax) / e.cx;
-                            const double delta = corridor_pos - mid_corridor;
+                            const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
                             range_stdev += delta * delta;
                         }
                     }
@@ -364,17 +391,19 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
 // search2: the same correlate_point / correlate_corridor_area (mod.rs:321-384, 411-466) with an
 // exact-integer pre-filter.
 //
-// For every candidate c of a searched pixel the reference computes a float score f(c) through a
-// serial 121-term f32 chain.  The real-valued NCC it approximates is
-//     rho(c) = (121*S12 - s1*s2) / sqrt(V1*V2),   S12 = sum a*b, s = window sum, V = 121*sum a^2 - s^2,
-// all of which are integers < 2^31 for u8 images, so rho's numerator and denominator can be formed
-// EXACTLY with v_dot4_u32_u8 (4 multiply-adds per lane-op instead of 3 ops per term).  g(c) is
-// rho(c) rounded through a handful of f32 operations (relative error < 8 * 2^-24).
-//
-// Error bound |f(c) - g(c)| <= DELTA (derivation in DESIGN.md §4): the reference's rounding of
-// avg (enters only at second order because the true deviations sum to zero), of each delta
-// (<= 2^-17 absolute), of the 121 products and partial sums (gamma_122), of the two f32 stdevs and
-// of the final divide add up to < 764 * 2^-24 = 4.6e-5 when both stdevs are >= min_stdev = 1.
+// For every candidate c of a searched pixel the reference computes
+//     f(c) = fl( S_f / fl(fl(sd1*sd2)*121) ),   S_f = serial f32 sum of fl(d1_k * d2_k)      (mod.rs:442-454)
+// where S_f approximates  sum (a_k - mean1)(b_k - mean2) = N / 121  with the EXACT integer
+//     N = 121*S12 - s1*s2,   S12 = sum a_k*b_k,   s = window sum          (all < 2^31 for u8 images).
+// S12 is formed exactly with v_dot4_u32_u8 (4 multiply-adds per lane-op instead of 3 ops per term) and
+//     g(c) = (float)N / (121 * 121 * sd1 * sd2)
+// uses the reference's OWN f32 stdevs, so the denominator's rounding cancels and only the numerator's
+// matters.  Error bound |f(c) - g(c)| <= DELTA (derivation in DESIGN.md §4), in units of u = 2^-24:
+//   deltas d = fl(a - avg): |rounding| <= 2^-17 = 128u each; the error of avg itself enters only at
+//     second order because the true deviations sum to zero  ->  128u*(1/sd1 + 1/sd2) <= 256u  (sd >= 1)
+//   121 rounded products + 121 serial additions (gamma_122)                      <= 122u
+//   final divide, denominator products, the filter's own f32 steps               <= 15u
+// total < 393u = 2.35e-5.
 //
 // Decision rule: the reference keeps the FIRST candidate (in stripe, i order) that maximises f
 // among those with f >= threshold.  Such a candidate c* satisfies g(c*) >= max g - 2*DELTA and
@@ -391,8 +420,14 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
 // apart, so 64 lanes reading consecutive candidates hit 64 distinct bank pairs.
 // ---------------------------------------------------------------------------------------------
 constexpr int S2_K = 4;                 // contenders kept per pixel before falling back to the full corridor
-constexpr int S2_LDS_BYTES = 40960;     // 8 copies of the target tile; 4 workgroups per CU
-constexpr float S2_DELTA = 5.0e-5f;     // >= 764 * 2^-24 + filter rounding (see above)
+constexpr int S2_LDS_BYTES = 40448;     // 8 tile copies + candidate statistics; 3-4 workgroups per CU
+constexpr float S2_DELTA = 2.5e-5f;     // >= 393 * 2^-24 (see above)
+
+// Contender word written by the filter kernel, one u64 per searched pixel:
+//   bits [0, 60): up to four 15-bit candidate codes (stripe index << 11 | i - r0), oldest first
+//   bits [60, 63): count 0..4; CW_WHOLE = re-evaluate the whole corridor exactly
+constexpr unsigned long long CW_WHOLE = 5ull;
+constexpr uint32_t CW_MAX_LEN = 2048u;  // i - r0 must fit in 11 bits
 
 struct CandXY {
     uint32_t x, y;
@@ -412,37 +447,41 @@ __device__ __forceinline__ bool candidate_in_bounds(const CorrParams &p, const C
     return !(c.x < KERNEL_SIZE || c.x >= p.w2 - KERNEL_SIZE || c.y < KERNEL_SIZE || c.y >= p.h2 - KERNEL_SIZE);
 }
 
-// Exact f32 score of one candidate from GLOBAL memory (also the v1 inner loop): mod.rs:442-454.
-__device__ __forceinline__ float exact_corr_global(const uint8_t *__restrict__ img2, uint32_t w2, uint32_t x2,
-                                                   uint32_t y2, const Row12 (&a)[KERNEL_WIDTH], float avg1,
-                                                   float stdev1, float avg2, float stdev2)
+// Per-pixel setup shared by both kernels: mod.rs:321-364.  Returns false when the pixel yields None
+// without looking at any candidate.
+struct PixelSetup {
+    float2 st1;
+    Line e;
+    uint32_t r0, r1;
+};
+__device__ __forceinline__ bool pixel_setup(const CorrParams &p, uint32_t x, uint32_t y,
+                                            const float2 *__restrict__ stats1, const uint32_t *__restrict__ range,
+                                            PixelSetup &ps)
 {
-    float corr = 0.0f;
-    const uint8_t *base = img2 + (size_t)(y2 - KERNEL_SIZE) * w2 + (x2 - KERNEL_SIZE);
-#pragma unroll
-    for (int r = 0; r < KERNEL_WIDTH; r++) {
-        const Row12 row = load_row12(base + (size_t)r * w2);
-#pragma unroll
-        for (int c = 0; c < KERNEL_WIDTH; c++) {
-            const uint32_t wa = c < 4 ? a[r].a : (c < 8 ? a[r].b : a[r].c);
-            const uint32_t wb = c < 4 ? row.a : (c < 8 ? row.b : row.c);
-            const float delta1 = byte_f32(wa, c & 3) - avg1;
-            const float delta2 = byte_f32(wb, c & 3) - avg2;
-            corr += delta1 * delta2;
-        }
+    if (!(x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1)) return false;
+    ps.st1 = stats1[(size_t)y * p.w1 + x];
+    ps.e = epipolar_line(p, x, y);
+    if (!(finite_f32(ps.st1.y) && !(fabsf(ps.st1.y) < p.min_stdev) && line_finite(ps.e))) return false; // :334-345
+    ps.r0 = KERNEL_SIZE;
+    ps.r1 = corridor_end_of(p, ps.e);
+    if (!p.first_pass) { // mod.rs:351-364
+        const uint32_t rg = range[(size_t)y * p.w1 + x];
+        if (rg == RANGE_NONE) return false;
+        ps.r0 = rg & 0xFFFFu;
+        ps.r1 = rg >> 16;
     }
-    return corr / (stdev1 * stdev2 * (float)KERNEL_POINT_COUNT);
+    return ps.r0 < ps.r1;
 }
 
-__global__ __launch_bounds__(256, 3) void search2_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                          const uint8_t *__restrict__ img2,
-                                                          const float2 *__restrict__ stats1,
-                                                          const float2 *__restrict__ stats2,
-                                                          const uint2 *__restrict__ istats1,
-                                                          const uint2 *__restrict__ istats2,
-                                                          const uint32_t *__restrict__ range,
-                                                          uint2 *__restrict__ out,
-                                                          unsigned long long *__restrict__ counters)
+// ---- kernel A: filter ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                                 const uint8_t *__restrict__ img2,
+                                                                 const float2 *__restrict__ stats1,
+                                                                 const uint2 *__restrict__ istats1,
+                                                                 const uint2 *__restrict__ istats2,
+                                                                 const uint32_t *__restrict__ range,
+                                                                 unsigned long long *__restrict__ contenders,
+                                                                 unsigned long long *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[S2_LDS_BYTES];
     __shared__ int bb[4]; // min x, min y, max x, max y of in-bounds candidate centres
@@ -458,32 +497,16 @@ __global__ __launch_bounds__(256, 3) void search2_kernel(CorrParams p, const uin
         bb[3] = -1;
     }
 
-    // ---- per-pixel setup: mod.rs:321-364 ---------------------------------------------------------
-    const bool interior =
-        in_image && x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
-    float2 st1 = make_float2(0.0f, 0.0f);
-    Line e;
-    e.cx = e.cy = e.ax = e.ay = 0.0;
-    e.ox = e.oy = 0;
-    uint32_t r0 = 0, r1 = 0;
-    bool active = false;
-    if (interior) {
-        st1 = stats1[(size_t)y * p.w1 + x];
-        e = epipolar_line(p, x, y);
-        active = finite_f32(st1.y) && !(fabsf(st1.y) < p.min_stdev) && line_finite(e);
-        r0 = KERNEL_SIZE;
-        r1 = corridor_end_of(p, e);
-        if (active && !p.first_pass) {
-            const uint32_t rg = range[(size_t)y * p.w1 + x];
-            active = rg != RANGE_NONE;
-            r0 = rg & 0xFFFFu;
-            r1 = rg >> 16;
-        }
-        active = active && r0 < r1;
-    }
+    PixelSetup ps;
+    ps.st1 = make_float2(0.0f, 1.0f);
+    ps.e.cx = ps.e.cy = ps.e.ax = ps.e.ay = 0.0;
+    ps.e.ox = ps.e.oy = 0;
+    ps.r0 = ps.r1 = 0;
+    const bool active = in_image && pixel_setup(p, x, y, stats1, range, ps);
+    const Line &e = ps.e;
+    const uint32_t r0 = ps.r0, r1 = ps.r1;
     const uint32_t len = active ? r1 - r0 : 0u;
     const int cs = p.corridor_size;
-    const uint32_t ncand = len * (uint32_t)(2 * cs + 1);
 
     // ---- bounding box of the in-bounds candidate centres (corners of the monotone corridor) -------
     int lminx = 0x7FFFFFFF, lminy = 0x7FFFFFFF, lmaxx = -1, lmaxy = -1;
@@ -515,15 +538,20 @@ __global__ __launch_bounds__(256, 3) void search2_kernel(CorrParams p, const uin
         atomicMax(&bb[3], lmaxy);
     }
     __syncthreads();
-    const int bx0 = bb[0] - KERNEL_SIZE, by0 = bb[1] - KERNEL_SIZE;
+    const bool any_active = bb[2] >= 0;
+    const int cx0 = bb[0], cy0 = bb[1];
+    const int bx0 = cx0 - KERNEL_SIZE, by0 = cy0 - KERNEL_SIZE;
     const int bwid = bb[2] - bb[0] + 2 * KERNEL_SIZE + 2; // + 1 for the 12th byte of a row read
     const int bhei = bb[3] - bb[1] + 2 * KERNEL_SIZE + 1;
-    const bool any_active = bb[2] >= 0;
     const uint32_t P = any_active ? (uint32_t)((bwid + 7) & ~7) : 8u;                 // row pitch, multiple of 8
     const uint32_t CS = any_active ? ((P * (uint32_t)bhei + 16u + 255u) & ~255u) + 32u : 0u; // copy stride
-    const bool use_lds = any_active && 8u * CS <= (uint32_t)S2_LDS_BYTES;
+    // per-candidate statistics (istats2) of every candidate centre in the box, staged next to the tile
+    const uint32_t cw = any_active ? (uint32_t)(bb[2] - bb[0] + 1) : 0u, ch = any_active ? (uint32_t)(bb[3] - bb[1] + 1) : 0u;
+    const uint32_t IS_OFF = 8u * CS;
+    const bool use_lds = any_active && IS_OFF + cw * ch * 8u <= (uint32_t)S2_LDS_BYTES;
+    const uint2 *lds_is = reinterpret_cast<const uint2 *>(tile + IS_OFF);
 
-    // ---- stage the target tile: 8 byte-shifted copies ---------------------------------------------
+    // ---- stage the target tile (8 byte-shifted copies) and the candidate statistics -----------------
     if (use_lds) {
         const uint32_t cols4 = P >> 2;
         const uint32_t units = cols4 * (uint32_t)bhei;
@@ -540,176 +568,293 @@ __global__ __launch_bounds__(256, 3) void search2_kernel(CorrParams p, const uin
             *reinterpret_cast<uint32_t *>(tile + 6 * CS + o) = __builtin_amdgcn_alignbyte(g.c, g.b, 2);
             *reinterpret_cast<uint32_t *>(tile + 7 * CS + o) = __builtin_amdgcn_alignbyte(g.c, g.b, 3);
         }
+        for (uint32_t u = threadIdx.x; u < cw * ch; u += 256) {
+            const uint32_t row = u / cw, col = u - row * cw;
+            *reinterpret_cast<uint2 *>(tile + IS_OFF + 8u * u) =
+                istats2[(size_t)(cy0 + (int)row) * p.w2 + (size_t)(cx0 + (int)col)];
+        }
     }
     __syncthreads();
 
-    // ---- searched window, packed bytes (12th byte zero so a 12-byte target row can be used whole) ---
-    Row12 a[KERNEL_WIDTH];
-    int s1 = 0;
-    float rv1 = 0.0f;
-    if (active) {
-        const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
+    unsigned long long word = 0ull; // count 0 = None
+    uint32_t evaluated = 0, multi = 0, whole = 0;
+    if (active && (!use_lds || len > CW_MAX_LEN)) {
+        word = CW_WHOLE << 60;
+        whole = 1;
+    } else if (active) {
+        // searched window, packed bytes: a[] has the 12th byte zero, ap[] = (0, a0..a10).  A 12-byte target
+        // row read at address q then serves BOTH the candidate whose window starts at q (with a[]) and the
+        // one starting at q + 1 (with ap[]): two candidates per LDS row read.
+        Row12 a[KERNEL_WIDTH], ap[KERNEL_WIDTH];
+        {
+            const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
 #pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH; r++) {
-            a[r] = load_row12(base + (size_t)r * p.w1);
-            a[r].c &= 0x00FFFFFFu;
-        }
-        const uint2 is1 = istats1[(size_t)y * p.w1 + x];
-        s1 = (int)(is1.x & 0x7FFFFFFFu);
-        rv1 = __uint_as_float(is1.y);
-    } else {
-#pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH; r++) a[r].a = a[r].b = a[r].c = 0u;
-    }
-
-    uint32_t evaluated = 0, exact_evals = 0;
-    bool have = false;
-    float bcorr = 0.0f;
-    uint32_t bx = 0, by = 0;
-
-    // exact score of candidate (x2, y2) with the tile in LDS (mod.rs:442-454, serial f32 chain)
-    auto exact_corr_lds = [&](uint32_t x2, uint32_t y2, float avg2, float stdev2) -> float {
-        const uint32_t a0 = (uint32_t)((int)y2 - KERNEL_SIZE - by0) * P + (uint32_t)((int)x2 - KERNEL_SIZE - bx0);
-        const uint32_t phi = a0 & 7u;
-        const uint8_t *src = tile + phi * CS + (a0 - phi);
-        float corr = 0.0f;
-#pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH; r++) {
-            const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
-            const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
-#pragma unroll
-            for (int c = 0; c < KERNEL_WIDTH; c++) {
-                const uint32_t wa = c < 4 ? a[r].a : (c < 8 ? a[r].b : a[r].c);
-                const uint32_t wb = c < 4 ? lo.x : (c < 8 ? lo.y : hi);
-                const float delta1 = byte_f32(wa, c & 3) - st1.x;
-                const float delta2 = byte_f32(wb, c & 3) - avg2;
-                corr += delta1 * delta2;
+            for (int r = 0; r < KERNEL_WIDTH; r++) {
+                a[r] = load_row12(base + (size_t)r * p.w1);
+                a[r].c &= 0x00FFFFFFu;
+                ap[r].a = a[r].a << 8;
+                ap[r].b = __builtin_amdgcn_alignbyte(a[r].b, a[r].a, 3);
+                ap[r].c = __builtin_amdgcn_alignbyte(a[r].c, a[r].b, 3);
             }
         }
-        return corr / (st1.y * stdev2 * (float)KERNEL_POINT_COUNT);
-    };
-    // the reference's acceptance rule, mod.rs:456-464
-    auto consider = [&](float corr, uint32_t x2, uint32_t y2) {
-        if (corr >= p.threshold && (!have || corr > bcorr)) {
-            have = true;
-            bcorr = corr;
-            bx = x2;
-            by = y2;
-        }
-    };
-    // exact evaluation of candidate number t (stripe-major order), with all the reference's skips
-    auto exact_candidate = [&](uint32_t t, bool count_it) {
-        const int off = (int)(t / len) - cs;
-        const uint32_t i = r0 + (t % len);
-        const CandXY c = candidate_xy(e, i, off);
-        if (!candidate_in_bounds(p, c)) return;
-        const float2 st2 = stats2[(size_t)c.y * p.w2 + c.x];
-        if (!finite_f32(st2.y) || fabsf(st2.y) < p.min_stdev) return;
-        if (count_it) evaluated++;
-        exact_evals++;
-        const float corr = use_lds ? exact_corr_lds(c.x, c.y, st2.x, st2.y)
-                                   : exact_corr_global(img2, p.w2, c.x, c.y, a, st1.x, st1.y, st2.x, st2.y);
-        consider(corr, c.x, c.y);
-    };
+        const int s1 = (int)(istats1[(size_t)y * p.w1 + x].x & 0x7FFFFFFFu);
+        const float c1 = 1.0f / (ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT)); // 1/(121*121*sd1)
 
-    uint32_t multi = 0, fallback = 0;
-    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, count = 0;
-    if (use_lds) {
-        // ---- filter: exact integer numerator, f32 normalisation --------------------------------------
         float runmax = -__builtin_inff();
         const float thr_lo = p.threshold - S2_DELTA;
+        const float ninf = -__builtin_inff();
+        unsigned long long clist = 0ull;
+        uint32_t count = 0;
+        // band bookkeeping: candidate `code` (stripe << 11 | i - r0) joins the contender list
+        auto record = [&](float g, uint32_t code) {
+            const float lim = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo);
+            if (g >= lim) {
+                if (g > runmax + 2.0f * S2_DELTA) { // everything recorded so far is out of the band
+                    count = 0;
+                    clist = 0ull;
+                }
+                runmax = fmaxf(runmax, g);
+                if (count < (uint32_t)S2_K) clist |= (unsigned long long)code << (15u * count);
+                count = min(count + 1u, (uint32_t)S2_K + 1u);
+            }
+        };
+        auto score = [&](uint32_t s12, uint2 is2) -> float {
+            const int num = (int)(KERNEL_POINT_COUNT * s12) - s1 * (int)(is2.x & 0x7FFFFFFFu);
+            return (float)num * (c1 * __builtin_amdgcn_rcpf(__uint_as_float(is2.y)));
+        };
         const bool major_x = e.ox == 0; // candidates advance along x (x2 == i exactly), stripes shift y
         for (int off = -cs; off <= cs; off++) {
-            if (!active) break;
             // The minor coordinate is monotone in i; if it is the same at both ends of the interval it
             // is the same everywhere and the per-candidate f64 evaluation can be skipped.
             const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
             const bool minor_const = major_x ? (cf.y == cl.y) : (cf.x == cl.x);
-            const uint32_t tbase = (uint32_t)(off + cs) * len;
-            for (uint32_t i = r0; i < r1; i++) {
-                CandXY c;
-                if (minor_const) {
-                    c.x = major_x ? i : cf.x;
-                    c.y = major_x ? cf.y : i;
-                } else {
-                    c = candidate_xy(e, i, off);
-                }
-                if (!candidate_in_bounds(p, c)) continue;
-                const uint2 is2 = istats2[(size_t)c.y * p.w2 + c.x];
-                if (!(is2.x & 0x80000000u)) continue; // stdev2 non-finite or < min_stdev (mod.rs:439)
-                evaluated++;
-                const uint32_t a0 =
-                    (uint32_t)((int)c.y - KERNEL_SIZE - by0) * P + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
-                const uint32_t phi = a0 & 7u;
-                const uint8_t *src = tile + phi * CS + (a0 - phi);
-                uint32_t s12 = 0;
+            const uint32_t tbase = (uint32_t)(off + cs) << 11;
+            if (major_x) {
+                // Candidates advance along x; the row y2 is constant over the stripe or steps occasionally.
+                // Two horizontally adjacent candidates in the same row share their LDS row reads; the two dot
+                // chains are independent and interleaved, and the candidate statistics are read before the
+                // dots and consumed after them.
+                const uint32_t i_hi = min(r1, p.w2 - KERNEL_SIZE);
+                uint32_t i = max(r0, (uint32_t)KERNEL_SIZE);
+                while (i < i_hi) {
+                    const bool has2 = i + 1 < i_hi;
+                    uint32_t ya = cf.y, yb = cf.y;
+                    if (!minor_const) {
+                        ya = candidate_xy(e, i, off).y;
+                        yb = has2 ? candidate_xy(e, i + 1, off).y : ya;
+                    }
+                    const bool pair = has2 && yb == ya;
+                    const uint32_t ti = tbase + (i - r0);
+                    const uint32_t icur = i;
+                    i += pair ? 2u : 1u;
+                    if (ya < KERNEL_SIZE || ya >= p.h2 - KERNEL_SIZE) continue;
+                    const uint2 *isrow = lds_is + (ya - (uint32_t)cy0) * cw + (icur - (uint32_t)cx0);
+                    const uint2 is0 = isrow[0];
+                    const uint2 is1 = isrow[pair ? 1 : 0];
+                    const uint32_t a0 = (uint32_t)((int)ya - KERNEL_SIZE - by0) * P + icur - (uint32_t)(KERNEL_SIZE + bx0);
+                    const uint32_t phi = a0 & 7u;
+                    const uint8_t *src = tile + phi * CS + (a0 - phi);
+                    // all 22 row reads in flight first, then the two independent dot chains interleaved
+                    uint2 lo[KERNEL_WIDTH];
+                    uint32_t hi[KERNEL_WIDTH];
 #pragma unroll
-                for (int r = 0; r < KERNEL_WIDTH; r++) {
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
-                    const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
-                    s12 = __builtin_amdgcn_udot4(a[r].a, lo.x, s12, false);
-                    s12 = __builtin_amdgcn_udot4(a[r].b, lo.y, s12, false);
-                    s12 = __builtin_amdgcn_udot4(a[r].c, hi, s12, false);
+                    for (int r = 0; r < KERNEL_WIDTH; r++) {
+                        lo[r] = *reinterpret_cast<const uint2 *>(src + r * P);
+                        hi[r] = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint32_t s12a = 0, s12b = 0;
+#pragma unroll
+                    for (int r = 0; r < KERNEL_WIDTH; r++) {
+                        s12a = __builtin_amdgcn_udot4(a[r].a, lo[r].x, s12a, false);
+                        s12b = __builtin_amdgcn_udot4(ap[r].a, lo[r].x, s12b, false);
+                        s12a = __builtin_amdgcn_udot4(a[r].b, lo[r].y, s12a, false);
+                        s12b = __builtin_amdgcn_udot4(ap[r].b, lo[r].y, s12b, false);
+                        s12a = __builtin_amdgcn_udot4(a[r].c, hi[r], s12a, false);
+                        s12b = __builtin_amdgcn_udot4(ap[r].c, hi[r], s12b, false);
+                    }
+                    // Pin both sums here: without this the compiler sinks each chain into an `if (valid)`
+                    // block, serialising the chains.
+                    asm volatile("" : "+v"(s12a), "+v"(s12b));
+                    const bool v0 = (is0.x & 0x80000000u) != 0;          // mod.rs:439 on the reference's stdev
+                    const bool v1 = pair && (is1.x & 0x80000000u) != 0;
+                    evaluated += (v0 ? 1u : 0u) + (v1 ? 1u : 0u);
+                    const float g0 = v0 ? score(s12a, is0) : ninf, g1 = v1 ? score(s12b, is1) : ninf;
+                    // one rarely-taken branch for the pair (keeps both chains ahead of it)
+                    if (fmaxf(g0, g1) >= fmaxf(runmax - 2.0f * S2_DELTA, thr_lo)) {
+                        record(g0, ti);
+                        record(g1, ti + 1);
+                    }
                 }
-                const int num = (int)(KERNEL_POINT_COUNT * s12) - s1 * (int)(is2.x & 0x7FFFFFFFu);
-                const float g = (float)num * (rv1 * __uint_as_float(is2.y));
-                const float lim = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo);
-                if (g >= lim) {
-                    if (g > runmax + 2.0f * S2_DELTA) count = 0; // everything recorded so far is out of the band
-                    runmax = fmaxf(runmax, g);
-                    const uint32_t t = tbase + (i - r0);
-                    if (count == 0) l0 = t;
-                    else if (count == 1) l1 = t;
-                    else if (count == 2) l2 = t;
-                    else if (count == 3) l3 = t;
-                    count = min(count + 1u, (uint32_t)S2_K + 1u);
+            } else {
+                for (uint32_t i = r0; i < r1; i++) {
+                    CandXY c;
+                    if (minor_const) { // column-constant stripe (x2 fixed, y2 == i)
+                        c.x = cf.x;
+                        c.y = i;
+                    } else {
+                        c = candidate_xy(e, i, off);
+                    }
+                    if (!candidate_in_bounds(p, c)) continue;
+                    const uint2 is2 = lds_is[(c.y - (uint32_t)cy0) * cw + (c.x - (uint32_t)cx0)];
+                    const uint32_t a0 =
+                        (uint32_t)((int)c.y - KERNEL_SIZE - by0) * P + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
+                    const uint32_t phi = a0 & 7u;
+                    const uint8_t *src = tile + phi * CS + (a0 - phi);
+                    uint32_t s12 = 0, s12x = 0;
+#pragma unroll
+                    for (int r = 0; r < KERNEL_WIDTH; r++) {
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
+                        const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
+                        s12 = __builtin_amdgcn_udot4(a[r].a, lo.x, s12, false);
+                        s12x = __builtin_amdgcn_udot4(a[r].b, lo.y, s12x, false);
+                        s12 = __builtin_amdgcn_udot4(a[r].c, hi, s12, false);
+                    }
+                    asm volatile("" : "+v"(s12), "+v"(s12x));
+                    const bool v = (is2.x & 0x80000000u) != 0; // stdev2 finite and >= min_stdev (mod.rs:439)
+                    evaluated += v ? 1u : 0u;
+                    const float g = score(s12 + s12x, is2);
+                    record(v ? g : ninf, tbase + (i - r0));
                 }
             }
         }
-    }
-    // ---- exact re-evaluation, in corridor order: the contenders, or the whole corridor when the tile
-    // did not fit in LDS or more than S2_K candidates fell inside the band ---------------------------
-    if (active) {
-        const bool whole = !use_lds || count > (uint32_t)S2_K;
-        fallback = whole ? 1u : 0u;
-        multi = (!whole && count > 1) ? 1u : 0u;
-        const uint32_t n_exact = whole ? ncand : count;
-        for (uint32_t j = 0; j < n_exact; j++) {
-            const uint32_t t = whole ? j : (j == 0 ? l0 : (j == 1 ? l1 : (j == 2 ? l2 : l3)));
-            exact_candidate(t, !use_lds);
+        if (count > (uint32_t)S2_K) {
+            word = CW_WHOLE << 60;
+            whole = 1;
+            evaluated = 0; // the exact kernel walks (and counts) the whole corridor
+        } else {
+            word = clist | ((unsigned long long)count << 60);
+            multi = count > 1 ? 1u : 0u;
         }
     }
-
-    if (in_image) {
-        uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
-        if (have) cell = make_uint2(bx | (by << 16), __float_as_uint(bcorr));
-        out[(size_t)y * p.w1 + x] = cell;
-    }
+    if (in_image) contenders[(size_t)y * p.w1 + x] = word;
     if (counters) {
-        uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = fallback;
+        uint32_t v0 = evaluated, v2 = multi, v3 = whole;
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) {
             v0 += __shfl_down(v0, sft, 64);
-            v1 += __shfl_down(v1, sft, 64);
             v2 += __shfl_down(v2, sft, 64);
             v3 += __shfl_down(v3, sft, 64);
         }
         if (lane == 0) {
             if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
-            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
             if (v2) atomicAdd(&counters[2], (unsigned long long)v2);
             if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
         }
     }
 }
 
-void launch_search2(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                    const float2 *stats2, const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                    uint2 *out, unsigned long long *counters, hipStream_t s)
+// ---- kernel B: exact re-evaluation of the contenders (mod.rs:442-464), in corridor order --------------
+__global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                             const uint8_t *__restrict__ img2,
+                                                             const float2 *__restrict__ stats1,
+                                                             const uint2 *__restrict__ istats2,
+                                                             const uint32_t *__restrict__ range,
+                                                             const unsigned long long *__restrict__ contenders,
+                                                             uint2 *__restrict__ out,
+                                                             unsigned long long *__restrict__ counters)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t x = blockIdx.x * 64 + lane;
+    const uint32_t y = p.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool in_image = x < p.w1 && y < p.row1;
+    const unsigned long long word = in_image ? contenders[(size_t)y * p.w1 + x] : 0ull;
+    const uint32_t count = (uint32_t)(word >> 60);
+    uint32_t evaluated = 0, exact_evals = 0;
+    uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
+    PixelSetup ps;
+    if (count != 0 && pixel_setup(p, x, y, stats1, range, ps)) {
+        const int cs = p.corridor_size;
+        const uint32_t len = ps.r1 - ps.r0;
+        // compute_point_data deltas (mod.rs:727-731); avg identical to stats1.x
+        float d1[KERNEL_POINT_COUNT];
+        {
+            const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
+#pragma unroll
+            for (int r = 0; r < KERNEL_WIDTH; r++) {
+                const Row12 row = load_row12(base + (size_t)r * p.w1);
+#pragma unroll
+                for (int c = 0; c < KERNEL_WIDTH; c++) {
+                    const uint32_t wv = c < 4 ? row.a : (c < 8 ? row.b : row.c);
+                    d1[r * KERNEL_WIDTH + c] = byte_f32(wv, c & 3) - ps.st1.x;
+                }
+            }
+        }
+        bool have = false;
+        float bcorr = 0.0f;
+        uint32_t bx = 0, by = 0;
+        auto exact_candidate = [&](uint32_t sidx, uint32_t di, bool count_it) {
+            const CandXY c = candidate_xy(ps.e, ps.r0 + di, (int)sidx - cs);
+            if (!candidate_in_bounds(p, c)) return;
+            const uint2 is2 = istats2[(size_t)c.y * p.w2 + c.x];
+            if (!(is2.x & 0x80000000u)) return; // stdev2 non-finite or < min_stdev (mod.rs:437-441)
+            if (count_it) evaluated++;
+            exact_evals++;
+            const float avg2 = (float)(is2.x & 0x7FFFFFFFu) / (float)KERNEL_POINT_COUNT; // == compute_point_avg
+            const float stdev2 = __uint_as_float(is2.y);
+            float corr = 0.0f;
+            const uint8_t *base = img2 + (size_t)(c.y - KERNEL_SIZE) * p.w2 + (c.x - KERNEL_SIZE);
+#pragma unroll
+            for (int r = 0; r < KERNEL_WIDTH; r++) {
+                const Row12 row = load_row12(base + (size_t)r * p.w2);
+#pragma unroll
+                for (int cc = 0; cc < KERNEL_WIDTH; cc++) {
+                    const uint32_t wv = cc < 4 ? row.a : (cc < 8 ? row.b : row.c);
+                    const float delta2 = byte_f32(wv, cc & 3) - avg2;
+                    corr += d1[r * KERNEL_WIDTH + cc] * delta2;
+                }
+            }
+            corr /= ps.st1.y * stdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
+            if (corr >= p.threshold && (!have || corr > bcorr)) {  // mod.rs:456-464
+                have = true;
+                bcorr = corr;
+                bx = c.x;
+                by = c.y;
+            }
+        };
+        if (count >= (uint32_t)CW_WHOLE) {
+            for (uint32_t sidx = 0; sidx < (uint32_t)(2 * cs + 1); sidx++)
+                for (uint32_t di = 0; di < len; di++) exact_candidate(sidx, di, true);
+        } else {
+            for (uint32_t j = 0; j < count; j++) {
+                const uint32_t code = (uint32_t)(word >> (15u * j)) & 0x7FFFu;
+                exact_candidate(code >> 11, code & 0x7FFu, false);
+            }
+        }
+        if (have) cell = make_uint2(bx | (by << 16), __float_as_uint(bcorr));
+    }
+    if (in_image) out[(size_t)y * p.w1 + x] = cell;
+    if (counters) {
+        uint32_t v0 = evaluated, v1 = exact_evals;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            v0 += __shfl_down(v0, sft, 64);
+            v1 += __shfl_down(v1, sft, 64);
+        }
+        if (lane == 0) {
+            if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
+            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
+        }
+    }
+}
+
+void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                           const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                           unsigned long long *contenders, unsigned long long *counters, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
-    hipLaunchKernelGGL(search2_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, stats2, istats1, istats2, range,
+    hipLaunchKernelGGL(search2_filter_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2, range,
+                       contenders, counters);
+}
+
+void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                          const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
+                          uint2 *out, unsigned long long *counters, hipStream_t s)
+{
+    if (p.row1 <= p.row0) return;
+    dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
+    hipLaunchKernelGGL(search2_exact_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats2, range, contenders,
                        out, counters);
 }
 

@@ -72,14 +72,51 @@ static void free_ctx_buffers(cvhip_ctx *c)
         c->stats[d] = nullptr;
     }
     if (c->range) (void)hipFree(c->range);
+    if (c->contenders) (void)hipFree(c->contenders);
+    c->contenders = nullptr;
     if (c->d_cand) (void)hipFree(c->d_cand);
     c->range = nullptr;
     c->d_cand = nullptr;
     for (auto &ev : c->events) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.e0);
+        (void)hipEventDestroy(ev.e1);
     }
     c->events.clear();
+}
+
+// Bracket a launch with HIP events on the context's stream when kernel timing is on.
+template <typename F> static int timed(cvhip_ctx *c, int cls, F &&launch)
+{
+    hipStream_t s = c->dev->d.stream;
+    if (!c->time_kernels) {
+        launch();
+        return CVHIP_OK;
+    }
+    if (c->events_used == c->events.size()) {
+        cvhip_ctx::TimedLaunch t;
+        CVHIP_TRY_HIP(hipEventCreate(&t.e0));
+        CVHIP_TRY_HIP(hipEventCreate(&t.e1));
+        t.cls = cls;
+        c->events.push_back(t);
+    }
+    cvhip_ctx::TimedLaunch &t = c->events[c->events_used++];
+    t.cls = cls;
+    CVHIP_TRY_HIP(hipEventRecord(t.e0, s));
+    launch();
+    CVHIP_TRY_HIP(hipEventRecord(t.e1, s));
+    return CVHIP_OK;
+}
+
+static int resolve_events(cvhip_ctx *c)
+{
+    for (size_t i = 0; i < c->events_used; i++) {
+        float ms = 0.0f;
+        CVHIP_TRY_HIP(hipEventElapsedTime(&ms, c->events[i].e0, c->events[i].e1));
+        c->prof_ms[c->events[i].cls] += (double)ms;
+        c->prof_launches[c->events[i].cls]++;
+    }
+    c->events_used = 0;
+    return CVHIP_OK;
 }
 
 // Rows of an lh-row level image owned by this context's shard: equal chunks of ceil(lh/den).
@@ -126,31 +163,32 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     p.pk = ds.k;
     p.k = (uint32_t)k;
     p.first_pass = first_pass ? 1 : 0;
+    {
+        static const int dbg = [] { const char *v = std::getenv("CVHIP_DEBUG"); return v ? std::atoi(v) : 0; }();
+        p.debug = k == 0 ? dbg : 0; // only the full-resolution level, so coarser levels still seed it
+    }
     shard_rows(c, lh1, &p.row0, &p.row1);
 
     const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
-    if (!first_pass) launch_search_range(p, c->stats[a], ds.cells[prev], c->range, s);
-
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->time_kernels) {
-        if (c->events_used == c->events.size()) {
-            hipEvent_t x, y;
-            CVHIP_TRY_HIP(hipEventCreate(&x));
-            CVHIP_TRY_HIP(hipEventCreate(&y));
-            c->events.emplace_back(x, y);
-        }
-        e0 = c->events[c->events_used].first;
-        e1 = c->events[c->events_used].second;
-        c->events_used++;
-        CVHIP_TRY_HIP(hipEventRecord(e0, s));
+    unsigned long long *cnt = c->count_candidates ? c->d_cand : nullptr;
+    if (!first_pass)
+        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->stats[a], ds.cells[prev], c->range, s); }));
+    if (c->search_version == 1) {
+        CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
+            launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.cells[next], cnt, s);
+        }));
+    } else {
+        if (!(p.debug & 2))
+            CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
+                launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
+                                      c->contenders, cnt, s);
+            }));
+        if (!(p.debug & 1))
+            CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
+                launch_search2_exact(p, c->img[a], c->img[b], c->stats[a], c->istats[b], c->range, c->contenders,
+                                     ds.cells[next], cnt, s);
+            }));
     }
-    if (c->search_version == 1)
-        launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.cells[next],
-                      c->count_candidates ? c->d_cand : nullptr, s);
-    else
-        launch_search2(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->istats[a], c->istats[b], c->range,
-                       ds.cells[next], c->count_candidates ? c->d_cand : nullptr, s);
-    if (c->time_kernels) CVHIP_TRY_HIP(hipEventRecord(e1, s));
     CVHIP_TRY_HIP(hipGetLastError());
 
     ds.cur = next;
@@ -168,8 +206,10 @@ static int cross_check_pass(cvhip_ctx *c, int k, int dir)
     if (!own.valid || !other.valid) return fail(CVHIP_ERR_INVALID, "cross_check_filter before both passes ran");
     if ((int)own.k != k || (int)other.k != k)
         return fail(CVHIP_ERR_INVALID, "cross_check_filter scale does not match the grids' current level");
-    launch_cross_check(own.cells[own.cur], other.cells[other.cur], own.lw, own.lh, other.lw, other.lh,
-                       c->dev->d.stream);
+    CVHIP_TRY(timed(c, cvhip_ctx::K_CROSS, [&] {
+        launch_cross_check(own.cells[own.cur], other.cells[other.cur], own.lw, own.lh, other.lw, other.lh,
+                           c->dev->d.stream);
+    }));
     CVHIP_TRY_HIP(hipGetLastError());
     return CVHIP_OK;
 }
@@ -316,6 +356,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         if (e == hipSuccess) e = hipMalloc(&c->istats[d], c->max_px * sizeof(uint2));
     }
     if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->contenders, c->max_px * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
@@ -351,8 +392,10 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
     CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s)); // transfer_in_images, gpu/mod.rs:274
     CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
     report(progress, user, dir, 0.02f);
-    launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
-    launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+    CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
+        launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
+        launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+    }));
     report(progress, user, dir, 0.20f);
     CVHIP_TRY(search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, dir));
     // Pageable host sources must not be reused by the caller before the copy has happened.
@@ -388,8 +431,10 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s));
     CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
-    launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
-    launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+    CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
+        launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
+        launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+    }));
     report(progress, user, 0, 0.20f);
     if (!sharded) {
         ctx->shard_num = 0;
@@ -441,7 +486,8 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
         }
     }
     if (ds.valid) {
-        launch_expand_grid(ds.cells[ds.cur], ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy, d_corr, s);
+        (void)timed(ctx, cvhip_ctx::K_EXPAND,
+                    [&] { launch_expand_grid(ds.cells[ds.cur], ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy, d_corr, s); });
     } else { // nothing computed: all None, like a fresh Grid (mod.rs:183-184)
         launch_fill_u32(reinterpret_cast<uint32_t *>(d_xy), 0xFFFFFFFFu, n * 2, s);
         if (d_corr) launch_fill_u32(reinterpret_cast<uint32_t *>(d_corr), 0x7FC00000u, n, s);
@@ -505,22 +551,35 @@ int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms,
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY_HIP(hipStreamSynchronize(s));
-    for (size_t i = 0; i < ctx->events_used; i++) {
-        float ms = 0.0f;
-        CVHIP_TRY_HIP(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
-        ctx->prof_ms += (double)ms;
-        ctx->prof_launches++;
-    }
-    ctx->events_used = 0;
+    CVHIP_TRY(resolve_events(ctx));
     unsigned long long cand = 0;
     CVHIP_TRY_HIP(hipMemcpy(&cand, ctx->d_cand, sizeof(cand), hipMemcpyDeviceToHost));
-    if (launches) *launches = ctx->prof_launches;
-    if (search_ms) *search_ms = ctx->prof_ms;
+    if (launches) *launches = ctx->prof_launches[cvhip_ctx::K_SEARCH];
+    if (search_ms) *search_ms = ctx->prof_ms[cvhip_ctx::K_SEARCH];
     if (candidates) *candidates = (uint64_t)cand;
     if (reset) {
-        ctx->prof_launches = 0;
-        ctx->prof_ms = 0.0;
+        for (int i = 0; i < cvhip_ctx::K_COUNT; i++) {
+            ctx->prof_launches[i] = 0;
+            ctx->prof_ms[i] = 0.0;
+        }
         CVHIP_TRY_HIP(hipMemset(ctx->d_cand, 0, 4 * sizeof(unsigned long long)));
+    }
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[6], uint32_t launches[6], int reset)
+{
+    if (!ctx || !ms || !launches) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(set_device(ctx->dev));
+    CVHIP_TRY_HIP(hipStreamSynchronize(ctx->dev->d.stream));
+    CVHIP_TRY(resolve_events(ctx));
+    for (int i = 0; i < cvhip_ctx::K_COUNT; i++) {
+        ms[i] = ctx->prof_ms[i];
+        launches[i] = ctx->prof_launches[i];
+        if (reset) {
+            ctx->prof_launches[i] = 0;
+            ctx->prof_ms[i] = 0.0;
+        }
     }
     return CVHIP_OK;
 }

@@ -54,6 +54,7 @@ struct CorrParams {
     uint32_t k;              // this level's k
     uint32_t row0, row1;     // rows of the searched image handled by this launch
     int first_pass;
+    int debug; // profiling aid (CVHIP_DEBUG): 1 = skip exact phase, 2 = skip filter phase, 4 = skip staging
 };
 
 // ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------
@@ -64,9 +65,12 @@ void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                    const float2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
                    hipStream_t s);
-void launch_search2(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                    const float2 *stats2, const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                    uint2 *out, unsigned long long *counters, hipStream_t s);
+void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                           const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                           unsigned long long *contenders, unsigned long long *counters, hipStream_t s);
+void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                          const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
+                          uint2 *out, unsigned long long *counters, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         hipStream_t s);
 void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
@@ -112,6 +116,7 @@ struct cvhip_ctx {
     uint2 *istats[2] = {nullptr, nullptr};
     int search_version = 2; // 1 = per-candidate exact kernel, 2 = integer filter + exact re-evaluation
     uint32_t *range = nullptr;
+    unsigned long long *contenders = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
     size_t max_px = 0;
 
     uint32_t shard_num = 0, shard_den = 1;
@@ -120,8 +125,14 @@ struct cvhip_ctx {
 
     int time_kernels = 0, count_candidates = 0;
     unsigned long long *d_cand = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    // kernel classes timed with HIP events when time_kernels is set
+    enum { K_STATS = 0, K_RANGE, K_SEARCH, K_EXACT, K_CROSS, K_EXPAND, K_COUNT };
+    struct TimedLaunch {
+        hipEvent_t e0, e1;
+        int cls;
+    };
+    std::vector<TimedLaunch> events;
     size_t events_used = 0;
-    uint32_t prof_launches = 0;
-    double prof_ms = 0.0;
+    uint32_t prof_launches[K_COUNT] = {0};
+    double prof_ms[K_COUNT] = {0};
 };

@@ -141,6 +141,11 @@ int cvhip_ctx_set_profiling(cvhip_ctx *ctx, int time_kernels, int count_candidat
 int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms, uint64_t *candidates,
                           int reset);
 
+/* Per-kernel-class device time since the last reset (needs time_kernels = 1), measured with HIP
+ * events on the context's stream: [0] window statistics, [1] search-range estimation, [2] search
+ * (filter kernel, or the whole search for version 1), [3] exact re-evaluation, [4] cross-check,
+ * [5] grid expansion in complete().  Synchronises. */
+int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[6], uint32_t launches[6], int reset);
 /* Device counters of the search kernel since the last reset (needs count_candidates = 1):
  * out[0] candidates that passed the reference's bounds/stdev tests (== candidates above),
  * out[1] exact 121-term f32 evaluations, out[2] pixels whose filter band held 2..4 contenders,
