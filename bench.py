@@ -31,24 +31,23 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_F32_NOFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op per lane-clock (no FMA allowed)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# v_dot4_u32_u8 issues at 4 cycles per wave-instruction per SIMD on gfx950 (measured with
+# scripts/micro/valu_rate.hip: 4.4 at 8 waves/SIMD), i.e. 64 lanes x 4 MAC / 4 cycles per SIMD:
+DOT4_PEAK_TMACS = 256 * 4 * 64 * 4 / 4 * 2.4e9 / 1e12   # = 157.3 T multiply-adds/s, the filter kernel's roof
 
 
 def algorithmic_work(level_dims, candidates):
-    """Algorithmic bytes/flops of ALL search_kernel launches of one step.
-    Per (level, direction) pass over n1 searched and n2 target pixels, each array touched once:
-    img1 u8 (1) + stats1 (8) + range (4) + result cell write (8) per searched pixel,
-    img2 u8 (1) + stats2 (8) per target pixel.  Flops: 363 per evaluated candidate
-    (121 x {sub, mul, add}) + 121 per interior searched pixel (its window deltas)."""
+    """Algorithmic bytes / multiply-adds of ALL search2_filter_kernel launches of one step
+    (DESIGN.md §4).  Per (level, direction) pass, each array touched once: searched pixel = img1 u8 (1)
+    + stats1 (8) + istats1 (8) + range (4) + contender word written (8) = 29 B; target pixel = img2 u8
+    (1) + istats2 (8) = 9 B.  Multiply-adds: 121 per evaluated candidate (the 11x11 integer dot)."""
     b = 0
-    fl = 363.0 * candidates
     for (w1, h1, w2, h2) in level_dims:
         n1, n2 = w1 * h1, w2 * h2
-        b += n1 * (1 + 8 + 4 + 8) + n2 * (1 + 8)   # forward
-        b += n2 * (1 + 8 + 4 + 8) + n1 * (1 + 8)   # reverse
-        fl += 121.0 * ((w1 - 10) * (h1 - 10) + (w2 - 10) * (h2 - 10))
-    return b, fl
+        b += n1 * 29 + n2 * 9   # forward
+        b += n2 * 29 + n1 * 9   # reverse
+    return b, 121.0 * candidates
 
 
 def main():
@@ -109,7 +108,7 @@ def main():
     # one counting pass (untimed): candidates evaluated per step, needed for the flop count
     pc.set_profiling(False, True)
     step()
-    cand_local = pc.get_profile()["candidates"]
+    cand_local = pc.get_counters()["candidates"]
     pc.set_profiling(False, False)
     for _ in range(max(args.warmup - 1, 0)):
         step()
@@ -120,10 +119,11 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    prof = pc.get_profile()
+    ktimes = pc.get_kernel_times()
     pc.set_profiling(False, False)
+    search_ms_local = ktimes["search"]["ms"]
 
-    t = torch.tensor([dt, float(cand_local), prof["search_ms"]], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, float(cand_local), search_ms_local], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -134,18 +134,18 @@ def main():
         search_ms = float(tmax[2])
     else:
         candidates = int(cand_local)
-        search_ms = prof["search_ms"]
+        search_ms = search_ms_local
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         mpx = W * H / 1e6
         value = mpx / (ms_per_step / 1e3)
-        bytes_alg, flops_alg = algorithmic_work(level_dims, candidates)
-        search_ms_per_step = search_ms / args.steps          # all search_kernel launches of one step (slowest rank)
-        launches_per_step = prof["launches"] / args.steps
+        bytes_alg, macs_alg = algorithmic_work(level_dims, candidates)
+        search_ms_per_step = search_ms / args.steps          # all filter-kernel launches of one step (slowest rank)
+        launches_per_step = ktimes["search"]["launches"] / args.steps
         # per-rank share of the algorithmic work when sharded
         ach_gbs = bytes_alg / world / (search_ms_per_step / 1e3) / 1e9
-        ach_tf = flops_alg / world / (search_ms_per_step / 1e3) / 1e12
+        ach_tmacs = macs_alg / world / (search_ms_per_step / 1e3) / 1e12
         result = {
             "metric": "Mpixels/s dense correlation, 4096x4096 pair" if W == 4096 else f"Mpixels/s dense correlation, {W}x{H} pair",
             "value": round(value, 3),
@@ -157,7 +157,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "u8 (exact integer filter) + f32/f64 (reference-order exact re-evaluation)",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} u8 value-noise pair, integer disparity field |d|<={max(W // 64, 1)}px, "
                                    f"affine parameter set (11x11 window, 5 stripes, thr 0.6), F = horizontal epipolar "
@@ -166,7 +166,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"row-sharded x{world}, RCCL all-gather per sharded pass",
                        "candidates_per_step": candidates},
             "roofline": {
-                "kernel": "search_kernel",
+                "kernel": "search2_filter_kernel",
                 "bound": "hbm",
                 "achieved": round(ach_gbs, 2),
                 "peak": HBM_PEAK_GBS,
@@ -176,12 +176,13 @@ def main():
                 "launches_per_step": launches_per_step,
                 "avg_launch_ms": round(search_ms_per_step / max(launches_per_step, 1), 4),
                 "algorithmic_bytes_per_step": bytes_alg,
-                "note": "the exact search is VALU-bound by construction (no FMA allowed, ~1e3 flop/B); "
-                        "see `compute` for the binding roof",
-                "compute": {"bound": "valu_f32_nofma", "achieved": round(ach_tf, 3), "peak": VALU_F32_NOFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(ach_tf / VALU_F32_NOFMA_TFLOPS, 4),
-                            "algorithmic_flops_per_step": flops_alg},
+                "note": "the search is compute-bound by construction (121 multiply-adds per candidate on ~0.5 B of "
+                        "compulsory traffic); `compute` prices it against the v_dot4_u32_u8 issue roof",
+                "compute": {"bound": "valu_dot4_u8", "achieved": round(ach_tmacs, 3),
+                            "peak": round(DOT4_PEAK_TMACS, 1), "unit": "T multiply-adds/s",
+                            "frac": round(ach_tmacs / DOT4_PEAK_TMACS, 4), "algorithmic_macs_per_step": macs_alg},
             },
+            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in ktimes.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cvref  # CPU oracle: only as the reported baseline, never on the product path

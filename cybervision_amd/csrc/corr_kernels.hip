@@ -170,6 +170,7 @@ void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float min_s
 // once in LDS: every cell is visited twice by up to ~100 pixels.
 // ---------------------------------------------------------------------------------------------
 constexpr int SR_TILE_W = 80, SR_TILE_H = 24; // LDS window of previous-level cells per workgroup
+constexpr int SR_WIN = 11;                    // cells per axis of one pixel's window, consecutive levels
 
 __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x, uint32_t y, uint32_t &xs0,
                                                 uint32_t &xs1, uint32_t &ys0, uint32_t &ys1)
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
                                                             const uint2 *__restrict__ prev,
                                                             uint32_t *__restrict__ range)
 {
-    __shared__ uint32_t cells[SR_TILE_W * SR_TILE_H];
+    __shared__ uint32_t cells[SR_TILE_W * SR_TILE_H + SR_WIN]; // + slack for the predicated row reads
     const uint32_t bx = blockIdx.x * 64, by = p.row0 + blockIdx.y * 4;
     const uint32_t x = bx + (threadIdx.x & 63);
     const uint32_t y = by + (threadIdx.x >> 6);
@@ -231,27 +232,62 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
                 auto cell_at = [&](uint32_t xx, uint32_t yy) -> uint32_t {
                     return staged ? cells[(yy - ty0) * SR_TILE_W + (xx - tx0)] : prev[(size_t)yy * p.pw + xx].x;
                 };
+                // A window never spans more than SR_WIN cells per axis for consecutive levels
+                // ((20 << k) >> pk) + 1 <= 11); the unrolled, predicated form below keeps all LDS offsets
+                // immediate and has no per-cell loop control.  Scan order is still row-major.
                 unsigned long long isum = 0;
                 uint32_t neighbor_count = 0;
-                for (uint32_t yy = ys0; yy < ys1; yy++) {
-                    for (uint32_t xx = xs0; xx < xs1; xx++) {
-                        const uint32_t cell = cell_at(xx, yy);
-                        if (cell == CELL_NONE) continue;
-                        neighbor_count += 1;
-                        isum += (unsigned long long)(((cell >> ash) & 0xFFFFu) << up);
+                const bool small = staged && xs1 - xs0 <= (uint32_t)SR_WIN && xs1 > xs0;
+                double range_stdev = 0.0;
+                double mid_corridor = 0.0;
+                if (small) {
+                    const uint32_t nx = xs1 - xs0;
+                    for (uint32_t yy = ys0; yy < ys1; yy++) {
+                        const uint32_t *row = &cells[(yy - ty0) * SR_TILE_W + (xs0 - tx0)];
+#pragma unroll
+                        for (uint32_t j = 0; j < (uint32_t)SR_WIN; j++) {
+                            const uint32_t cell = row[j];
+                            const bool ok = j < nx && cell != CELL_NONE;
+                            neighbor_count += ok ? 1u : 0u;
+                            isum += ok ? (unsigned long long)(((cell >> ash) & 0xFFFFu) << up) : 0ull;
+                        }
                     }
-                }
-                if (neighbor_count != 0) {
-                    const double mid_corridor = (double)isum / (double)neighbor_count; // exact sum, one rounding
-                    double range_stdev = 0.0;
+                    if (neighbor_count != 0) {
+                        mid_corridor = (double)isum / (double)neighbor_count; // exact sum, one rounding
+                        for (uint32_t yy = ys0; yy < ys1; yy++) {
+                            const uint32_t *row = &cells[(yy - ty0) * SR_TILE_W + (xs0 - tx0)];
+#pragma unroll
+                            for (uint32_t j = 0; j < (uint32_t)SR_WIN; j++) {
+                                const uint32_t cell = row[j];
+                                const bool ok = j < nx && cell != CELL_NONE;
+                                const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
+                                const double next = range_stdev + delta * delta;
+                                range_stdev = ok ? next : range_stdev;
+                            }
+                        }
+                    }
+                } else {
                     for (uint32_t yy = ys0; yy < ys1; yy++) {
                         for (uint32_t xx = xs0; xx < xs1; xx++) {
                             const uint32_t cell = cell_at(xx, yy);
                             if (cell == CELL_NONE) continue;
-                            const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
-                            range_stdev += delta * delta;
+                            neighbor_count += 1;
+                            isum += (unsigned long long)(((cell >> ash) & 0xFFFFu) << up);
                         }
                     }
+                    if (neighbor_count != 0) {
+                        mid_corridor = (double)isum / (double)neighbor_count;
+                        for (uint32_t yy = ys0; yy < ys1; yy++) {
+                            for (uint32_t xx = xs0; xx < xs1; xx++) {
+                                const uint32_t cell = cell_at(xx, yy);
+                                if (cell == CELL_NONE) continue;
+                                const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
+                                range_stdev += delta * delta;
+                            }
+                        }
+                    }
+                }
+                if (neighbor_count != 0) {
                     range_stdev = sqrt(range_stdev / (double)neighbor_count);
                     const uint32_t center = f64_to_u32_sat(round(mid_corridor));
                     const uint32_t length = f64_to_u32_sat(round(p.min_range + range_stdev * p.extend_range));
@@ -474,7 +510,7 @@ __device__ __forceinline__ bool pixel_setup(const CorrParams &p, uint32_t x, uin
 }
 
 // ---- kernel A: filter ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+__global__ __launch_bounds__(256, 4) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                                  const uint8_t *__restrict__ img2,
                                                                  const float2 *__restrict__ stats1,
                                                                  const uint2 *__restrict__ istats1,
@@ -878,7 +914,14 @@ __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ ow
     const uint32_t min_y = min(sat_sub_u32(my, sa), rh), max_y = min(my + sa + 1, rh);
     const uint32_t r_min_x = sat_sub_u32(x, sa), r_max_x = x + sa + 1;
     const uint32_t r_min_y = sat_sub_u32(y, sa), r_max_y = y + sa + 1;
-    bool found = false;
+    // The result is an existence test (mod.rs:613-623 returns true at the first hit), so the scan
+    // order is free: probe the window centre first — a consistent pair of matches points straight
+    // back — and fall back to the full row-major scan only when that fails.
+    auto points_back = [&](uint32_t rm) {
+        const uint32_t rx = rm & 0xFFFFu, ry = rm >> 16;
+        return rm != CELL_NONE && rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y;
+    };
+    bool found = mx < rw && my < rh && points_back(other[(size_t)my * rw + mx].x);
     for (uint32_t sy = min_y; sy < max_y && !found; sy++) {
         for (uint32_t sx = min_x; sx < max_x; sx++) {
             const uint32_t rm = other[(size_t)sy * rw + sx].x;
