@@ -50,6 +50,17 @@ def algorithmic_work(level_dims, candidates):
     return b, 121.0 * candidates
 
 
+def traffic_per_launch(world):
+    """HBM bytes per search2_filter_kernel launch from the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied: scripts/collect_traffic.py);
+    committed under profiles/.  None when no PMC data matches this configuration."""
+    f = ROOT / "profiles" / "current_traffic.json"
+    if world != 1 or not f.exists():
+        return None
+    k = json.loads(f.read_text())["kernels"].get("search2_filter_kernel")
+    return round(k["hbm_bytes_per_step"] / k["launches_per_step"]) if k else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,7 +183,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic_per_launch(world),
                 "launches_per_step": launches_per_step,
                 "avg_launch_ms": round(search_ms_per_step / max(launches_per_step, 1), 4),
                 "algorithmic_bytes_per_step": bytes_alg,
