@@ -59,6 +59,14 @@ def make_allgather(rank: int, world: int, group=None, device: bool = True):
         mine = full[rank * shard_bytes:(rank + 1) * shard_bytes]
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(full, mine, group=group)  # in place: mine is full's rank-th chunk
+        elif device:
+            # gloo cannot all-gather device memory: stage through the host (test / fallback path only)
+            import torch
+
+            torch.cuda.current_stream().synchronize()
+            outs = [torch.empty(shard_bytes, dtype=torch.uint8) for _ in range(n_shards)]
+            dist.all_gather(outs, mine.cpu(), group=group)
+            full.copy_(torch.cat(outs))
         else:
             outs = [full[r * shard_bytes:(r + 1) * shard_bytes] for r in range(n_shards)]
             dist.all_gather(outs, mine.clone(), group=group)

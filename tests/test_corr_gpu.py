@@ -344,3 +344,26 @@ def test_sharded_level_call_with_gather_hook(gpu_device, oracle):
         raise AssertionError("sharded level without a gather hook must fail")
     finally:
         pc.close()
+
+
+def test_two_rank_sharded_level_calls():
+    """End-to-end N = 2: two processes (sharing this box's one GPU) row-shard every search pass,
+    cvhip_correlate_level drives the all-gather hook itself (gloo staged through the host here; RCCL
+    on a real multi-GPU node), and both ranks must reproduce the golden grid bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(root / "tests" / "_shard_gpu_worker.py"), "persp_240x180"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {rank} ok" in out, out
