@@ -54,9 +54,12 @@ class GpuDevice:
         if hardware_mode == HardwareMode.Cpu:
             raise ValueError("HardwareMode.Cpu has no GPU device (the CPU path is the reference's own)")
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().cvhip_device_create_on_stream(int(hardware_mode == HardwareMode.GpuLowPower), ordinal,
-                                                            C.c_void_p(stream or 0), C.byref(self._h)),
-                   "cvhip_device_create")
+        low = int(hardware_mode == HardwareMode.GpuLowPower)
+        if stream is None:
+            rc = _lib.lib().cvhip_device_create(low, ordinal, C.byref(self._h))
+        else:  # 0 is a valid value: HIP's default (null) stream, which is torch's default current stream
+            rc = _lib.lib().cvhip_device_create_on_stream(low, ordinal, C.c_void_p(stream), C.byref(self._h))
+        _lib.check(rc, "cvhip_device_create")
 
     @property
     def handle(self):

@@ -245,14 +245,20 @@ extern "C" {
 const char *cvhip_last_error(void) { return g_last_error.c_str(); }
 uint32_t cvhip_abi_version(void) { return 1; }
 
-int cvhip_device_create_on_stream(int low_power, int ordinal, void *hip_stream, cvhip_device **out);
+static int device_create(int low_power, int ordinal, bool caller_stream, void *hip_stream, cvhip_device **out);
 
 int cvhip_device_create(int low_power, int ordinal, cvhip_device **out)
 {
-    return cvhip_device_create_on_stream(low_power, ordinal, nullptr, out);
+    return device_create(low_power, ordinal, false, nullptr, out);
 }
 
 int cvhip_device_create_on_stream(int low_power, int ordinal, void *hip_stream, cvhip_device **out)
+{
+    // hip_stream == NULL is HIP's default (null) stream — e.g. torch's default current stream
+    return device_create(low_power, ordinal, true, hip_stream, out);
+}
+
+static int device_create(int low_power, int ordinal, bool caller_stream, void *hip_stream, cvhip_device **out)
 {
     if (!out) return fail(CVHIP_ERR_INVALID, "out is null");
     *out = nullptr;
@@ -269,7 +275,7 @@ int cvhip_device_create_on_stream(int low_power, int ordinal, void *hip_stream, 
     dev->d.ordinal = ordinal;
     dev->d.low_power = low_power;
     dev->d.name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-    if (hip_stream) { // caller's stream (e.g. torch's current stream): work is ordered with the caller's
+    if (caller_stream) { // caller's stream (e.g. torch's current stream): work is ordered with the caller's
         dev->d.stream = reinterpret_cast<hipStream_t>(hip_stream);
         dev->d.owns_stream = false;
     } else {

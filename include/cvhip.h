@@ -61,7 +61,8 @@ uint32_t cvhip_abi_version(void);
 int cvhip_device_create(int low_power, int ordinal, cvhip_device **out);
 /* Same, but all work is submitted to the caller's HIP stream (a hipStream_t passed as void*,
  * e.g. torch.cuda.current_stream().cuda_stream) so it is ordered with the caller's own work
- * (collectives between passes when row-sharding).  The stream is not owned by the library. */
+ * (collectives between passes when row-sharding).  NULL means HIP's default (null) stream.  The
+ * stream is not owned by the library. */
 int cvhip_device_create_on_stream(int low_power, int ordinal, void *hip_stream, cvhip_device **out);
 void cvhip_device_destroy(cvhip_device *dev);
 /* DeviceContext::get_device_name (gpu/mod.rs:70). Valid until cvhip_device_destroy. */

@@ -49,7 +49,9 @@ def main():
     assert sharded_levels >= 1, "test case too small to exercise the collective"
     xy, corr = pc.complete()
     want_xy, want_corr = g["fwd_xy"].astype(np.int32), g["fwd_corr"]
-    assert (xy == want_xy).all(), f"rank {rank}: sharded result differs from the golden grid"
+    bad = np.nonzero((xy != want_xy).any(axis=-1))
+    assert bad[0].size == 0, (f"rank {rank}: sharded result differs from the golden grid in {bad[0].size} cells, "
+                              f"rows {np.unique(bad[0])[:20]} cols {np.unique(bad[1])[:20]}")
     valid = want_xy[..., 0] >= 0
     assert (corr.view(np.uint32)[valid] == want_corr.view(np.uint32)[valid]).all()
     pc.close()
