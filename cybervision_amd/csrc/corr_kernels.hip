@@ -900,46 +900,56 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
 // match (x2, y2) is the full-res match (x2, y2) << k, so the window test reduces to +-4 level
 // cells.  Each thread owns one cell of `own` and only reads `other`.
 // ---------------------------------------------------------------------------------------------
+constexpr int CC_ROWS = 4; // rows per thread: independent load chains in flight (the kernel is latency-bound)
+
 __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ own, const uint2 *__restrict__ other,
                                                            uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= ow || y >= oh) return;
-    const uint32_t cell = own[(size_t)y * ow + x].x;
-    if (cell == CELL_NONE) return;
+    const uint32_t y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CC_ROWS;
+    if (x >= ow) return;
     const uint32_t sa = CROSS_CHECK_SEARCH_AREA;
-    const uint32_t mx = cell & 0xFFFFu, my = cell >> 16;
-    const uint32_t min_x = min(sat_sub_u32(mx, sa), rw), max_x = min(mx + sa + 1, rw);
-    const uint32_t min_y = min(sat_sub_u32(my, sa), rh), max_y = min(my + sa + 1, rh);
-    const uint32_t r_min_x = sat_sub_u32(x, sa), r_max_x = x + sa + 1;
-    const uint32_t r_min_y = sat_sub_u32(y, sa), r_max_y = y + sa + 1;
+    uint32_t cell[CC_ROWS], probe[CC_ROWS];
+#pragma unroll
+    for (int j = 0; j < CC_ROWS; j++) cell[j] = y0 + j < oh ? own[(size_t)(y0 + j) * ow + x].x : CELL_NONE;
     // The result is an existence test (mod.rs:613-623 returns true at the first hit), so the scan
     // order is free: probe the window centre first — a consistent pair of matches points straight
     // back — and fall back to the full row-major scan only when that fails.
-    auto points_back = [&](uint32_t rm) {
-        const uint32_t rx = rm & 0xFFFFu, ry = rm >> 16;
-        return rm != CELL_NONE && rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y;
-    };
-    bool found = mx < rw && my < rh && points_back(other[(size_t)my * rw + mx].x);
-    for (uint32_t sy = min_y; sy < max_y && !found; sy++) {
-        for (uint32_t sx = min_x; sx < max_x; sx++) {
-            const uint32_t rm = other[(size_t)sy * rw + sx].x;
-            if (rm == CELL_NONE) continue;
+#pragma unroll
+    for (int j = 0; j < CC_ROWS; j++) {
+        const uint32_t mx = cell[j] & 0xFFFFu, my = cell[j] >> 16;
+        probe[j] = (cell[j] != CELL_NONE && mx < rw && my < rh) ? other[(size_t)my * rw + mx].x : CELL_NONE;
+    }
+#pragma unroll
+    for (int j = 0; j < CC_ROWS; j++) {
+        if (cell[j] == CELL_NONE) continue;
+        const uint32_t y = y0 + j;
+        const uint32_t mx = cell[j] & 0xFFFFu, my = cell[j] >> 16;
+        const uint32_t min_x = min(sat_sub_u32(mx, sa), rw), max_x = min(mx + sa + 1, rw);
+        const uint32_t min_y = min(sat_sub_u32(my, sa), rh), max_y = min(my + sa + 1, rh);
+        const uint32_t r_min_x = sat_sub_u32(x, sa), r_max_x = x + sa + 1;
+        const uint32_t r_min_y = sat_sub_u32(y, sa), r_max_y = y + sa + 1;
+        auto points_back = [&](uint32_t rm) {
             const uint32_t rx = rm & 0xFFFFu, ry = rm >> 16;
-            if (rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y) {
-                found = true;
-                break;
+            return rm != CELL_NONE && rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y;
+        };
+        bool found = points_back(probe[j]);
+        for (uint32_t sy = min_y; sy < max_y && !found; sy++) {
+            for (uint32_t sx = min_x; sx < max_x; sx++) {
+                if (points_back(other[(size_t)sy * rw + sx].x)) {
+                    found = true;
+                    break;
+                }
             }
         }
+        if (!found) own[(size_t)y * ow + x] = make_uint2(CELL_NONE, 0x7FC00000u);
     }
-    if (!found) own[(size_t)y * ow + x] = make_uint2(CELL_NONE, 0x7FC00000u);
 }
 
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         hipStream_t s)
 {
-    dim3 grid((ow + 63) / 64, (oh + 3) / 4);
+    dim3 grid((ow + 63) / 64, (oh + 4 * CC_ROWS - 1) / (4 * CC_ROWS));
     hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, own, other, ow, oh, rw, rh);
 }
 
