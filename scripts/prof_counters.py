@@ -17,7 +17,11 @@ p1, p2 = synth.box_pyramid(img1, steps), synth.box_pyramid(img2, steps)
 d1 = [torch.from_numpy(p).cuda() for p in p1]
 d2 = [torch.from_numpy(p).cuda() for p in p2]
 dev = correlation.create_gpu_context()
-pc = correlation.PointCorrelations(dev, (W, W), (W, W), synth.F_HORIZONTAL)
+F = synth.F_HORIZONTAL
+for a in sys.argv:
+    if a.startswith("--tilt="):
+        F = synth.f_tilt(float(a.split("=")[1]))
+pc = correlation.PointCorrelations(dev, (W, W), (W, W), F)
 COUNT = "--count" in sys.argv
 pc.set_profiling(True, COUNT)
 for i in range(steps + 1):
