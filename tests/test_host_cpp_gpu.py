@@ -1,0 +1,63 @@
+"""The C++ host layer (cybervision_amd/csrc/host/cvhip_host.hpp) on a real GPU: a g++-built program
+drives ORB -> matcher -> RANSAC (host sampling + GPU scoring) -> dense correlation through the
+reference-shaped C++ classes; results must equal the ctypes path bit for bit and respect the known
+geometry."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from cybervision_amd import correlation, orb, pointmatching, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_cpp_host_pipeline(gpu_device, tmp_path):
+    exe = tmp_path / "host_pipeline"
+    lib_dir = ROOT / "cybervision_amd"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", str(exe), str(ROOT / "tests" / "cpp" / "host_pipeline.cpp"),
+                           f"-L{lib_dir}", "-lcvhip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    w, h = 384, 320
+    a, _, _ = synth.make_pair(w, h, seed=21)
+    img1 = synth.add_blocks(a, count=250, seed=3)
+    # second view: the first shifted 7 px to the left, so matches are (x, y) -> (x - 7, y): horizontal epipolar lines
+    img2 = np.ascontiguousarray(np.roll(img1, -7, axis=1))
+    img1.tofile(tmp_path / "img1.raw")
+    img2.tofile(tmp_path / "img2.raw")
+    res = subprocess.run([str(exe), str(tmp_path / "img1.raw"), str(tmp_path / "img2.raw"), str(w), str(h), str(tmp_path)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["keypoints1"] > 200 and info["matches"] > 100
+
+    # ORB and matcher: identical to the ctypes path
+    kp = np.fromfile(tmp_path / "kp1.bin", dtype=np.uint32).reshape(-1, 10)
+    xy1, desc1 = orb.extract_points(gpu_device, img1)
+    xy2, desc2 = orb.extract_points(gpu_device, img2)
+    assert (kp[:, :2] == xy1).all() and (kp[:, 2:] == desc1).all()
+    m = np.fromfile(tmp_path / "matches.bin", dtype=np.uint32).reshape(-1, 4)
+    want_m, _ = pointmatching.match_points(gpu_device, xy1, desc1, xy2, desc2, pointmatching.THRESHOLD_AFFINE)
+    assert (m == want_m).all()
+
+    # RANSAC: most matches are inliers of a horizontal-line F; F ~ +-[[0,0,0],[0,0,1],[0,-1,0]] up to scale
+    assert info["inliers"] > 0.8 * info["matches"]
+    F = np.fromfile(tmp_path / "f.bin", dtype=np.float64).reshape(3, 3)
+    assert abs(F[2, 2] - 1.0) < 1e-12 and np.abs(F[:2, :2]).max() == 0.0  # affine form, normalised by f[2][2]
+    Fn = F / np.abs(F).max()
+    assert abs(abs(Fn[1, 2]) - 1) < 1e-6 and abs(Fn[1, 2] + Fn[2, 1]) < 1e-3
+    assert abs(Fn[0, 2]) < 1e-3 and abs(Fn[2, 0]) < 1e-3
+
+    # dense: identical to the ctypes path on the same pyramids
+    steps = synth.optimal_scale_steps(w, h)
+    p1, p2 = synth.box_pyramid(img1, steps), synth.box_pyramid(img2, steps)
+    want_xy, want_corr = correlation.correlate_dense(gpu_device, p1, p2, synth.F_HORIZONTAL)
+    xy = np.fromfile(tmp_path / "dense_xy.bin", dtype=np.int32).reshape(h, w, 2)
+    corr = np.fromfile(tmp_path / "dense_corr.bin", dtype=np.float32).reshape(h, w)
+    valid = want_xy[..., 0] >= 0
+    assert info["dense_valid"] == int(valid.sum()) and info["levels"] == steps + 1
+    assert (xy == want_xy).all() and (corr.view(np.uint32)[valid] == want_corr.view(np.uint32)[valid]).all()
+    ys, xs = np.nonzero(valid)
+    assert (np.abs(want_xy[..., 0][valid] - (xs - 7)) <= 1).mean() > 0.97  # the 7-px shift is recovered
