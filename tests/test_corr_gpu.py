@@ -367,3 +367,31 @@ def test_two_rank_sharded_level_calls():
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {rank} ok" in out, out
+
+
+def test_full_size_4096_v2_equals_exact_kernel():
+    """BASELINE's 4096^2 pair: the filter + exact-re-evaluation search (v2) must reproduce, bit for bit,
+    the plain kernel that sends every one of the 3.2e9 candidates through the reference's serial f32
+    chain (v1, itself bit-exact against the oracle on every small case) — match coordinates and scores,
+    both directions.  Plus the size-independent properties: known disparity recovered, empty border."""
+    from cybervision_amd import correlation as corr_mod
+
+    dev = corr_mod.create_gpu_context()
+    try:
+        a, b, d = synth.make_pair(4096, 4096)
+        steps = synth.optimal_scale_steps(4096, 4096)
+        c = dict(img1=a, img2=b, F=synth.F_HORIZONTAL, projection=0, steps=steps)
+        cnt = {}
+        (fxy, fc), (rxy, rc) = run_gpu(dev, c, both=True, version=2, counters=cnt)
+        (fxy1, fc1), (rxy1, rc1) = run_gpu(dev, c, both=True, version=1)
+    finally:
+        dev.close()
+    assert (fxy == fxy1).all() and (rxy == rxy1).all(), "v2 match coordinates differ from the exact kernel"
+    vf, vr = fxy1[..., 0] >= 0, rxy1[..., 0] >= 0
+    assert (bits(fc)[vf] == bits(fc1)[vf]).all() and (bits(rc)[vr] == bits(rc1)[vr]).all(), "scores differ"
+    assert cnt["candidates"] > 3_000_000_000 and cnt["exact_evals"] < 0.02 * cnt["candidates"]
+    assert vf.mean() > 0.8
+    assert not vf[:5].any() and not vf[-5:].any() and not vf[:, :5].any() and not vf[:, -5:].any()
+    ys, xs = np.nonzero(vf)
+    x2, y2 = fxy[..., 0][vf], fxy[..., 1][vf]
+    assert (np.abs(x2 + d[y2, x2] - xs) <= 1).mean() > 0.97
