@@ -15,6 +15,7 @@
 #include "cvhip_internal.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace cvhip {
 
@@ -464,6 +465,7 @@ constexpr float S2_DELTA = 2.5e-5f;     // >= 393 * 2^-24 (see above)
 //   bits [60, 63): count 0..4; CW_WHOLE = re-evaluate the whole corridor exactly
 constexpr unsigned long long CW_WHOLE = 5ull;
 constexpr uint32_t CW_MAX_LEN = 2048u;  // i - r0 must fit in 11 bits
+constexpr uint32_t S2_FIXED_PITCH = 128u;
 
 struct CandXY {
     uint32_t x, y;
@@ -510,7 +512,8 @@ __device__ __forceinline__ bool pixel_setup(const CorrParams &p, uint32_t x, uin
 }
 
 // ---- kernel A: filter ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+template <bool COUNT>
+__global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                                  const uint8_t *__restrict__ img2,
                                                                  const float2 *__restrict__ stats1,
                                                                  const uint2 *__restrict__ istats1,
@@ -579,7 +582,9 @@ __global__ __launch_bounds__(256, 4) void search2_filter_kernel(CorrParams p, co
     const int bx0 = cx0 - KERNEL_SIZE, by0 = cy0 - KERNEL_SIZE;
     const int bwid = bb[2] - bb[0] + 2 * KERNEL_SIZE + 2; // + 1 for the 12th byte of a row read
     const int bhei = bb[3] - bb[1] + 2 * KERNEL_SIZE + 1;
-    const uint32_t P = any_active ? (uint32_t)((bwid + 7) & ~7) : 8u;                 // row pitch, multiple of 8
+    // row pitch, multiple of 8; the common case (box <= 128 B wide) uses a compile-time pitch so that every
+    // LDS row offset in the candidate loop is an immediate
+    const uint32_t P = !any_active ? 8u : (bwid <= (int)S2_FIXED_PITCH ? S2_FIXED_PITCH : (uint32_t)((bwid + 7) & ~7));
     const uint32_t CS = any_active ? ((P * (uint32_t)bhei + 16u + 255u) & ~255u) + 32u : 0u; // copy stride
     // per-candidate statistics (istats2) of every candidate centre in the box, staged next to the tile
     const uint32_t cw = any_active ? (uint32_t)(bb[2] - bb[0] + 1) : 0u, ch = any_active ? (uint32_t)(bb[3] - bb[1] + 1) : 0u;
@@ -606,8 +611,12 @@ __global__ __launch_bounds__(256, 4) void search2_filter_kernel(CorrParams p, co
         }
         for (uint32_t u = threadIdx.x; u < cw * ch; u += 256) {
             const uint32_t row = u / cw, col = u - row * cw;
-            *reinterpret_cast<uint2 *>(tile + IS_OFF + 8u * u) =
-                istats2[(size_t)(cy0 + (int)row) * p.w2 + (size_t)(cx0 + (int)col)];
+            // {window sum, f32 stdev}; candidates the reference skips (stdev non-finite or < min_stdev,
+            // mod.rs:437-441) get stdev = +inf so that their acceptance threshold can never be reached
+            uint2 v = istats2[(size_t)(cy0 + (int)row) * p.w2 + (size_t)(cx0 + (int)col)];
+            v.y = (v.x & 0x80000000u) ? v.y : 0x7F800000u;
+            v.x &= 0x7FFFFFFFu;
+            *reinterpret_cast<uint2 *>(tile + IS_OFF + 8u * u) = v;
         }
     }
     __syncthreads();
@@ -634,13 +643,18 @@ __global__ __launch_bounds__(256, 4) void search2_filter_kernel(CorrParams p, co
             }
         }
         const int s1 = (int)(istats1[(size_t)y * p.w1 + x].x & 0x7FFFFFFFu);
-        const float c1 = 1.0f / (ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT)); // 1/(121*121*sd1)
+        const float k1 = ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT); // 121*121*sd1
+        const float c1 = 1.0f / k1;
 
         float runmax = -__builtin_inff();
         const float thr_lo = p.threshold - S2_DELTA;
-        const float ninf = -__builtin_inff();
         unsigned long long clist = 0ull;
         uint32_t count = 0;
+        // Acceptance band in the integer domain.  g = N * c1 / sd2 >= lim  <=>  (float)N >= lim * k1 * sd2
+        // (k1, sd2 > 0).  limk = lim * k1 shaved by 2^-20 keeps the cheap test free of false negatives
+        // against the handful of f32 roundings on either side; a hit is then re-tested with g itself.
+        float limk = thr_lo * k1 * (1.0f - 9.5367431640625e-7f);
+        auto score = [&](int num, float sd2) -> float { return (float)num * (c1 * __builtin_amdgcn_rcpf(sd2)); };
         // band bookkeeping: candidate `code` (stripe << 11 | i - r0) joins the contender list
         auto record = [&](float g, uint32_t code) {
             const float lim = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo);
@@ -650,110 +664,118 @@ __global__ __launch_bounds__(256, 4) void search2_filter_kernel(CorrParams p, co
                     clist = 0ull;
                 }
                 runmax = fmaxf(runmax, g);
+                limk = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo) * k1 * (1.0f - 9.5367431640625e-7f);
                 if (count < (uint32_t)S2_K) clist |= (unsigned long long)code << (15u * count);
                 count = min(count + 1u, (uint32_t)S2_K + 1u);
             }
         };
-        auto score = [&](uint32_t s12, uint2 is2) -> float {
-            const int num = (int)(KERNEL_POINT_COUNT * s12) - s1 * (int)(is2.x & 0x7FFFFFFFu);
-            return (float)num * (c1 * __builtin_amdgcn_rcpf(__uint_as_float(is2.y)));
-        };
         const bool major_x = e.ox == 0; // candidates advance along x (x2 == i exactly), stripes shift y
-        for (int off = -cs; off <= cs; off++) {
-            // The minor coordinate is monotone in i; if it is the same at both ends of the interval it
-            // is the same everywhere and the per-candidate f64 evaluation can be skipped.
-            const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
-            const bool minor_const = major_x ? (cf.y == cl.y) : (cf.x == cl.x);
-            const uint32_t tbase = (uint32_t)(off + cs) << 11;
-            if (major_x) {
-                // Candidates advance along x; the row y2 is constant over the stripe or steps occasionally.
-                // Two horizontally adjacent candidates in the same row share their LDS row reads; the two dot
-                // chains are independent and interleaved, and the candidate statistics are read before the
-                // dots and consumed after them.
-                const uint32_t i_hi = min(r1, p.w2 - KERNEL_SIZE);
-                uint32_t i = max(r0, (uint32_t)KERNEL_SIZE);
-                while (i < i_hi) {
-                    const bool has2 = i + 1 < i_hi;
-                    uint32_t ya = cf.y, yb = cf.y;
-                    if (!minor_const) {
-                        ya = candidate_xy(e, i, off).y;
-                        yb = has2 ? candidate_xy(e, i + 1, off).y : ya;
-                    }
-                    const bool pair = has2 && yb == ya;
-                    const uint32_t ti = tbase + (i - r0);
-                    const uint32_t icur = i;
-                    i += pair ? 2u : 1u;
-                    if (ya < KERNEL_SIZE || ya >= p.h2 - KERNEL_SIZE) continue;
-                    const uint2 *isrow = lds_is + (ya - (uint32_t)cy0) * cw + (icur - (uint32_t)cx0);
-                    const uint2 is0 = isrow[0];
-                    const uint2 is1 = isrow[pair ? 1 : 0];
-                    const uint32_t a0 = (uint32_t)((int)ya - KERNEL_SIZE - by0) * P + icur - (uint32_t)(KERNEL_SIZE + bx0);
-                    const uint32_t phi = a0 & 7u;
-                    const uint8_t *src = tile + phi * CS + (a0 - phi);
-                    // all 22 row reads in flight first, then the two independent dot chains interleaved
-                    uint2 lo[KERNEL_WIDTH];
-                    uint32_t hi[KERNEL_WIDTH];
+
+        // One corridor walk, instantiated for the fixed and for the dynamic row pitch.
+        auto walk = [&](auto pitch_tag) {
+            constexpr uint32_t PF = decltype(pitch_tag)::value;
+            const uint32_t Pp = PF ? PF : P;
+            for (int off = -cs; off <= cs; off++) {
+                // The minor coordinate is monotone in i; if it is the same at both ends of the interval it
+                // is the same everywhere and the per-candidate f64 evaluation can be skipped.
+                const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
+                const bool minor_const = major_x ? (cf.y == cl.y) : (cf.x == cl.x);
+                const uint32_t tbase = (uint32_t)(off + cs) << 11;
+                if (major_x) {
+                    // Candidates advance along x; the row y2 is constant over the stripe or steps occasionally.
+                    // Two horizontally adjacent candidates in the same row share their LDS row reads; the two
+                    // dot chains are independent and interleaved.
+                    const uint32_t i_hi = min(r1, p.w2 - KERNEL_SIZE);
+                    uint32_t i = max(r0, (uint32_t)KERNEL_SIZE);
+                    while (i < i_hi) {
+                        const bool has2 = i + 1 < i_hi;
+                        uint32_t ya = cf.y, yb = cf.y;
+                        if (!minor_const) {
+                            ya = candidate_xy(e, i, off).y;
+                            yb = has2 ? candidate_xy(e, i + 1, off).y : ya;
+                        }
+                        const bool pair = has2 && yb == ya;
+                        const uint32_t ti = tbase + (i - r0);
+                        const uint32_t icur = i;
+                        i += pair ? 2u : 1u;
+                        if (ya < KERNEL_SIZE || ya >= p.h2 - KERNEL_SIZE) continue;
+                        const uint2 *isrow = lds_is + (ya - (uint32_t)cy0) * cw + (icur - (uint32_t)cx0);
+                        const uint2 is0 = isrow[0];
+                        uint2 is1 = isrow[pair ? 1 : 0];
+                        is1.y = pair ? is1.y : 0x7F800000u; // no second candidate: unreachable threshold
+                        const uint32_t a0 =
+                            (uint32_t)((int)ya - KERNEL_SIZE - by0) * Pp + icur - (uint32_t)(KERNEL_SIZE + bx0);
+                        const uint32_t phi = a0 & 7u;
+                        const uint8_t *src = tile + phi * CS + (a0 - phi);
+                        // all 22 row reads in flight first, then the two independent dot chains interleaved
+                        uint2 lo[KERNEL_WIDTH];
+                        uint32_t hi[KERNEL_WIDTH];
 #pragma unroll
-                    for (int r = 0; r < KERNEL_WIDTH; r++) {
-                        lo[r] = *reinterpret_cast<const uint2 *>(src + r * P);
-                        hi[r] = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    uint32_t s12a = 0, s12b = 0;
+                        for (int r = 0; r < KERNEL_WIDTH; r++) {
+                            lo[r] = *reinterpret_cast<const uint2 *>(src + r * Pp);
+                            hi[r] = *reinterpret_cast<const uint32_t *>(src + r * Pp + 8);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        uint32_t s12a = 0, s12b = 0;
 #pragma unroll
-                    for (int r = 0; r < KERNEL_WIDTH; r++) {
-                        s12a = __builtin_amdgcn_udot4(a[r].a, lo[r].x, s12a, false);
-                        s12b = __builtin_amdgcn_udot4(ap[r].a, lo[r].x, s12b, false);
-                        s12a = __builtin_amdgcn_udot4(a[r].b, lo[r].y, s12a, false);
-                        s12b = __builtin_amdgcn_udot4(ap[r].b, lo[r].y, s12b, false);
-                        s12a = __builtin_amdgcn_udot4(a[r].c, hi[r], s12a, false);
-                        s12b = __builtin_amdgcn_udot4(ap[r].c, hi[r], s12b, false);
+                        for (int r = 0; r < KERNEL_WIDTH; r++) {
+                            s12a = __builtin_amdgcn_udot4(a[r].a, lo[r].x, s12a, false);
+                            s12b = __builtin_amdgcn_udot4(ap[r].a, lo[r].x, s12b, false);
+                            s12a = __builtin_amdgcn_udot4(a[r].b, lo[r].y, s12a, false);
+                            s12b = __builtin_amdgcn_udot4(ap[r].b, lo[r].y, s12b, false);
+                            s12a = __builtin_amdgcn_udot4(a[r].c, hi[r], s12a, false);
+                            s12b = __builtin_amdgcn_udot4(ap[r].c, hi[r], s12b, false);
+                        }
+                        // Pin both sums here so the two chains stay interleaved in one block.
+                        asm volatile("" : "+v"(s12a), "+v"(s12b));
+                        const float sd0 = __uint_as_float(is0.y), sd1 = __uint_as_float(is1.y);
+                        if (COUNT) evaluated += (sd0 < __builtin_inff() ? 1u : 0u) + (sd1 < __builtin_inff() ? 1u : 0u);
+                        const int n0 = (int)(KERNEL_POINT_COUNT * s12a) - s1 * (int)is0.x;
+                        const int n1 = (int)(KERNEL_POINT_COUNT * s12b) - s1 * (int)is1.x;
+                        // one rarely-taken branch for the pair
+                        if ((float)n0 >= limk * sd0 || (float)n1 >= limk * sd1) {
+                            if (sd0 < __builtin_inff()) record(score(n0, sd0), ti);
+                            if (sd1 < __builtin_inff()) record(score(n1, sd1), ti + 1);
+                        }
                     }
-                    // Pin both sums here: without this the compiler sinks each chain into an `if (valid)`
-                    // block, serialising the chains.
-                    asm volatile("" : "+v"(s12a), "+v"(s12b));
-                    const bool v0 = (is0.x & 0x80000000u) != 0;          // mod.rs:439 on the reference's stdev
-                    const bool v1 = pair && (is1.x & 0x80000000u) != 0;
-                    evaluated += (v0 ? 1u : 0u) + (v1 ? 1u : 0u);
-                    const float g0 = v0 ? score(s12a, is0) : ninf, g1 = v1 ? score(s12b, is1) : ninf;
-                    // one rarely-taken branch for the pair (keeps both chains ahead of it)
-                    if (fmaxf(g0, g1) >= fmaxf(runmax - 2.0f * S2_DELTA, thr_lo)) {
-                        record(g0, ti);
-                        record(g1, ti + 1);
-                    }
-                }
-            } else {
-                for (uint32_t i = r0; i < r1; i++) {
-                    CandXY c;
-                    if (minor_const) { // column-constant stripe (x2 fixed, y2 == i)
-                        c.x = cf.x;
-                        c.y = i;
-                    } else {
-                        c = candidate_xy(e, i, off);
-                    }
-                    if (!candidate_in_bounds(p, c)) continue;
-                    const uint2 is2 = lds_is[(c.y - (uint32_t)cy0) * cw + (c.x - (uint32_t)cx0)];
-                    const uint32_t a0 =
-                        (uint32_t)((int)c.y - KERNEL_SIZE - by0) * P + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
-                    const uint32_t phi = a0 & 7u;
-                    const uint8_t *src = tile + phi * CS + (a0 - phi);
-                    uint32_t s12 = 0, s12x = 0;
+                } else {
+                    for (uint32_t i = r0; i < r1; i++) {
+                        CandXY c;
+                        if (minor_const) { // column-constant stripe (x2 fixed, y2 == i)
+                            c.x = cf.x;
+                            c.y = i;
+                        } else {
+                            c = candidate_xy(e, i, off);
+                        }
+                        if (!candidate_in_bounds(p, c)) continue;
+                        const uint2 is2 = lds_is[(c.y - (uint32_t)cy0) * cw + (c.x - (uint32_t)cx0)];
+                        const uint32_t a0 =
+                            (uint32_t)((int)c.y - KERNEL_SIZE - by0) * Pp + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
+                        const uint32_t phi = a0 & 7u;
+                        const uint8_t *src = tile + phi * CS + (a0 - phi);
+                        uint32_t s12 = 0, s12x = 0;
 #pragma unroll
-                    for (int r = 0; r < KERNEL_WIDTH; r++) {
-                        const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
-                        const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
-                        s12 = __builtin_amdgcn_udot4(a[r].a, lo.x, s12, false);
-                        s12x = __builtin_amdgcn_udot4(a[r].b, lo.y, s12x, false);
-                        s12 = __builtin_amdgcn_udot4(a[r].c, hi, s12, false);
+                        for (int r = 0; r < KERNEL_WIDTH; r++) {
+                            const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * Pp);
+                            const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * Pp + 8);
+                            s12 = __builtin_amdgcn_udot4(a[r].a, lo.x, s12, false);
+                            s12x = __builtin_amdgcn_udot4(a[r].b, lo.y, s12x, false);
+                            s12 = __builtin_amdgcn_udot4(a[r].c, hi, s12, false);
+                        }
+                        asm volatile("" : "+v"(s12), "+v"(s12x));
+                        const float sd2 = __uint_as_float(is2.y);
+                        if (COUNT) evaluated += sd2 < __builtin_inff() ? 1u : 0u;
+                        const int num = (int)(KERNEL_POINT_COUNT * (s12 + s12x)) - s1 * (int)is2.x;
+                        if ((float)num >= limk * sd2 && sd2 < __builtin_inff()) record(score(num, sd2), tbase + (i - r0));
                     }
-                    asm volatile("" : "+v"(s12), "+v"(s12x));
-                    const bool v = (is2.x & 0x80000000u) != 0; // stdev2 finite and >= min_stdev (mod.rs:439)
-                    evaluated += v ? 1u : 0u;
-                    const float g = score(s12 + s12x, is2);
-                    record(v ? g : ninf, tbase + (i - r0));
                 }
             }
-        }
+        };
+        if (P == S2_FIXED_PITCH)
+            walk(std::integral_constant<uint32_t, S2_FIXED_PITCH>{});
+        else
+            walk(std::integral_constant<uint32_t, 0u>{});
+
         if (count > (uint32_t)S2_K) {
             word = CW_WHOLE << 60;
             whole = 1;
@@ -880,8 +902,12 @@ void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
-    hipLaunchKernelGGL(search2_filter_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2, range,
-                       contenders, counters);
+    if (counters)
+        hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
+                           range, contenders, counters);
+    else
+        hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
+                           range, contenders, counters);
 }
 
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
