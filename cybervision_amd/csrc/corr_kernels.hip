@@ -960,13 +960,15 @@ __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ ow
             return rm != CELL_NONE && rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y;
         };
         bool found = points_back(probe[j]);
+        // fallback: whole rows at a time, nine independent loads in flight (no per-cell early exit)
         for (uint32_t sy = min_y; sy < max_y && !found; sy++) {
-            for (uint32_t sx = min_x; sx < max_x; sx++) {
-                if (points_back(other[(size_t)sy * rw + sx].x)) {
-                    found = true;
-                    break;
-                }
-            }
+            const uint2 *row = other + (size_t)sy * rw;
+            uint32_t cellsr[2 * CROSS_CHECK_SEARCH_AREA + 1];
+#pragma unroll
+            for (uint32_t t = 0; t < 2 * CROSS_CHECK_SEARCH_AREA + 1; t++)
+                cellsr[t] = min_x + t < max_x ? row[min_x + t].x : CELL_NONE;
+#pragma unroll
+            for (uint32_t t = 0; t < 2 * CROSS_CHECK_SEARCH_AREA + 1; t++) found = found || points_back(cellsr[t]);
         }
         if (!found) own[(size_t)y * ow + x] = make_uint2(CELL_NONE, 0x7FC00000u);
     }
