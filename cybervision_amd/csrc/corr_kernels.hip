@@ -816,26 +816,53 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
     const uint32_t x = blockIdx.x * 64 + lane;
     const uint32_t y = p.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool in_image = x < p.w1 && y < p.row1;
+    // All loads that depend only on (x, y) are issued together, unconditionally for interior pixels: the
+    // kernel is a chain of dependent memory round trips otherwise (contender word -> setup -> windows).
+    const bool interior =
+        in_image && x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
     const unsigned long long word = in_image ? contenders[(size_t)y * p.w1 + x] : 0ull;
+    float2 st1v = make_float2(0.0f, 0.0f);
+    uint32_t rg = 0;
+    Row12 arow[KERNEL_WIDTH];
+    if (interior) {
+        st1v = stats1[(size_t)y * p.w1 + x];
+        if (!p.first_pass) rg = range[(size_t)y * p.w1 + x];
+        const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
+#pragma unroll
+        for (int r = 0; r < KERNEL_WIDTH; r++) arow[r] = load_row12(base + (size_t)r * p.w1);
+    } else {
+#pragma unroll
+        for (int r = 0; r < KERNEL_WIDTH; r++) arow[r].a = arow[r].b = arow[r].c = 0u;
+    }
     const uint32_t count = (uint32_t)(word >> 60);
     uint32_t evaluated = 0, exact_evals = 0;
     uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
     PixelSetup ps;
-    if (count != 0 && pixel_setup(p, x, y, stats1, range, ps)) {
+    bool go = false;
+    if (interior && count != 0) { // pixel_setup (mod.rs:321-364) on the values loaded above
+        ps.st1 = st1v;
+        ps.e = epipolar_line(p, x, y);
+        go = finite_f32(ps.st1.y) && !(fabsf(ps.st1.y) < p.min_stdev) && line_finite(ps.e);
+        ps.r0 = KERNEL_SIZE;
+        ps.r1 = corridor_end_of(p, ps.e);
+        if (!p.first_pass) {
+            go = go && rg != RANGE_NONE;
+            ps.r0 = rg & 0xFFFFu;
+            ps.r1 = rg >> 16;
+        }
+        go = go && ps.r0 < ps.r1;
+    }
+    if (go) {
         const int cs = p.corridor_size;
         const uint32_t len = ps.r1 - ps.r0;
         // compute_point_data deltas (mod.rs:727-731); avg identical to stats1.x
         float d1[KERNEL_POINT_COUNT];
-        {
-            const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
 #pragma unroll
-            for (int r = 0; r < KERNEL_WIDTH; r++) {
-                const Row12 row = load_row12(base + (size_t)r * p.w1);
+        for (int r = 0; r < KERNEL_WIDTH; r++) {
 #pragma unroll
-                for (int c = 0; c < KERNEL_WIDTH; c++) {
-                    const uint32_t wv = c < 4 ? row.a : (c < 8 ? row.b : row.c);
-                    d1[r * KERNEL_WIDTH + c] = byte_f32(wv, c & 3) - ps.st1.x;
-                }
+            for (int c = 0; c < KERNEL_WIDTH; c++) {
+                const uint32_t wv = c < 4 ? arow[r].a : (c < 8 ? arow[r].b : arow[r].c);
+                d1[r * KERNEL_WIDTH + c] = byte_f32(wv, c & 3) - ps.st1.x;
             }
         }
         bool have = false;
