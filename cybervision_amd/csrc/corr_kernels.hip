@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
                                                                  const uint2 *__restrict__ istats2,
                                                                  const uint32_t *__restrict__ range,
                                                                  unsigned long long *__restrict__ contenders,
+                                                                 uint2 *__restrict__ out,
                                                                  unsigned long long *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[S2_LDS_BYTES];
@@ -621,8 +622,9 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
     }
     __syncthreads();
 
-    unsigned long long word = 0ull; // count 0 = None
-    uint32_t evaluated = 0, multi = 0, whole = 0;
+    unsigned long long word = 0ull; // 0 = settled here, CW_WHOLE = left to the exact kernel
+    uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
+    uint32_t evaluated = 0, multi = 0, whole = 0, exact_evals = 0;
     if (active && (!use_lds || len > CW_MAX_LEN)) {
         word = CW_WHOLE << 60;
         whole = 1;
@@ -781,21 +783,67 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
             whole = 1;
             evaluated = 0; // the exact kernel walks (and counts) the whole corridor
         } else {
-            word = clist | ((unsigned long long)count << 60);
+            // ---- exact re-evaluation of the contenders, right here: the tile and the candidate statistics
+            // are still in LDS.  mod.rs:442-464 — the reference's serial f32 chain and acceptance rule.
             multi = count > 1 ? 1u : 0u;
+            bool have = false;
+            float bcorr = 0.0f;
+            uint32_t bxy = 0;
+            const float avg1 = ps.st1.x, sdev1 = ps.st1.y;
+            for (uint32_t j = 0; j < count; j++) {
+                const uint32_t code = (uint32_t)(clist >> (15u * j)) & 0x7FFFu;
+                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                const uint2 is2 = lds_is[(c.y - (uint32_t)cy0) * cw + (c.x - (uint32_t)cx0)];
+                const float avg2 = (float)is2.x / (float)KERNEL_POINT_COUNT; // == compute_point_avg (exact sum)
+                const float sdev2 = __uint_as_float(is2.y);
+                const uint32_t a0 = (uint32_t)((int)c.y - KERNEL_SIZE - by0) * P + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
+                const uint32_t phi = a0 & 7u;
+                const uint8_t *src = tile + phi * CS + (a0 - phi);
+                float corr = 0.0f;
+#pragma unroll
+                for (int r = 0; r < KERNEL_WIDTH; r++) {
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
+                    const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
+                    Row12 ar = a[r];
+                    // opaque per iteration: keeps the 121 searched-window deltas from being hoisted out of the
+                    // contender loop into 121 live registers
+                    asm volatile("" : "+v"(ar.a), "+v"(ar.b), "+v"(ar.c));
+#pragma unroll
+                    for (int cc = 0; cc < KERNEL_WIDTH; cc++) {
+                        const uint32_t wa = cc < 4 ? ar.a : (cc < 8 ? ar.b : ar.c);
+                        const uint32_t wb = cc < 4 ? lo.x : (cc < 8 ? lo.y : hi);
+                        const float delta1 = byte_f32(wa, cc & 3) - avg1;
+                        const float delta2 = byte_f32(wb, cc & 3) - avg2;
+                        corr += delta1 * delta2;
+                    }
+                }
+                corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
+                exact_evals++;
+                if (corr >= p.threshold && (!have || corr > bcorr)) { // mod.rs:456-464
+                    have = true;
+                    bcorr = corr;
+                    bxy = c.x | (c.y << 16);
+                }
+            }
+            if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
         }
     }
-    if (in_image) contenders[(size_t)y * p.w1 + x] = word;
+    if (in_image) {
+        contenders[(size_t)y * p.w1 + x] = word;
+        if (!whole) out[(size_t)y * p.w1 + x] = cell;
+    }
     if (counters) {
-        uint32_t v0 = evaluated, v2 = multi, v3 = whole;
+        uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = whole;
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) {
             v0 += __shfl_down(v0, sft, 64);
+            v1 += __shfl_down(v1, sft, 64);
             v2 += __shfl_down(v2, sft, 64);
             v3 += __shfl_down(v3, sft, 64);
         }
         if (lane == 0) {
             if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
+            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
             if (v2) atomicAdd(&counters[2], (unsigned long long)v2);
             if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
         }
@@ -816,15 +864,17 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
     const uint32_t x = blockIdx.x * 64 + lane;
     const uint32_t y = p.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool in_image = x < p.w1 && y < p.row1;
-    // All loads that depend only on (x, y) are issued together, unconditionally for interior pixels: the
-    // kernel is a chain of dependent memory round trips otherwise (contender word -> setup -> windows).
+    // Only pixels the filter kernel marked CW_WHOLE are handled here (the filter kernel settles everything
+    // else itself); a wave without such a pixel leaves after reading its contender words.
     const bool interior =
         in_image && x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
     const unsigned long long word = in_image ? contenders[(size_t)y * p.w1 + x] : 0ull;
+    if (!__any((uint32_t)(word >> 60) == (uint32_t)CW_WHOLE)) return;
+    const bool mine = interior && (uint32_t)(word >> 60) == (uint32_t)CW_WHOLE;
     float2 st1v = make_float2(0.0f, 0.0f);
     uint32_t rg = 0;
     Row12 arow[KERNEL_WIDTH];
-    if (interior) {
+    if (mine) {
         st1v = stats1[(size_t)y * p.w1 + x];
         if (!p.first_pass) rg = range[(size_t)y * p.w1 + x];
         const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
@@ -839,7 +889,7 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
     uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
     PixelSetup ps;
     bool go = false;
-    if (interior && count != 0) { // pixel_setup (mod.rs:321-364) on the values loaded above
+    if (interior && count == (uint32_t)CW_WHOLE) { // pixel_setup (mod.rs:321-364) on the values loaded above
         ps.st1 = st1v;
         ps.e = epipolar_line(p, x, y);
         go = finite_f32(ps.st1.y) && !(fabsf(ps.st1.y) < p.min_stdev) && line_finite(ps.e);
@@ -908,7 +958,7 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
         }
         if (have) cell = make_uint2(bx | (by << 16), __float_as_uint(bcorr));
     }
-    if (in_image) out[(size_t)y * p.w1 + x] = cell;
+    if (in_image && count == (uint32_t)CW_WHOLE) out[(size_t)y * p.w1 + x] = cell; // everything else was settled by the filter kernel
     if (counters) {
         uint32_t v0 = evaluated, v1 = exact_evals;
 #pragma unroll
@@ -925,16 +975,16 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
 
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, unsigned long long *counters, hipStream_t s)
+                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
     if (counters)
         hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, counters);
+                           range, contenders, out, counters);
     else
         hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, counters);
+                           range, contenders, out, counters);
 }
 
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,

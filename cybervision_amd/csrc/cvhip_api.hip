@@ -181,7 +181,7 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         if (!(p.debug & 2))
             CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                 launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                      c->contenders, cnt, s);
+                                      c->contenders, ds.cells[next], cnt, s);
             }));
         if (!(p.debug & 1))
             CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
