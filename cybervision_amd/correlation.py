@@ -153,6 +153,18 @@ class PointCorrelations:
             self.correlated_points = (out_xy, out_corr)
         return out_xy, out_corr
 
+    def triangulate_affine(self):
+        """AffineTriangulation::triangulate (triangulation.rs:268-330) straight from the device grid:
+        -> (points3d[n, 3] float64 = (x, y, |p1 - p2|), p2[n, 2] uint32), one row per Some cell in scan order."""
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().cvhip_triangulate_affine(self._h, None, None, 0, C.byref(n)), "cvhip_triangulate_affine")
+        pts = np.zeros((max(n.value, 1), 3), dtype=np.float64)
+        p2 = np.zeros((max(n.value, 1), 2), dtype=np.uint32)
+        if n.value:
+            _lib.check(_lib.lib().cvhip_triangulate_affine(self._h, C.c_void_p(pts.ctypes.data), C.c_void_p(p2.ctypes.data),
+                                                           n.value, C.byref(n)), "cvhip_triangulate_affine")
+        return pts[:n.value].copy(), p2[:n.value].copy()
+
     # -- measurement / sharding hooks -----------------------------------------------------------
     def set_profiling(self, time_kernels: bool, count_candidates: bool):
         _lib.check(_lib.lib().cvhip_ctx_set_profiling(self._h, int(time_kernels), int(count_candidates)),

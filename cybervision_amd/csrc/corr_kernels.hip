@@ -1096,6 +1096,114 @@ void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k
     hipLaunchKernelGGL(expand_grid_kernel, grid, dim3(256), 0, s, cells, lw, lh, k, gw, gh, out_xy, out_corr);
 }
 
+// ---------------------------------------------------------------------------------------------
+// triangulate_affine: AffineTriangulation::triangulate + triangulate_point (triangulation.rs:268-330)
+// on the device-resident forward grid: count Some cells per 256-cell block (scan order), exclusive
+// scan of the block counts, then an ordered write of (x, y, sqrt(dx^2 + dy^2)) per track.
+// dx^2 + dy^2 is an exact integer in f64; sqrt is the correctly rounded f64 square root.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool full_res_match(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh, uint32_t k,
+                                               uint32_t gx, uint32_t gy, uint32_t &mx, uint32_t &my)
+{
+    const uint32_t mask = (1u << k) - 1u;
+    if ((gx & mask) || (gy & mask)) return false;
+    const uint32_t lx = gx >> k, ly = gy >> k;
+    if (lx >= lw || ly >= lh) return false;
+    const uint32_t c = cells[(size_t)ly * lw + lx].x;
+    if (c == CELL_NONE) return false;
+    mx = (c & 0xFFFFu) << k;
+    my = (c >> 16) << k;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void tri_count_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+                                                         uint32_t k, uint32_t gw, uint32_t gh,
+                                                         uint32_t *__restrict__ block_counts)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t mx, my;
+    const bool f = i < (size_t)gw * gh && full_res_match(cells, lw, lh, k, (uint32_t)(i % gw), (uint32_t)(i / gw), mx, my);
+    __shared__ uint32_t wsum[4];
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// single-block exclusive scan over n values (in place); total written to *total
+__global__ __launch_bounds__(1024) void tri_scan_kernel(uint32_t *__restrict__ data, uint32_t n,
+                                                         uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? data[i] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t t = __shfl_up(incl, s, 64);
+            if ((int)(threadIdx.x & 63) >= s) incl += t;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) woff += wtot[w];
+        const uint32_t carry = carry_s;
+        if (i < n) data[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void tri_write_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+                                                         uint32_t k, uint32_t gw, uint32_t gh,
+                                                         const uint32_t *__restrict__ block_offsets,
+                                                         unsigned long long cap, double *__restrict__ out_points3d,
+                                                         uint32_t *__restrict__ out_p2)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t mx = 0, my = 0;
+    const uint32_t gx = (uint32_t)(i % gw), gy = (uint32_t)(i / gw);
+    const bool f = i < (size_t)gw * gh && full_res_match(cells, lw, lh, k, gx, gy, mx, my);
+    __shared__ uint32_t wsum[4];
+    const unsigned long long b = __ballot(f);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (f) {
+        unsigned long long off = block_offsets[blockIdx.x];
+        for (uint32_t w = 0; w < wv; w++) off += wsum[w];
+        off += (unsigned long long)__popcll(b & ((1ull << lane) - 1ull));
+        if (off < cap) {
+            const double dx = (double)gx - (double)mx, dy = (double)gy - (double)my;
+            out_points3d[3 * off + 0] = (double)gx;
+            out_points3d[3 * off + 1] = (double)gy;
+            out_points3d[3 * off + 2] = sqrt(dx * dx + dy * dy);
+            if (out_p2) {
+                out_p2[2 * off + 0] = mx;
+                out_p2[2 * off + 1] = my;
+            }
+        }
+    }
+}
+
+void launch_triangulate_affine(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+                               uint32_t *block_counts, uint32_t *total, double *out_points3d, uint32_t *out_p2,
+                               unsigned long long cap, hipStream_t s)
+{
+    const uint32_t nblocks = (uint32_t)(((size_t)gw * gh + 255) / 256);
+    hipLaunchKernelGGL(tri_count_kernel, dim3(nblocks), dim3(256), 0, s, cells, lw, lh, k, gw, gh, block_counts);
+    hipLaunchKernelGGL(tri_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total);
+    if (cap)
+        hipLaunchKernelGGL(tri_write_kernel, dim3(nblocks), dim3(256), 0, s, cells, lw, lh, k, gw, gh, block_counts, cap,
+                           out_points3d, out_p2);
+}
+
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

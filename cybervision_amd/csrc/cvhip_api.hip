@@ -514,6 +514,45 @@ int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr)
     return cvhip_complete_dir(ctx, 0, out_xy, out_corr);
 }
 
+int cvhip_triangulate_affine(cvhip_ctx *ctx, double *out_points3d, uint32_t *out_p2, uint64_t cap, uint64_t *out_n)
+{
+    if (!ctx || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (cap && !out_points3d) return fail(CVHIP_ERR_INVALID, "out_points3d is null");
+    CVHIP_TRY(set_device(ctx->dev));
+    hipStream_t s = ctx->dev->d.stream;
+    DirState &ds = ctx->dir[0];
+    *out_n = 0;
+    if (!ds.valid) return CVHIP_OK; // nothing computed: no tracks
+    const size_t n = (size_t)ds.gw * ds.gh;
+    const uint32_t nblocks = (uint32_t)((n + 255) / 256);
+    // the search-interval buffer is free between levels: reuse it for the block counts (+ total)
+    if ((size_t)nblocks + 1 > ctx->max_px) return fail(CVHIP_ERR_INVALID, "image too small for the scratch buffer");
+    uint32_t *counts = ctx->range, *total = ctx->range + nblocks;
+    const bool p3_dev = out_points3d ? is_device_ptr(out_points3d) : true, p2_dev = out_p2 ? is_device_ptr(out_p2) : true;
+    double *d_p3 = out_points3d;
+    uint32_t *d_p2 = out_p2;
+    hipError_t e = hipSuccess;
+    if (cap && !p3_dev) e = hipMalloc(&d_p3, (size_t)cap * 3 * sizeof(double));
+    if (e == hipSuccess && cap && out_p2 && !p2_dev) e = hipMalloc(&d_p2, (size_t)cap * 2 * sizeof(uint32_t));
+    uint32_t h_total = 0;
+    if (e == hipSuccess) {
+        launch_triangulate_affine(ds.cells[ds.cur], ds.lw, ds.lh, ds.k, ds.gw, ds.gh, counts, total, d_p3, d_p2, cap, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_total, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    const uint64_t written = std::min<uint64_t>(h_total, cap);
+    if (e == hipSuccess && cap && !p3_dev && written)
+        e = hipMemcpy(out_points3d, d_p3, (size_t)written * 3 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && cap && out_p2 && !p2_dev && written)
+        e = hipMemcpy(out_p2, d_p2, (size_t)written * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (cap && !p3_dev && d_p3) (void)hipFree(d_p3);
+    if (cap && out_p2 && !p2_dev && d_p2) (void)hipFree(d_p2);
+    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("triangulate_affine: ") + hipGetErrorString(e));
+    *out_n = h_total;
+    return CVHIP_OK;
+}
+
 int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_allgather_fn gather, void *user)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");

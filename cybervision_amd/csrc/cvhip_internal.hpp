@@ -77,6 +77,10 @@ void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh
 void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                         int32_t *out_xy, float *out_corr, hipStream_t s);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
+// tracks of the affine dense consumer; block_counts must hold ceil(gw*gh/256) u32, total is one u32
+void launch_triangulate_affine(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+                               uint32_t *block_counts, uint32_t *total, double *out_points3d, uint32_t *out_p2,
+                               unsigned long long cap, hipStream_t s);
 
 // ---- handles --------------------------------------------------------------------------------
 struct Device {

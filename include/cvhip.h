@@ -117,6 +117,14 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
  * the stream given to cvhip_device_create_on_stream) and return 0, or non-zero to abort. */
 typedef int (*cvhip_allgather_fn)(void *user, void *cells, uint64_t shard_bytes, uint32_t n_shards, int dir);
 
+/* Dense consumer — replaces AffineTriangulation::triangulate + triangulate_point
+ * (triangulation.rs:268-330; reached from Triangulation::triangulate, :181-201, right after
+ * PointCorrelations::complete()).  Straight from the device-resident forward grid, one track per
+ * Some cell in scan order: out_points3d gets (x, y, sqrt(dx^2 + dy^2)) as 3 doubles per track,
+ * out_p2 (may be NULL) the matched point (2 u32).  At most `cap` tracks are written; *out_n is
+ * the number of Some cells (call with cap = 0 to size the buffers).  Host or device pointers. */
+int cvhip_triangulate_affine(cvhip_ctx *ctx, double *out_points3d, uint32_t *out_p2, uint64_t cap, uint64_t *out_n);
+
 /* Row sharding (multi-GPU): restrict the SEARCH passes of this context to shard `num` of `den`
  * equal row chunks of the searched level image: rows [num*rps, min((num+1)*rps, h_level)) with
  * rps = ceil(h_level / den).  Rows outside the band keep whatever the level grid holds until

@@ -69,6 +69,8 @@ def lib():
         L.cvref_match_points.restype = C.c_uint32
         L.cvref_match_points.argtypes = [_u32p, _u32p, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_uint32, _u32p,
                                          _u32p]
+        L.cvref_triangulate_affine.restype = C.c_uint64
+        L.cvref_triangulate_affine.argtypes = [_i32p, C.c_uint32, C.c_uint32, _f64p, _u32p]
         L.cvref_reprojection_error.restype = C.c_double
         L.cvref_reprojection_error.argtypes = [_f64p, _u32p]
         L.cvref_ransac_score.argtypes = [_f64p, C.c_uint32, _u32p, C.c_uint32, C.c_double, _u32p, _f64p]
@@ -228,3 +230,15 @@ def ransac_score(F, matches, t: float):
     err = np.zeros(H, dtype=np.float64)
     lib().cvref_ransac_score(F, H, matches, N, t, cnt, err)
     return cnt, err
+
+
+def triangulate_affine(xy):
+    """AffineTriangulation::triangulate (triangulation.rs:268-330) -> (points3d[n, 3] f64, p2[n, 2] u32)."""
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    h, w = xy.shape[:2]
+    cap = int((xy[..., 0] >= 0).sum())
+    pts = np.zeros((max(cap, 1), 3), dtype=np.float64)
+    p2 = np.zeros((max(cap, 1), 2), dtype=np.uint32)
+    n = lib().cvref_triangulate_affine(xy, w, h, pts, p2)
+    assert n == cap
+    return pts[:n].copy(), p2[:n].copy()

@@ -652,3 +652,27 @@ uint32_t cvref_corr_optimal_scale_steps(uint32_t w, uint32_t h)
     if (min_dimension <= SCALE_MIN_SIZE) return 0;
     return (uint32_t)floor(log2((double)min_dimension / (double)SCALE_MIN_SIZE));
 }
+
+/* AffineTriangulation::triangulate + triangulate_point, triangulation.rs:268-330 */
+uint64_t cvref_triangulate_affine(const int32_t *xy, uint32_t w, uint32_t h, double *out_points3d, uint32_t *out_p2)
+{
+    uint64_t n = 0;
+    for (uint32_t y = 0; y < h; y++) {
+        for (uint32_t x = 0; x < w; x++) {
+            const int32_t *m = &xy[2 * ((size_t)w * y + x)];
+            if (m[0] < 0) continue;
+            double dx = (double)x - (double)(uint32_t)m[0];
+            double dy = (double)y - (double)(uint32_t)m[1];
+            double distance = sqrt(dx * dx + dy * dy);
+            out_points3d[3 * n + 0] = (double)x;
+            out_points3d[3 * n + 1] = (double)y;
+            out_points3d[3 * n + 2] = distance;
+            if (out_p2) {
+                out_p2[2 * n + 0] = (uint32_t)m[0];
+                out_p2[2 * n + 1] = (uint32_t)m[1];
+            }
+            n++;
+        }
+    }
+    return n;
+}

@@ -395,3 +395,27 @@ def test_full_size_4096_v2_equals_exact_kernel():
     ys, xs = np.nonzero(vf)
     x2, y2 = fxy[..., 0][vf], fxy[..., 1][vf]
     assert (np.abs(x2 + d[y2, x2] - xs) <= 1).mean() > 0.97
+
+
+@pytest.mark.parametrize("name", ["tilt3_200x150", "h256", "flat"])
+def test_triangulate_affine_matches_oracle(gpu_device, oracle, name):
+    """Dense consumer (triangulation.rs:268-330) straight from the device grid: same tracks, same order,
+    same f64 bits as the oracle applied to the completed grid."""
+    c = cases.make_case(name)
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"])
+    try:
+        for i in range(c["steps"] + 1):
+            k = c["steps"] - i
+            pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+        pts, m2 = pc.triangulate_affine()
+        xy, _ = pc.complete()
+    finally:
+        pc.close()
+    want_pts, want_m2 = oracle.triangulate_affine(xy)
+    assert pts.shape == want_pts.shape and (pts.view(np.uint64) == want_pts.view(np.uint64)).all()
+    assert (m2 == want_m2).all()
+    if name != "flat":
+        assert len(pts) > 1000 and (pts[:, 2] >= 0).all()

@@ -126,3 +126,15 @@ def test_cross_check_removes_one_sided_matches(oracle):
         win = rxy[max(my - 4, 0):my + 5, max(mx - 4, 0):mx + 5].reshape(-1, 2)
         win = win[win[:, 0] >= 0]
         assert ((np.abs(win[:, 0] - x) <= 4) & (np.abs(win[:, 1] - y) <= 4)).any()
+
+
+def test_triangulate_affine_known_answers(oracle):
+    """AffineTriangulation::triangulate_point (triangulation.rs:314-330): depth = |p1 - p2|, one track
+    per Some cell in scan order."""
+    xy = np.full((4, 5, 2), -1, dtype=np.int32)
+    xy[1, 2] = (5, 5)      # (2,1) -> (5,5): dx = -3, dy = -4 -> 5
+    xy[3, 0] = (0, 3)      # identical point -> 0
+    xy[0, 4] = (3, 1)      # dx = 1, dy = -1 -> sqrt(2)
+    pts, p2 = oracle.triangulate_affine(xy)
+    assert pts.tolist() == [[4.0, 0.0, 2.0 ** 0.5], [2.0, 1.0, 5.0], [0.0, 3.0, 0.0]]
+    assert p2.tolist() == [[3, 1], [5, 5], [0, 3]]
