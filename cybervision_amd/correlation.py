@@ -247,3 +247,19 @@ def correlate_dense(device: GpuDevice, pyr1, pyr2, fundamental_matrix,
         return pc.complete()
     finally:
         pc.close()
+
+
+def box_pyramid_device(device: GpuDevice, img, steps: int):
+    """[level 0, ..., level `steps`] of 2x2 box-filter levels built on the device (cvhip_downsample_box);
+    img is a torch CUDA uint8 tensor, the levels are torch tensors resident in HBM."""
+    import torch
+
+    out = [img.contiguous()]
+    for _ in range(steps):
+        src = out[-1]
+        h, w = int(src.shape[0]), int(src.shape[1])
+        dst = torch.empty((h // 2, w // 2), dtype=torch.uint8, device=src.device)
+        _lib.check(_lib.lib().cvhip_downsample_box(device.handle, C.c_void_p(src.data_ptr()), w, h,
+                                                   C.c_void_p(dst.data_ptr())), "cvhip_downsample_box")
+        out.append(dst)
+    return out

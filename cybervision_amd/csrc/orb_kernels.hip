@@ -609,6 +609,42 @@ struct DevAllocs {
 
 using namespace cvhip;
 
+// 2x2 box-filter pyramid step (documented substitute for the upstream Lanczos3 resize)
+__global__ __launch_bounds__(256) void downsample_box_kernel(const uint8_t *__restrict__ src, uint32_t w, uint32_t dw,
+                                                             uint32_t dh, uint8_t *__restrict__ dst)
+{
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const uint8_t *r0 = src + (size_t)(2 * y) * w + 2 * x, *r1 = r0 + w;
+    dst[(size_t)y * dw + x] = (uint8_t)(((uint32_t)r0[0] + r0[1] + r1[0] + r1[1] + 2u) >> 2);
+}
+
+extern "C" int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint32_t w, uint32_t h, uint8_t *dst)
+{
+    if (!dev || !src || !dst) return fail(CVHIP_ERR_INVALID, "null argument");
+    const uint32_t dw = w / 2, dh = h / 2;
+    if (dw == 0 || dh == 0) return fail(CVHIP_ERR_INVALID, "image too small to halve");
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    DevAllocs mem;
+    const bool s_dev = dev_ptr(src), d_dev = dev_ptr(dst);
+    const uint8_t *d_src = src;
+    uint8_t *d_dst = dst, *tmp = nullptr;
+    if (!s_dev) {
+        CVHIP_TRY_HIP(mem.alloc(&tmp, (size_t)w * h));
+        CVHIP_TRY_HIP(hipMemcpyAsync(tmp, src, (size_t)w * h, hipMemcpyHostToDevice, s));
+        d_src = tmp;
+    }
+    if (!d_dev) CVHIP_TRY_HIP(mem.alloc(&d_dst, (size_t)dw * dh));
+    hipLaunchKernelGGL(downsample_box_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, s, d_src, w, dw, dh,
+                       d_dst);
+    CVHIP_TRY_HIP(hipGetLastError());
+    if (!d_dev) CVHIP_TRY_HIP(hipMemcpyAsync(dst, d_dst, (size_t)dw * dh, hipMemcpyDeviceToHost, s));
+    if (!s_dev || !d_dev) CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    return CVHIP_OK;
+}
+
 extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
                                  uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n)
 {

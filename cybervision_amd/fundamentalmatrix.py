@@ -24,3 +24,18 @@ def ransac_score(device, F, matches, t: float):
     _lib.check(_lib.lib().cvhip_ransac_score(device.handle, p(F), H, p(matches), N, float(t), p(cnt), p(err)),
                "cvhip_ransac_score")
     return cnt, err
+
+
+def find_ransac_affine(device, matches, seed: int = 0):
+    """FundamentalMatrix::new(Affine, _).find_ransac(matches) entirely on the device
+    (cvhip_ransac_affine).  -> (F[3, 3] float64, inlier_mask[N] bool).  Raises CvhipError (code -5) with
+    the reference's RansacError text when no model is found."""
+    matches = np.ascontiguousarray(np.asarray(matches, dtype=np.uint32).reshape(-1, 4))
+    N = matches.shape[0]
+    F = np.zeros(9, dtype=np.float64)
+    mask = np.zeros(max(N, 1), dtype=np.uint8)
+    cnt = C.c_uint32(0)
+    _lib.check(_lib.lib().cvhip_ransac_affine(device.handle, C.c_void_p(matches.ctypes.data), N, seed,
+                                              C.c_void_p(F.ctypes.data), C.byref(cnt), C.c_void_p(mask.ctypes.data)),
+               "cvhip_ransac_affine")
+    return F.reshape(3, 3), mask[:N].astype(bool)

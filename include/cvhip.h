@@ -38,6 +38,7 @@ extern "C" {
 #define CVHIP_ERR_DEVICE (-2)      /* HIP runtime error (message has hipGetErrorString) */
 #define CVHIP_ERR_UNSUPPORTED (-3) /* valid in the reference, not supported here (documented) */
 #define CVHIP_ERR_NOMEM (-4)
+#define CVHIP_ERR_NO_MODEL (-5)    /* RANSAC: "Not enough matches" / "No reliable matches found" (RansacError) */
 
 typedef struct cvhip_device cvhip_device;
 typedef struct cvhip_ctx cvhip_ctx;
@@ -166,6 +167,16 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
 
 /* ------------------------------------------------------------------------------------------
+ * Pyramid level on the device.  The reference builds every level with
+ * the `image` crate's Lanczos3 resize on the host (reconstruction.rs:146-162), upstream of the
+ * boundary; its source is not available here, so this is the documented substitute used by the
+ * benchmark: one 2x2 box-filter step with rounding, dst dims floor(w/2) x floor(h/2),
+ * dst[y][x] = (s[2y][2x] + s[2y][2x+1] + s[2y+1][2x] + s[2y+1][2x+1] + 2) >> 2.  Keeps pyramids
+ * resident in HBM for both the ORB and the dense stage.  Host or device pointers.
+ * ---------------------------------------------------------------------------------------- */
+int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint32_t w, uint32_t h, uint8_t *dst);
+
+/* ------------------------------------------------------------------------------------------
  * ORB — replaces orb::extract_points (orb.rs:50-84).
  * out_xy: 2*cap u32 (x, y), out_desc: 8*cap u32, *out_n = keypoints written (<= cap).
  * Order = the reference's (Harris-descending stable, then BRIEF filter).  cap >= 10000 to
@@ -191,6 +202,19 @@ int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const uint32_t *d
  * ---------------------------------------------------------------------------------------- */
 int cvhip_ransac_score(cvhip_device *dev, const double *F, uint32_t H, const uint32_t *matches, uint32_t N,
                        double t, uint32_t *out_count, double *out_err_sum);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole affine RANSAC on the device — replaces
+ * FundamentalMatrix::new(Affine, _).find_ransac(matches) (fundamentalmatrix.rs:72-147, 155-286,
+ * 231-239): sampling, the 4-point model fit and the sample checks run next to the scoring kernel;
+ * the host only reads one early-exit word per 50 000-iteration round.  matches: 4*N u32
+ * (x1,y1,x2,y2) sorted by descriptor distance as KeypointMatching returns them (the first 5000 are
+ * sampled).  out_F: 9 doubles row-major; out_inlier_mask: N bytes (may be NULL).  The reference's RNG
+ * is OS-seeded (not reproducible), so equality with it is statistical; `seed` makes this one
+ * reproducible.  Returns CVHIP_ERR_NO_MODEL with the reference's RansacError messages.
+ * ---------------------------------------------------------------------------------------- */
+int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint64_t seed, double *out_F,
+                        uint32_t *out_inlier_count, uint8_t *out_inlier_mask);
 
 #ifdef __cplusplus
 }

@@ -419,3 +419,29 @@ def test_triangulate_affine_matches_oracle(gpu_device, oracle, name):
     assert (m2 == want_m2).all()
     if name != "flat":
         assert len(pts) > 1000 and (pts[:, 2] >= 0).all()
+
+
+def test_device_box_pyramid_equals_host(gpu_device):
+    """cvhip_downsample_box reproduces synth.box_pyramid byte for byte (odd sizes included)."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    for (h, w) in [(257, 301), (128, 128), (65, 96)]:
+        img = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        want = synth.box_pyramid(img, 3)
+        torch_stream_dev = correlation.create_gpu_context(stream=torch.cuda.current_stream().cuda_stream)
+        try:
+            got = correlation.box_pyramid_device(torch_stream_dev, torch.from_numpy(img).cuda(), 3)
+            torch.cuda.synchronize()
+        finally:
+            torch_stream_dev.close()
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and (a.cpu().numpy() == b).all()
+        # host pointers work too
+        import ctypes as C
+
+        from cybervision_amd import _lib
+        dst = np.zeros((h // 2, w // 2), dtype=np.uint8)
+        _lib.check(_lib.lib().cvhip_downsample_box(gpu_device.handle, C.c_void_p(img.ctypes.data), w, h,
+                                                   C.c_void_p(dst.ctypes.data)), "cvhip_downsample_box")
+        assert (dst == want[1]).all()

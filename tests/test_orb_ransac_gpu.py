@@ -116,3 +116,60 @@ def test_ransac_score_ragged_sizes(gpu_device, oracle):
         want_c, want_e = oracle.ransac_score(F, m, 0.1)
         got_c, got_e = fundamentalmatrix.ransac_score(gpu_device, F, m, 0.1)
         assert (got_c == want_c).all() and (got_e.view(np.uint64) == want_e.view(np.uint64)).all()
+
+
+def affine_matches(n=4000, outlier_frac=0.35, seed=5):
+    """Matches of a known affine geometry x2^T F x1 = 0 with F = f_tilt(12 deg): the point in image 2 lies on
+    the line through (x1, y1) with that direction, at a random signed distance (integer rounding noise)."""
+    import math
+
+    rng = np.random.default_rng(seed)
+    th = math.radians(12.0)
+    x1 = rng.integers(100, 1900, size=n).astype(np.float64)
+    y1 = rng.integers(100, 1900, size=n).astype(np.float64)
+    dist = rng.uniform(-80, 80, size=n)
+    x2 = x1 + dist * math.cos(th)
+    y2 = y1 + dist * math.sin(th)
+    out = rng.random(n) < outlier_frac
+    x2[out] = rng.integers(0, 2000, size=int(out.sum()))
+    y2[out] = rng.integers(0, 2000, size=int(out.sum()))
+    m = np.stack([x1, y1, np.round(x2), np.round(y2)], axis=1).clip(0, None).astype(np.uint32)
+    return m, ~out, synth.f_tilt(12.0)
+
+
+def test_device_affine_ransac_recovers_known_model(gpu_device, oracle):
+    m, truth_inlier, F_true = affine_matches()
+    F, mask = fundamentalmatrix.find_ransac_affine(gpu_device, m, seed=7)
+    # affine form, normalised by f[2][2] (fundamentalmatrix.rs:284-285)
+    assert F[2, 2] == 1.0 and (F[:2, :2] == 0).all()
+    # direction of the epilines: (F[0][2], F[1][2]) ~ (-sin, cos) up to scale
+    d = np.array([F[0, 2], F[1, 2]])
+    d /= np.linalg.norm(d)
+    want = np.array([F_true[0, 2], F_true[1, 2]])
+    assert min(np.linalg.norm(d - want), np.linalg.norm(d + want)) < 5e-3
+    # the inlier set is (almost) the planted one; rounding to integer pixels costs a few
+    assert (mask & truth_inlier).sum() > 0.9 * truth_inlier.sum()
+    assert (mask & ~truth_inlier).sum() < 0.05 * (~truth_inlier).sum()
+    # the returned mask is exactly fits_model of the returned F (optimize_result, :231-239)
+    cnt, _ = oracle.ransac_score(F, m, fundamentalmatrix.RANSAC_T_AFFINE)
+    assert cnt[0] == mask.sum()
+    errs = np.array([oracle.reprojection_error(F, mm) for mm in m[:200]])
+    assert ((np.abs(errs) <= 0.1) == mask[:200]).all()
+    # reproducible for a fixed seed, different (but equally good) for another
+    F2, mask2 = fundamentalmatrix.find_ransac_affine(gpu_device, m, seed=7)
+    assert (F2 == F).all() and (mask2 == mask).all()
+    F3, mask3 = fundamentalmatrix.find_ransac_affine(gpu_device, m, seed=8)
+    assert abs(int(mask3.sum()) - int(mask.sum())) < 0.05 * mask.sum()
+
+
+def test_device_affine_ransac_error_reporting(gpu_device):
+    from cybervision_amd._lib import CvhipError
+
+    with pytest.raises(CvhipError) as ei:
+        fundamentalmatrix.find_ransac_affine(gpu_device, np.zeros((5, 4), dtype=np.uint32))
+    assert ei.value.code == -5 and "Not enough matches" in str(ei.value)
+    rng = np.random.default_rng(1)
+    noise = rng.integers(0, 2000, size=(300, 4)).astype(np.uint32)  # no consistent geometry at t = 0.1
+    with pytest.raises(CvhipError) as ei:
+        fundamentalmatrix.find_ransac_affine(gpu_device, noise, seed=3)
+    assert ei.value.code == -5 and "No reliable matches" in str(ei.value)
