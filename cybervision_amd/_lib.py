@@ -45,6 +45,7 @@ SIGNATURES = {
     "cvhip_complete_dir": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "cvhip_triangulate_affine": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cvhip_ctx_set_row_shard": (C.c_int, [_vp, _u32, _u32, ALLGATHER_FN, _vp]),
+    "cvhip_ctx_set_row_band": (C.c_int, [_vp, _u32, _u32]),
     "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32),
                                        C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "cvhip_ctx_set_profiling": (C.c_int, [_vp, C.c_int, C.c_int]),

@@ -210,6 +210,15 @@ class PointCorrelations:
         self._gather_cb = cb  # keep the thunk alive as long as the context may call it
         _lib.check(_lib.lib().cvhip_ctx_set_row_shard(self._h, num, den, cb, None), "cvhip_ctx_set_row_shard")
 
+    def set_row_band(self, num: int, den: int) -> bool:
+        """Independent-band sharding (no collectives until the final gather).  Returns False when the
+        geometry is not row-local and the all-gather mode (set_row_shard) has to be used instead."""
+        rc = _lib.lib().cvhip_ctx_set_row_band(self._h, num, den)
+        if rc == -3:
+            return False
+        _lib.check(rc, "cvhip_ctx_set_row_band")
+        return True
+
     def level_grid(self, direction: CorrelationDirection):
         cells = C.c_void_p()
         lw, lh, r0, r1, rps = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

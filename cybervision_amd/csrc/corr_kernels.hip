@@ -111,12 +111,12 @@ __device__ __forceinline__ uint32_t corridor_end_of(const CorrParams &p, const L
 // VALID mirrors the reference's per-candidate test "stdev finite and >= min_stdev" (mod.rs:439)
 // evaluated on the reference's own f32 stdev.
 __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
-                                                            float min_stdev, float2 *__restrict__ stats,
-                                                            uint2 *__restrict__ istats)
+                                                            uint32_t row0, uint32_t row1, float min_stdev,
+                                                            float2 *__restrict__ stats, uint2 *__restrict__ istats)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    const uint32_t y = row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= row1) return;
     const float nan = __builtin_nanf("");
     float2 out = make_float2(nan, nan);
     uint2 iout = make_uint2(0u, 0u);
@@ -150,11 +150,13 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
     istats[(size_t)y * w + x] = iout;
 }
 
-void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float min_stdev, float2 *stats, uint2 *istats,
-                         hipStream_t s)
+void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, uint32_t row0, uint32_t row1, float min_stdev,
+                         float2 *stats, uint2 *istats, hipStream_t s)
 {
-    dim3 grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, img, w, h, min_stdev, stats, istats);
+    row1 = min(row1, h);
+    if (row1 <= row0) return;
+    dim3 grid((w + 63) / 64, (row1 - row0 + 3) / 4);
+    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, img, w, h, row0, row1, min_stdev, stats, istats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1006,10 +1008,12 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
 constexpr int CC_ROWS = 4; // rows per thread: independent load chains in flight (the kernel is latency-bound)
 
 __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ own, const uint2 *__restrict__ other,
-                                                           uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh)
+                                                           uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
+                                                           uint32_t row0)
 {
+    // oh = end of the row range handled by this launch, row0 its start
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CC_ROWS;
+    const uint32_t y0 = row0 + (blockIdx.y * 4 + (threadIdx.x >> 6)) * CC_ROWS;
     if (x >= ow) return;
     const uint32_t sa = CROSS_CHECK_SEARCH_AREA;
     uint32_t cell[CC_ROWS], probe[CC_ROWS];
@@ -1052,10 +1056,12 @@ __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ ow
 }
 
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
-                        hipStream_t s)
+                        uint32_t row0, uint32_t row1, hipStream_t s)
 {
-    dim3 grid((ow + 63) / 64, (oh + 4 * CC_ROWS - 1) / (4 * CC_ROWS));
-    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, own, other, ow, oh, rw, rh);
+    row1 = min(row1, oh);
+    if (row1 <= row0) return;
+    dim3 grid((ow + 63) / 64, (row1 - row0 + 4 * CC_ROWS - 1) / (4 * CC_ROWS));
+    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, own, other, ow, row1, rw, rh, row0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -167,7 +167,13 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         static const int dbg = [] { const char *v = std::getenv("CVHIP_DEBUG"); return v ? std::atoi(v) : 0; }();
         p.debug = k == 0 ? dbg : 0; // only the full-resolution level, so coarser levels still seed it
     }
-    shard_rows(c, lh1, &p.row0, &p.row1);
+    if (c->band_mode) {
+        const uint32_t *r = dir == 0 ? c->band[k].sf : c->band[k].sr;
+        p.row0 = std::min(r[0], lh1);
+        p.row1 = std::min(r[1], lh1);
+    } else {
+        shard_rows(c, lh1, &p.row0, &p.row1);
+    }
 
     const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
     unsigned long long *cnt = c->count_candidates ? c->d_cand : nullptr;
@@ -206,8 +212,14 @@ static int cross_check_pass(cvhip_ctx *c, int k, int dir)
     if (!own.valid || !other.valid) return fail(CVHIP_ERR_INVALID, "cross_check_filter before both passes ran");
     if ((int)own.k != k || (int)other.k != k)
         return fail(CVHIP_ERR_INVALID, "cross_check_filter scale does not match the grids' current level");
+    uint32_t r0 = 0, r1 = own.lh;
+    if (c->band_mode) {
+        const uint32_t *r = dir == 0 ? c->band[k].cf : c->band[k].cr;
+        r0 = std::min(r[0], own.lh);
+        r1 = std::min(r[1], own.lh);
+    }
     CVHIP_TRY(timed(c, cvhip_ctx::K_CROSS, [&] {
-        launch_cross_check(own.cells[own.cur], other.cells[other.cur], own.lw, own.lh, other.lw, other.lh,
+        launch_cross_check(own.cells[own.cur], other.cells[other.cur], own.lw, own.lh, other.lw, other.lh, r0, r1,
                            c->dev->d.stream);
     }));
     CVHIP_TRY_HIP(hipGetLastError());
@@ -398,10 +410,17 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
     CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s)); // transfer_in_images, gpu/mod.rs:274
     CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
     report(progress, user, dir, 0.02f);
-    CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-        launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
-        launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
-    }));
+    {
+        uint32_t sr0 = 0, sr1 = std::max(h1, h2);
+        if (ctx->band_mode) {
+            sr0 = ctx->band[k].st[0];
+            sr1 = ctx->band[k].st[1];
+        }
+        CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
+            launch_window_stats(ctx->img[0], w1, h1, sr0, sr1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
+            launch_window_stats(ctx->img[1], w2, h2, sr0, sr1, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+        }));
+    }
     report(progress, user, dir, 0.20f);
     CVHIP_TRY(search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, dir));
     // Pageable host sources must not be reused by the caller before the copy has happened.
@@ -430,18 +449,27 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     // every rank (identical results, no collective).  The rule depends on level dims only, so all
     // ranks take the same branch.
     const uint32_t den = ctx->shard_den, num = ctx->shard_num;
-    const bool sharded = den > 1 && std::min(h1, h2) / den >= 64;
+    const bool sharded = !ctx->band_mode && den > 1 && std::min(h1, h2) / den >= 64;
     if (sharded && !ctx->gather)
         return fail(CVHIP_ERR_INVALID, "row-sharded context without an all-gather hook (cvhip_ctx_set_row_shard)");
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s));
     CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
-    CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-        launch_window_stats(ctx->img[0], w1, h1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
-        launch_window_stats(ctx->img[1], w2, h2, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
-    }));
+    {
+        uint32_t sr0 = 0, sr1 = std::max(h1, h2);
+        if (ctx->band_mode) {
+            sr0 = ctx->band[k].st[0];
+            sr1 = ctx->band[k].st[1];
+        }
+        CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
+            launch_window_stats(ctx->img[0], w1, h1, sr0, sr1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
+            launch_window_stats(ctx->img[1], w2, h2, sr0, sr1, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+        }));
+    }
     report(progress, user, 0, 0.20f);
+    if (ctx->band_mode && (k > ctx->band_steps || (ctx->w1 >> k) != w1 || (ctx->h1 >> k) != h1))
+        return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
     if (!sharded) {
         ctx->shard_num = 0;
         ctx->shard_den = 1;
@@ -561,6 +589,116 @@ int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_al
     ctx->shard_den = den;
     ctx->gather = gather;
     ctx->gather_user = user;
+    return CVHIP_OK;
+}
+
+// Host-side copy of the kernels' epipolar line for a level pixel (get_epipolar_line, mod.rs:386-409).
+static bool host_minor_offset_bound(const cvhip_ctx *c, int dir, int k, uint32_t lw1, uint32_t lh1, uint32_t lw2,
+                                    uint32_t lh2, double *bound)
+{
+    double F[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) F[i * 3 + j] = dir == 0 ? c->F[i * 3 + j] : c->F[j * 3 + i];
+    // the bound below relies on l = F*p having constant (x, y) components: the affine form
+    if (F[0] != 0.0 || F[1] != 0.0 || F[3] != 0.0 || F[4] != 0.0) return false;
+    const double scale = 1.0 / (double)(1u << k);
+    double worst = 0.0;
+    const uint32_t xs[2] = {KERNEL_SIZE, lw1 - KERNEL_SIZE - 1}, ys[2] = {KERNEL_SIZE, lh1 - KERNEL_SIZE - 1};
+    for (uint32_t px : xs)
+        for (uint32_t py : ys) {
+            const double p0 = (double)px / scale, p1 = (double)py / scale;
+            double f[3];
+            for (int i = 0; i < 3; i++) f[i] = (F[i * 3 + 0] * p0 + F[i * 3 + 1] * p1) + F[i * 3 + 2];
+            if (std::fabs(f[0]) > std::fabs(f[1])) return false; // corridor advances along y: not row-local
+            const double cy = -f[0] / f[1], ay = -scale * f[2] / f[1];
+            if (!std::isfinite(cy) || !std::isfinite(ay)) return false;
+            const uint32_t ends[2] = {KERNEL_SIZE, lw2 - KERNEL_SIZE};
+            for (uint32_t i : ends)
+                for (int off : {-c->corridor_size, c->corridor_size})
+                    worst = std::max(worst, std::fabs(std::floor((cy * (double)i + ay) + (double)off) - (double)py));
+        }
+    (void)lh2;
+    *bound = worst + 1.0; // y2 - y is affine in (x, y, i) up to the floor: corners bound it
+    return true;
+}
+
+int cvhip_ctx_set_row_band(cvhip_ctx *ctx, uint32_t num, uint32_t den)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (den == 0 || den > 64 || num >= den) return fail(CVHIP_ERR_INVALID, "need 0 <= num < den <= 64");
+    ctx->band_mode = false;
+    ctx->shard_num = num;
+    ctx->shard_den = den;
+    if (den == 1) return CVHIP_OK;
+    // the reference's level schedule (optimal_scale_steps, mod.rs:542-550; reconstruction.rs:565-568)
+    const uint32_t min_dim = std::min(ctx->w1, ctx->h1);
+    const int steps = min_dim <= 64 ? 0 : (int)std::floor(std::log2((double)min_dim / 64.0));
+    if (steps > 15) return fail(CVHIP_ERR_UNSUPPORTED, "band mode: too many levels");
+    auto expand = [](const uint32_t (&r)[2], uint32_t m, uint32_t (&o)[2]) {
+        o[0] = r[0] > m ? r[0] - m : 0u;
+        o[1] = r[1] + m;
+    };
+    auto hull = [](const uint32_t (&a)[2], const uint32_t (&b)[2], uint32_t (&o)[2]) {
+        const bool ea = a[1] <= a[0], eb = b[1] <= b[0];
+        if (ea && eb) {
+            o[0] = o[1] = 0;
+        } else if (ea) {
+            o[0] = b[0];
+            o[1] = b[1];
+        } else if (eb) {
+            o[0] = a[0];
+            o[1] = a[1];
+        } else {
+            o[0] = std::min(a[0], b[0]);
+            o[1] = std::max(a[1], b[1]);
+        }
+    };
+    cvhip_ctx::BandPlan *bp = ctx->band;
+    shard_rows(ctx, ctx->h1, &bp[0].cf[0], &bp[0].cf[1]); // the band of the final forward grid
+    bp[0].cr[0] = bp[0].cr[1] = 0;                        // the filtered reverse grid is never needed at level 0
+    for (int k = 0; k <= steps; k++) {
+        const uint32_t lw1 = ctx->w1 >> k, lh1 = ctx->h1 >> k, lw2 = ctx->w2 >> k, lh2 = ctx->h2 >> k;
+        if (lw1 < KERNEL_WIDTH || lh1 < KERNEL_WIDTH || lw2 < KERNEL_WIDTH || lh2 < KERNEL_WIDTH)
+            return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level too small");
+        double df = 0.0, dr = 0.0;
+        if (!host_minor_offset_bound(ctx, 0, k, lw1, lh1, lw2, lh2, &df) ||
+            !host_minor_offset_bound(ctx, 1, k, lw2, lh2, lw1, lh1, &dr))
+            return fail(CVHIP_ERR_UNSUPPORTED,
+                        "band mode needs row-local geometry (affine F with near-horizontal epipolar lines); "
+                        "use cvhip_ctx_set_row_shard with an all-gather hook instead");
+        const double dmax = std::max(df, dr);
+        if (dmax > 64.0) return fail(CVHIP_ERR_UNSUPPORTED, "band mode: epipolar lines too steep for a row band");
+        const uint32_t D = (uint32_t)dmax, E = D + CROSS_CHECK_SEARCH_AREA;
+        uint32_t t[2];
+        // a filtered cell needs its own search result and the other direction's unfiltered cells within
+        // +-(D + 4) rows (mod.rs:588-624); a search result needs the filtered coarser cells (below)
+        expand(bp[k].cr, E, t);
+        if (bp[k].cr[1] <= bp[k].cr[0]) t[0] = t[1] = 0;
+        hull(bp[k].cf, t, bp[k].sf);
+        expand(bp[k].cf, E, t);
+        if (bp[k].cf[1] <= bp[k].cf[0]) t[0] = t[1] = 0;
+        hull(bp[k].cr, t, bp[k].sr);
+        // window statistics: searched rows of either image plus the candidates' rows around them
+        uint32_t u[2];
+        hull(bp[k].sf, bp[k].sr, u);
+        expand(u, D + 1, bp[k].st);
+        if (k < steps) {
+            // estimate_search_range of row y reads coarser rows [ceil((y-10)/2), ceil((y+10)/2)): +-6 (+1 slack)
+            auto half = [](const uint32_t (&r)[2], uint32_t (&o)[2]) {
+                o[0] = r[0] / 2;
+                o[1] = (r[1] + 1) / 2;
+            };
+            uint32_t hsf[2], hsr[2];
+            half(bp[k].sf, hsf);
+            half(bp[k].sr, hsr);
+            expand(hsf, 7, bp[k + 1].cf);
+            expand(hsr, 7, bp[k + 1].cr);
+            if (bp[k].sf[1] <= bp[k].sf[0]) bp[k + 1].cf[0] = bp[k + 1].cf[1] = 0;
+            if (bp[k].sr[1] <= bp[k].sr[0]) bp[k + 1].cr[0] = bp[k + 1].cr[1] = 0;
+        }
+    }
+    ctx->band_steps = steps;
+    ctx->band_mode = true;
     return CVHIP_OK;
 }
 

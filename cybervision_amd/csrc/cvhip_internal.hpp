@@ -58,8 +58,8 @@ struct CorrParams {
 };
 
 // ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------
-void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, float min_stdev, float2 *stats, uint2 *istats,
-                         hipStream_t s);
+void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, uint32_t row0, uint32_t row1, float min_stdev,
+                         float2 *stats, uint2 *istats, hipStream_t s);
 void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
                          hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
@@ -73,7 +73,7 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
                           uint2 *out, unsigned long long *counters, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
-                        hipStream_t s);
+                        uint32_t row0, uint32_t row1, hipStream_t s);
 void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                         int32_t *out_xy, float *out_corr, hipStream_t s);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
@@ -127,6 +127,15 @@ struct cvhip_ctx {
     uint32_t shard_num = 0, shard_den = 1;
     cvhip_allgather_fn gather = nullptr;
     void *gather_user = nullptr;
+    // Independent-band mode (cvhip_ctx_set_row_band): per level k, the row intervals [lo, hi) of the
+    // forward / reverse search passes (sf, sr) and cross-checks (cf, cr) this context has to compute so
+    // that its band of the final forward grid is exact without any exchange.
+    struct BandPlan {
+        uint32_t sf[2], sr[2], cf[2], cr[2], st[2];
+    };
+    bool band_mode = false;
+    int band_steps = 0;
+    BandPlan band[16];
 
     int time_kernels = 0, count_candidates = 0;
     unsigned long long *d_cand = nullptr;

@@ -136,6 +136,19 @@ int cvhip_triangulate_affine(cvhip_ctx *ctx, double *out_points3d, uint32_t *out
  * calls the host gathers between passes (cvhip_ctx_level_grid).  num = 0, den = 1 (default) =
  * all rows; den <= 64; gather may be NULL when only the per-pass calls are used. */
 int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_allgather_fn gather, void *user);
+/* Row sharding without collectives ("independent band" mode).  For row-local geometry — an affine F
+ * whose epipolar lines stay within a few rows of the pixel's own row at every pyramid level — shard
+ * `num` of `den` computes, at every level, only the rows its band of the FINAL forward grid depends
+ * on: the band plus a halo (about 2*D + 20 rows per level, D = the corridor's row excursion) that is
+ * recomputed redundantly instead of exchanged.  Uses the fact that the two cross-checks of a level
+ * commute (any reverse match that supports a forward match is itself supported by it, mod.rs:588-624),
+ * so no filtered grid has to be communicated between passes.  After the last level only rows
+ * [num*rps, (num+1)*rps) of the forward level grid (cvhip_ctx_level_grid, dir 0) are meaningful; the
+ * host gathers those bands once (the single RCCL gather of the north star) before cvhip_complete.
+ * Returns CVHIP_ERR_UNSUPPORTED when the geometry is not row-local (perspective F, steep or
+ * column-major lines): fall back to cvhip_ctx_set_row_shard + all-gather hook.  The context must be
+ * driven with cvhip_correlate_level over the reference's schedule (scale = 2^-k, k = steps..0). */
+int cvhip_ctx_set_row_band(cvhip_ctx *ctx, uint32_t num, uint32_t den);
 /* Device pointer + geometry of direction `dir`'s current level grid, for the host's
  * collectives.  One 8-byte cell per level pixel, row-major lw x lh: u32 x | y << 16 in LEVEL
  * coordinates (0xFFFFFFFF = None) followed by the f32 score.  The buffer always has room for

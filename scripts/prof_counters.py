@@ -21,7 +21,8 @@ F = synth.F_HORIZONTAL
 for a in sys.argv:
     if a.startswith("--tilt="):
         F = synth.f_tilt(float(a.split("=")[1]))
-pc = correlation.PointCorrelations(dev, (W, W), (W, W), F)
+proj = correlation.ProjectionMode.Perspective if "--perspective" in sys.argv else correlation.ProjectionMode.Affine
+pc = correlation.PointCorrelations(dev, (W, W), (W, W), F, proj)
 COUNT = "--count" in sys.argv
 pc.set_profiling(True, COUNT)
 for i in range(steps + 1):

@@ -37,16 +37,23 @@ def main():
         calls.append((nbytes, n, direction))
         inner(ptr, nbytes, n, direction)
 
-    pc.set_row_shard(rank, world, gather)
+    band = pc.set_row_band(rank, world)  # independent bands when the geometry is row-local ...
+    assert band == (sys.argv[2] == "band"), f"expected mode {sys.argv[2]}"
+    if not band:
+        pc.set_row_shard(rank, world, gather)  # ... else bands + all-gather after every sharded pass
     sharded_levels = 0
     for i in range(steps + 1):
         k = steps - i
         before = len(calls)
         pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
-        expect = sharding.level_is_sharded(d1[k].shape[0], d2[k].shape[0], world)
+        expect = (not band) and sharding.level_is_sharded(d1[k].shape[0], d2[k].shape[0], world)
         assert (len(calls) - before) == (2 if expect else 0), (k, calls[before:])
         sharded_levels += int(expect)
-    assert sharded_levels >= 1, "test case too small to exercise the collective"
+    if band:  # the single final gather of the forward bands
+        g = pc.level_grid(correlation.CorrelationDirection.Forward)
+        inner(g["cells"], g["rows_per_shard"] * g["lw"] * 8, world, 0)
+    else:
+        assert sharded_levels >= 1, "test case too small to exercise the collective"
     xy, corr = pc.complete()
     want_xy, want_corr = g["fwd_xy"].astype(np.int32), g["fwd_corr"]
     bad = np.nonzero((xy != want_xy).any(axis=-1))

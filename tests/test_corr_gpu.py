@@ -346,7 +346,8 @@ def test_sharded_level_call_with_gather_hook(gpu_device, oracle):
         pc.close()
 
 
-def test_two_rank_sharded_level_calls():
+@pytest.mark.parametrize("case,mode", [("persp_240x180", "gather"), ("tilt3_200x150", "band")])
+def test_two_rank_sharded_level_calls(case, mode):
     """End-to-end N = 2: two processes (sharing this box's one GPU) row-shard every search pass,
     cvhip_correlate_level drives the all-gather hook itself (gloo staged through the host here; RCCL
     on a real multi-GPU node), and both ranks must reproduce the golden grid bit for bit."""
@@ -362,7 +363,7 @@ def test_two_rank_sharded_level_calls():
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(root / "tests" / "_shard_gpu_worker.py"), "persp_240x180"],
+        procs.append(subprocess.Popen([sys.executable, str(root / "tests" / "_shard_gpu_worker.py"), case, mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
@@ -445,3 +446,52 @@ def test_device_box_pyramid_equals_host(gpu_device):
         _lib.check(_lib.lib().cvhip_downsample_box(gpu_device.handle, C.c_void_p(img.ctypes.data), w, h,
                                                    C.c_void_p(dst.ctypes.data)), "cvhip_downsample_box")
         assert (dst == want[1]).all()
+
+
+@pytest.mark.parametrize("name,den", [("h256", 2), ("sem320x200", 3), ("tilt3_200x150", 2)])
+def test_independent_band_mode_equals_unsharded(gpu_device, oracle, name, den):
+    """cvhip_ctx_set_row_band: every shard context runs the whole pyramid on its band + halo with NO
+    exchange between levels; stitching the bands of the final forward grids must give the oracle's grid
+    bit for bit (this is what the single final gather does on a multi-GPU node)."""
+    import torch
+
+    from cybervision_amd import sharding
+
+    c = cases.make_case(name)
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    F = correlation.CorrelationDirection.Forward
+    want = run_oracle(oracle, c)
+    ctxs = [correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"]) for _ in range(den)]
+    try:
+        for r, pc in enumerate(ctxs):
+            assert pc.set_row_band(r, den), "geometry should be row-local"
+            for i in range(c["steps"] + 1):
+                k = c["steps"] - i
+                pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+        gpu_device.synchronize()
+        grids = [pc.level_grid(F) for pc in ctxs]
+        for r in range(1, den):  # the final gather: band r of context r -> context 0
+            g = grids[r]
+            r0, r1 = sharding.shard_rows(g["lh"], r, den)
+            nbytes = (r1 - r0) * g["lw"] * 8
+            if nbytes:
+                src = sharding.alias_bytes(g["cells"] + r0 * g["lw"] * 8, nbytes, device=True)
+                dst = sharding.alias_bytes(grids[0]["cells"] + r0 * g["lw"] * 8, nbytes, device=True)
+                dst.copy_(src)
+        torch.cuda.synchronize()
+        assert_same_grid(ctxs[0].complete(F), want, f"{name} stitched from {den} independent bands")
+    finally:
+        for pc in ctxs:
+            pc.close()
+
+
+def test_band_mode_rejects_non_row_local_geometry(gpu_device):
+    for Fm, proj in [(cases.perspective_f(240, 180), correlation.ProjectionMode.Perspective),
+                     (synth.f_tilt(60.0), correlation.ProjectionMode.Affine)]:
+        pc = correlation.PointCorrelations(gpu_device, (240, 180), (240, 180), Fm, proj)
+        try:
+            assert pc.set_row_band(0, 2) is False
+        finally:
+            pc.close()
