@@ -50,8 +50,8 @@ def main():
         assert (len(calls) - before) == (2 if expect else 0), (k, calls[before:])
         sharded_levels += int(expect)
     if band:  # the single final gather of the forward bands
-        g = pc.level_grid(correlation.CorrelationDirection.Forward)
-        inner(g["cells"], g["rows_per_shard"] * g["lw"] * 8, world, 0)
+        lg = pc.level_grid(correlation.CorrelationDirection.Forward)
+        inner(lg["cells"], lg["rows_per_shard"] * lg["lw"] * 8, world, 0)
     else:
         assert sharded_levels >= 1, "test case too small to exercise the collective"
     xy, corr = pc.complete()
