@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=4096, help="image side (default: BASELINE's 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simulate-shard", default="", help="num/den: time one rank's share of a den-GPU band-mode run on 1 GPU")
     ap.add_argument("--cpu-sample", type=int, default=512, help="side of the first crop timed on the CPU")
     args = ap.parse_args()
 
@@ -99,8 +100,22 @@ def main():
     stream = torch.cuda.current_stream()
     dev = correlation.create_gpu_context(ordinal=local_rank, stream=stream.cuda_stream)
     pc = correlation.PointCorrelations(dev, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
-    if world > 1:
-        pc.set_row_shard(rank, world, sharding.make_allgather(rank, world))
+    band_mode = False
+    final_gather = None
+    sim = None
+    if args.simulate_shard:  # single-GPU emulation of ONE rank's share of an N-GPU run (no collectives)
+        num, den = (int(v) for v in args.simulate_shard.split("/"))
+        sim = (num, den)
+        if not pc.set_row_band(num, den):
+            raise SystemExit("--simulate-shard needs row-local geometry")
+        band_mode = True
+    elif world > 1:
+        gather = sharding.make_allgather(rank, world)
+        band_mode = pc.set_row_band(rank, world)   # independent bands + halo, one final gather ...
+        if band_mode:
+            final_gather = gather
+        else:
+            pc.set_row_shard(rank, world, gather)  # ... or, for non-row-local geometry, an all-gather per sharded pass
     out_xy = torch.empty((H, W, 2), dtype=torch.int32, device="cuda")
     out_corr = torch.empty((H, W), dtype=torch.float32, device="cuda")
 
@@ -109,6 +124,9 @@ def main():
         for i in range(steps + 1):
             k = steps - i
             pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+        if final_gather is not None:  # the single RCCL gather: forward bands of the full-resolution level
+            g = pc.level_grid(correlation.CorrelationDirection.Forward)
+            final_gather(g["cells"], g["rows_per_shard"] * g["lw"] * 8, world, 0)
         pc.complete(out_xy=out_xy, out_corr=out_corr)
 
     def fence():
@@ -174,7 +192,10 @@ def main():
                                    f"affine parameter set (11x11 window, 5 stripes, thr 0.6), F = horizontal epipolar "
                                    f"lines, {steps + 1} pyramid levels (2x2 box), fwd+rev search + 2 cross-checks per "
                                    f"level + complete() to HBM",
-                       "parallelism": "single GPU" if world == 1 else f"row-sharded x{world}, RCCL all-gather per sharded pass",
+                       "parallelism": ("single GPU" if world == 1 else
+                                       (f"row bands x{world} + halo, no exchange between levels, one RCCL all-gather of the final grid"
+                                        if band_mode else f"row-sharded x{world}, RCCL all-gather per sharded pass"))
+                                      + (f" [EMULATION of shard {sim[0]}/{sim[1]} on one GPU, no collective]" if sim else ""),
                        "candidates_per_step": candidates},
             "roofline": {
                 "kernel": "search2_filter_kernel",
