@@ -40,13 +40,14 @@ DOT4_PEAK_TMACS = 256 * 4 * 64 * 4 / 4 * 2.4e9 / 1e12   # = 157.3 T multiply-add
 def algorithmic_work(level_dims, candidates):
     """Algorithmic bytes / multiply-adds of ALL search2_filter_kernel launches of one step
     (DESIGN.md §4).  Per (level, direction) pass, each array touched once: searched pixel = img1 u8 (1)
-    + stats1 (8) + istats1 (8) + range (4) + contender word written (8) = 29 B; target pixel = img2 u8
-    (1) + istats2 (8) = 9 B.  Multiply-adds: 121 per evaluated candidate (the 11x11 integer dot)."""
+    + stats1 (8) + istats1 (8) + range (4) + contender word written (8) + result cell written (8) = 37 B;
+    target pixel = img2 u8 (1) + istats2 (8) = 9 B.  Multiply-adds: 121 per evaluated candidate (the
+    11x11 integer dot)."""
     b = 0
     for (w1, h1, w2, h2) in level_dims:
         n1, n2 = w1 * h1, w2 * h2
-        b += n1 * 29 + n2 * 9   # forward
-        b += n2 * 29 + n1 * 9   # reverse
+        b += n1 * 37 + n2 * 9   # forward
+        b += n2 * 37 + n1 * 9   # reverse
     return b, 121.0 * candidates
 
 

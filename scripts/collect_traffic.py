@@ -21,6 +21,7 @@ def per_kernel(d, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cvhip::", "")
+        name = name.split("<")[0]  # template instantiations of one kernel count together
         acc[name][0] += float(r["Counter_Value"])
         acc[name][1] += 1
     return acc
