@@ -585,6 +585,7 @@ int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_al
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
     if (den == 0 || den > 64 || num >= den) return fail(CVHIP_ERR_INVALID, "need 0 <= num < den <= 64");
+    ctx->band_mode = false;
     ctx->shard_num = num;
     ctx->shard_den = den;
     ctx->gather = gather;

@@ -58,7 +58,9 @@ def make_allgather(rank: int, world: int, group=None, device: bool = True):
         full = alias_bytes(cells_ptr, shard_bytes * n_shards, device)
         mine = full[rank * shard_bytes:(rank + 1) * shard_bytes]
         if dist.get_backend(group) == "nccl":
-            dist.all_gather_into_tensor(full, mine, group=group)  # in place: mine is full's rank-th chunk
+            # the send chunk is a private copy (16.8 MB at 4096^2 / 8 ranks: microseconds) so that the
+            # collective never sees overlapping send/receive buffers
+            dist.all_gather_into_tensor(full, mine.clone(), group=group)
         elif device:
             # gloo cannot all-gather device memory: stage through the host (test / fallback path only)
             import torch

@@ -173,3 +173,23 @@ def test_device_affine_ransac_error_reporting(gpu_device):
     with pytest.raises(CvhipError) as ei:
         fundamentalmatrix.find_ransac_affine(gpu_device, noise, seed=3)
     assert ei.value.code == -5 and "No reliable matches" in str(ei.value)
+
+
+def test_orb_multiscale_driver_matches_oracle(gpu_device, oracle):
+    """match_keypoints' per-image loop (reconstruction.rs:407-459): levels coarse to fine, coordinates
+    mapped back with (x as f32 / scale) as usize, lists concatenated."""
+    img = orb_image(1100, 900, seed=13, blocks=500)
+    steps = orb.optimal_scale_steps(1100, 900)
+    assert steps == 1 and oracle.lib().cvref_orb_optimal_scale_steps(1100, 900) == 1
+    pyr = synth.box_pyramid(img, steps)
+    got_xy, got_desc = orb.extract_points_multiscale(gpu_device, pyr)
+    want_xy, want_desc = [], []
+    for i in range(steps + 1):
+        k = steps - i
+        xy, desc = oracle.orb_extract(pyr[k])
+        scale = np.float32(1.0 / (1 << k))
+        want_xy.append(np.floor(xy.astype(np.float32) / scale).astype(np.uint32))
+        want_desc.append(desc)
+    want_xy, want_desc = np.concatenate(want_xy), np.concatenate(want_desc)
+    assert len(want_xy) > 1000
+    assert (got_xy == want_xy).all() and (got_desc == want_desc).all()
