@@ -339,7 +339,10 @@ extern "C" int cvhip_ransac_score(cvhip_device *dev, const double *F, uint32_t H
     if (H == 0) return CVHIP_OK;
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     hipStream_t s = dev->d.stream;
-    const bool f_dev = dev_ptr(F), m_dev = N ? dev_ptr(matches) : true, c_dev = dev_ptr(out_count),
+    // the kernel reads matches as 16-byte vectors: a device pointer that is not 16-byte aligned is copied too
+    const bool f_dev = dev_ptr(F),
+               m_dev = N ? (dev_ptr(matches) && (reinterpret_cast<uintptr_t>(matches) & 15u) == 0) : true,
+               c_dev = dev_ptr(out_count),
                e_dev = dev_ptr(out_err_sum);
     double *d_F = const_cast<double *>(F), *d_err = out_err_sum;
     uint32_t *d_m = const_cast<uint32_t *>(matches), *d_cnt = out_count;
@@ -351,7 +354,8 @@ extern "C" int cvhip_ransac_score(cvhip_device *dev, const double *F, uint32_t H
     if (e == hipSuccess && !m_dev) {
         e = hipMalloc(&d_m, (size_t)N * 4 * sizeof(uint32_t));
         if (e == hipSuccess)
-            e = hipMemcpyAsync(d_m, matches, (size_t)N * 4 * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+            e = hipMemcpyAsync(d_m, matches, (size_t)N * 4 * sizeof(uint32_t),
+                               dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     }
     if (e == hipSuccess && !c_dev) e = hipMalloc(&d_cnt, (size_t)H * sizeof(uint32_t));
     if (e == hipSuccess && !e_dev) e = hipMalloc(&d_err, (size_t)H * sizeof(double));
