@@ -196,18 +196,25 @@ __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x,
     ys1 = min((y_max + step - 1) >> p.pk, p.ph);
 }
 
+// One thread per 2x2 block of searched pixels {2bx-1, 2bx} x {2by-1, 2by}: for consecutive levels
+// (pk == k + 1) those four pixels see exactly the same previous-level cells —
+//   ceil((2m-1-10)/2) = ceil((2m-10)/2) = m-5   and   ceil((2m-1+10)/2) = ceil((2m+10)/2) = m+5,
+// clamping included — so the neighbour statistics are computed once and shared; each pixel then applies
+// its own validity tests and corridor bounds.  (Pixels of one block on different corridor axes, possible
+// only for perspective geometry, each get their own axis' statistics.)
 __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const float2 *__restrict__ stats1,
                                                             const uint2 *__restrict__ prev,
                                                             uint32_t *__restrict__ range)
 {
     __shared__ uint32_t cells[SR_TILE_W * SR_TILE_H + SR_WIN]; // + slack for the predicated row reads
-    const uint32_t bx = blockIdx.x * 64, by = p.row0 + blockIdx.y * 4;
-    const uint32_t x = bx + (threadIdx.x & 63);
-    const uint32_t y = by + (threadIdx.x >> 6);
+    // tile of 64 x 4 blocks = pixels [128*bx0 - 1, 128*bx0 + 127] x [by_first*2 - 1, ...]
+    const uint32_t bxi = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t byi = (p.row0 >> 1) + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const uint32_t tile_x0 = blockIdx.x * 128, tile_y0 = ((p.row0 >> 1) + blockIdx.y * 4) * 2;
     // window of the whole tile = union of its corner pixels' windows (the bounds are monotone in x, y)
     uint32_t tx0, tx1, ty0, ty1, ux0, ux1, uy0, uy1;
-    neighbor_window(p, bx, by, tx0, ux1, ty0, uy1);
-    neighbor_window(p, min(bx + 63, p.w1 - 1), min(by + 3, p.h1 - 1), ux0, tx1, uy0, ty1);
+    neighbor_window(p, sat_sub_u32(tile_x0, 1), sat_sub_u32(tile_y0, 1), tx0, ux1, ty0, uy1);
+    neighbor_window(p, min(tile_x0 + 126, p.w1 - 1), min(tile_y0 + 6, p.h1 - 1), ux0, tx1, uy0, ty1);
     const uint32_t tw = tx1 > tx0 ? tx1 - tx0 : 0u, th = ty1 > ty0 ? ty1 - ty0 : 0u;
     const bool staged = tw <= (uint32_t)SR_TILE_W && th <= (uint32_t)SR_TILE_H;
     if (staged) {
@@ -217,101 +224,156 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
         }
     }
     __syncthreads();
-    if (x >= p.w1 || y >= p.row1) return;
-    uint32_t out = RANGE_NONE;
-    const bool interior = x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
-    if (interior) {
+
+    // the (up to) four pixels of this block and their per-pixel tests (mod.rs:334-345)
+    uint32_t px[4], py[4];
+    bool valid[4];
+    uint32_t cend[4];
+    int axis[4]; // 1: corridor position = y of the previous match (the (1, 0)-offset branch), 0: x
+    bool any_valid = false, shared = p.pk == p.k + 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        px[q] = 2 * bxi + (q & 1) - 1; // wraps to 0xFFFFFFFF for bxi == 0, q even: rejected below
+        py[q] = 2 * byi + (q >> 1) - 1;
+        valid[q] = false;
+        cend[q] = 0;
+        axis[q] = 0;
+        const uint32_t x = px[q], y = py[q];
+        if (x >= p.w1 || y >= p.row1 || y < p.row0 || y >= p.h1) continue;
+        const bool interior = x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
+        if (!interior) continue;
         const float2 st1 = stats1[(size_t)y * p.w1 + x];
-        if (finite_f32(st1.y) && !(fabsf(st1.y) < p.min_stdev)) { // mod.rs:334 (same outcome, skipped early)
-            const Line e = epipolar_line(p, x, y);
-            if (line_finite(e)) {
-                const uint32_t corridor_start = KERNEL_SIZE;
-                const uint32_t corridor_end = corridor_end_of(p, e);
-                uint32_t xs0, xs1, ys0, ys1;
-                neighbor_window(p, x, y, xs0, xs1, ys0, ys1);
-                // axis of corridor_pos: y for the (1, 0)-offset branch, x otherwise (see header)
-                const uint32_t ash = e.ox == 1 ? 16u : 0u;
-                const uint32_t up = p.pk - p.k; // corridor_pos = coordinate << up, an integer
-                auto cell_at = [&](uint32_t xx, uint32_t yy) -> uint32_t {
-                    return staged ? cells[(yy - ty0) * SR_TILE_W + (xx - tx0)] : prev[(size_t)yy * p.pw + xx].x;
-                };
-                // A window never spans more than SR_WIN cells per axis for consecutive levels
-                // ((20 << k) >> pk) + 1 <= 11); the unrolled, predicated form below keeps all LDS offsets
-                // immediate and has no per-cell loop control.  Scan order is still row-major.
-                unsigned long long isum = 0;
-                uint32_t neighbor_count = 0;
-                const bool small = staged && xs1 - xs0 <= (uint32_t)SR_WIN && xs1 > xs0;
-                double range_stdev = 0.0;
-                double mid_corridor = 0.0;
-                if (small) {
-                    const uint32_t nx = xs1 - xs0;
-                    for (uint32_t yy = ys0; yy < ys1; yy++) {
-                        const uint32_t *row = &cells[(yy - ty0) * SR_TILE_W + (xs0 - tx0)];
+        if (!(finite_f32(st1.y) && !(fabsf(st1.y) < p.min_stdev))) continue; // mod.rs:334 (same outcome)
+        const Line e = epipolar_line(p, x, y);
+        if (!line_finite(e)) continue;
+        valid[q] = true;
+        cend[q] = corridor_end_of(p, e);
+        axis[q] = e.ox == 1 ? 1 : 0;
+        any_valid = true;
+    }
+
+    // neighbour statistics per corridor axis; res[a] = {center, length} or invalid
+    bool have[2] = {false, false};
+    uint32_t center[2] = {0, 0}, length[2] = {0, 0};
+    auto block_stats = [&](uint32_t x, uint32_t y, int a) {
+        uint32_t xs0, xs1, ys0, ys1;
+        neighbor_window(p, x, y, xs0, xs1, ys0, ys1);
+        const uint32_t ash = a ? 16u : 0u;
+        const uint32_t up = p.pk - p.k; // corridor_pos = coordinate << up, an integer
+        auto cell_at = [&](uint32_t xx, uint32_t yy) -> uint32_t {
+            return staged ? cells[(yy - ty0) * SR_TILE_W + (xx - tx0)] : prev[(size_t)yy * p.pw + xx].x;
+        };
+        unsigned long long isum = 0;
+        uint32_t neighbor_count = 0;
+        double range_stdev = 0.0, mid_corridor = 0.0;
+        const bool small = staged && xs1 - xs0 <= (uint32_t)SR_WIN && xs1 > xs0;
+        if (small) {
+            // unrolled, predicated rows: all LDS offsets immediate, no per-cell loop control; still row-major
+            const uint32_t nx = xs1 - xs0;
+            for (uint32_t yy = ys0; yy < ys1; yy++) {
+                const uint32_t *row = &cells[(yy - ty0) * SR_TILE_W + (xs0 - tx0)];
 #pragma unroll
-                        for (uint32_t j = 0; j < (uint32_t)SR_WIN; j++) {
-                            const uint32_t cell = row[j];
-                            const bool ok = j < nx && cell != CELL_NONE;
-                            neighbor_count += ok ? 1u : 0u;
-                            isum += ok ? (unsigned long long)(((cell >> ash) & 0xFFFFu) << up) : 0ull;
-                        }
-                    }
-                    if (neighbor_count != 0) {
-                        mid_corridor = (double)isum / (double)neighbor_count; // exact sum, one rounding
-                        for (uint32_t yy = ys0; yy < ys1; yy++) {
-                            const uint32_t *row = &cells[(yy - ty0) * SR_TILE_W + (xs0 - tx0)];
-#pragma unroll
-                            for (uint32_t j = 0; j < (uint32_t)SR_WIN; j++) {
-                                const uint32_t cell = row[j];
-                                const bool ok = j < nx && cell != CELL_NONE;
-                                const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
-                                const double next = range_stdev + delta * delta;
-                                range_stdev = ok ? next : range_stdev;
-                            }
-                        }
-                    }
-                } else {
-                    for (uint32_t yy = ys0; yy < ys1; yy++) {
-                        for (uint32_t xx = xs0; xx < xs1; xx++) {
-                            const uint32_t cell = cell_at(xx, yy);
-                            if (cell == CELL_NONE) continue;
-                            neighbor_count += 1;
-                            isum += (unsigned long long)(((cell >> ash) & 0xFFFFu) << up);
-                        }
-                    }
-                    if (neighbor_count != 0) {
-                        mid_corridor = (double)isum / (double)neighbor_count;
-                        for (uint32_t yy = ys0; yy < ys1; yy++) {
-                            for (uint32_t xx = xs0; xx < xs1; xx++) {
-                                const uint32_t cell = cell_at(xx, yy);
-                                if (cell == CELL_NONE) continue;
-                                const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
-                                range_stdev += delta * delta;
-                            }
-                        }
-                    }
-                }
-                if (neighbor_count != 0) {
-                    range_stdev = sqrt(range_stdev / (double)neighbor_count);
-                    const uint32_t center = f64_to_u32_sat(round(mid_corridor));
-                    const uint32_t length = f64_to_u32_sat(round(p.min_range + range_stdev * p.extend_range));
-                    uint32_t s0 = sat_sub_u32(center, length);
-                    s0 = s0 < corridor_start ? corridor_start : (s0 > corridor_end ? corridor_end : s0);
-                    const uint64_t s1w = (uint64_t)center + (uint64_t)length; // saturating_add
-                    uint32_t s1 = s1w > (uint64_t)corridor_end ? corridor_end : (uint32_t)s1w;
-                    s1 = s1 < s0 ? s0 : s1;
-                    out = s0 | (s1 << 16);
+                for (uint32_t j = 0; j < (uint32_t)SR_WIN; j++) {
+                    const uint32_t cell = row[j];
+                    const bool ok = j < nx && cell != CELL_NONE;
+                    neighbor_count += ok ? 1u : 0u;
+                    isum += ok ? (unsigned long long)(((cell >> ash) & 0xFFFFu) << up) : 0ull;
                 }
             }
+            if (neighbor_count != 0) {
+                mid_corridor = (double)isum / (double)neighbor_count; // exact sum, one rounding
+                for (uint32_t yy = ys0; yy < ys1; yy++) {
+                    const uint32_t *row = &cells[(yy - ty0) * SR_TILE_W + (xs0 - tx0)];
+#pragma unroll
+                    for (uint32_t j = 0; j < (uint32_t)SR_WIN; j++) {
+                        const uint32_t cell = row[j];
+                        const bool ok = j < nx && cell != CELL_NONE;
+                        const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
+                        const double next = range_stdev + delta * delta;
+                        range_stdev = ok ? next : range_stdev;
+                    }
+                }
+            }
+        } else {
+            for (uint32_t yy = ys0; yy < ys1; yy++)
+                for (uint32_t xx = xs0; xx < xs1; xx++) {
+                    const uint32_t cell = cell_at(xx, yy);
+                    if (cell == CELL_NONE) continue;
+                    neighbor_count += 1;
+                    isum += (unsigned long long)(((cell >> ash) & 0xFFFFu) << up);
+                }
+            if (neighbor_count != 0) {
+                mid_corridor = (double)isum / (double)neighbor_count;
+                for (uint32_t yy = ys0; yy < ys1; yy++)
+                    for (uint32_t xx = xs0; xx < xs1; xx++) {
+                        const uint32_t cell = cell_at(xx, yy);
+                        if (cell == CELL_NONE) continue;
+                        const double delta = (double)(((cell >> ash) & 0xFFFFu) << up) - mid_corridor;
+                        range_stdev += delta * delta;
+                    }
+            }
+        }
+        have[a] = neighbor_count != 0;
+        if (have[a]) {
+            range_stdev = sqrt(range_stdev / (double)neighbor_count);
+            center[a] = f64_to_u32_sat(round(mid_corridor));
+            length[a] = f64_to_u32_sat(round(p.min_range + range_stdev * p.extend_range));
+        }
+    };
+    auto finish = [&](int q, int a) -> uint32_t { // mod.rs:530-539 for pixel q with axis a's statistics
+        if (!have[a]) return RANGE_NONE;
+        const uint32_t corridor_start = KERNEL_SIZE, corridor_end = cend[q];
+        uint32_t s0 = sat_sub_u32(center[a], length[a]);
+        s0 = s0 < corridor_start ? corridor_start : (s0 > corridor_end ? corridor_end : s0);
+        const uint64_t s1w = (uint64_t)center[a] + (uint64_t)length[a]; // saturating_add
+        uint32_t s1 = s1w > (uint64_t)corridor_end ? corridor_end : (uint32_t)s1w;
+        s1 = s1 < s0 ? s0 : s1;
+        return s0 | (s1 << 16);
+    };
+
+    uint32_t out[4] = {RANGE_NONE, RANGE_NONE, RANGE_NONE, RANGE_NONE};
+    if (any_valid) {
+        if (shared) {
+            // one scan per axis in use, on behalf of all valid pixels of the block
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                int rep = -1;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (valid[q] && axis[q] == a && rep < 0) rep = q;
+                if (rep >= 0) {
+                    const uint32_t rx = rep == 0 ? px[0] : (rep == 1 ? px[1] : (rep == 2 ? px[2] : px[3]));
+                    const uint32_t ry = rep == 0 ? py[0] : (rep == 1 ? py[1] : (rep == 2 ? py[2] : py[3]));
+                    block_stats(rx, ry, a);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (valid[q]) out[q] = finish(q, axis[q]);
+        } else {
+            // non-consecutive levels: windows differ inside the block, every pixel scans for itself
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (valid[q]) {
+                    block_stats(px[q], py[q], axis[q]);
+                    out[q] = finish(q, axis[q]);
+                }
         }
     }
-    range[(size_t)y * p.w1 + x] = out;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t x = px[q], y = py[q];
+        if (x < p.w1 && y >= p.row0 && y < p.row1 && y < p.h1) range[(size_t)y * p.w1 + x] = out[q];
+    }
 }
 
 void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
                          hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
-    dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
+    // blocks by = row0/2 .. row1/2 cover pixel rows 2by-1, 2by; bx = 0 .. w1/2 cover columns 2bx-1, 2bx
+    const uint32_t nby = (p.row1 >> 1) - (p.row0 >> 1) + 1, nbx = (p.w1 >> 1) + 1;
+    dim3 grid((nbx + 63) / 64, (nby + 3) / 4);
     hipLaunchKernelGGL(search_range_kernel, grid, dim3(256), 0, s, p, stats1, prev, range);
 }
 
