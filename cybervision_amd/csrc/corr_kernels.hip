@@ -110,23 +110,45 @@ __device__ __forceinline__ uint32_t corridor_end_of(const CorrParams &p, const L
 // search2_kernel needs per candidate in one 8-byte word (avg = (float)s / 121 exactly, see above).
 // VALID mirrors the reference's per-candidate test "stdev finite and >= min_stdev" (mod.rs:439)
 // evaluated on the reference's own f32 stdev.
+constexpr int WS_PITCH = 88; // bytes per staged row: 64 + 2*5 window columns, dword aligned start, padded
+
 __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
                                                             uint32_t row0, uint32_t row1, float min_stdev,
                                                             float2 *__restrict__ stats, uint2 *__restrict__ istats)
 {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    // The 64x4 tile's 74x14 source bytes are staged once in LDS (one dword load per thread instead of 33
+    // unaligned loads per pixel, which made the kernel address-unit-bound); each lane then reads its 12
+    // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.
+    __shared__ uint32_t tile[14 * (WS_PITCH / 4)];
+    const uint32_t x0 = blockIdx.x * 64, y0 = row0 + blockIdx.y * 4;
+    const int sx = (int)x0 - 8, sy = (int)y0 - KERNEL_SIZE; // staged origin; sx is 0 mod 4 relative to x0
+    for (uint32_t u = threadIdx.x; u < 14u * (WS_PITCH / 4); u += 256) {
+        const uint32_t r = u / (WS_PITCH / 4), c4 = (u - r * (WS_PITCH / 4)) * 4;
+        const int gy = sy + (int)r, gx = sx + (int)c4;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < (int)h && gx >= 0 && gx < (int)w) // bytes past the row end are never used
+            __builtin_memcpy(&v, img + (size_t)gy * w + gx, 4);
+        tile[u] = v;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t x = x0 + lane, y = y0 + wv;
     if (x >= w || y >= row1) return;
     const float nan = __builtin_nanf("");
     float2 out = make_float2(nan, nan);
     uint2 iout = make_uint2(0u, 0u);
     if (x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < w && y + KERNEL_SIZE < h) {
-        const uint8_t *base = img + (size_t)(y - KERNEL_SIZE) * w + (x - KERNEL_SIZE);
+        const uint32_t off = lane + 3u; // window starts at byte (x - 5) - (x0 - 8) of the staged row
+        const uint32_t d0 = off >> 2, sh = off & 3u;
         uint32_t isum = 0;
         Row12 rows[KERNEL_WIDTH];
 #pragma unroll
         for (int r = 0; r < KERNEL_WIDTH; r++) {
-            rows[r] = load_row12(base + (size_t)r * w);
+            const uint32_t *src = &tile[(wv + r) * (WS_PITCH / 4) + d0];
+            const uint32_t q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+            rows[r].a = __builtin_amdgcn_alignbyte(q1, q0, sh);
+            rows[r].b = __builtin_amdgcn_alignbyte(q2, q1, sh);
+            rows[r].c = __builtin_amdgcn_alignbyte(q3, q2, sh);
             isum += __builtin_amdgcn_udot4(rows[r].a, 0x01010101u, 0u, false);
             isum += __builtin_amdgcn_udot4(rows[r].b, 0x01010101u, 0u, false);
             isum += __builtin_amdgcn_udot4(rows[r].c, 0x00010101u, 0u, false);
@@ -137,8 +159,8 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
         for (int r = 0; r < KERNEL_WIDTH; r++) {
 #pragma unroll
             for (int c = 0; c < KERNEL_WIDTH; c++) {
-                const uint32_t wv = c < 4 ? rows[r].a : (c < 8 ? rows[r].b : rows[r].c);
-                const float delta = byte_f32(wv, c & 3) - avg;
+                const uint32_t wvv = c < 4 ? rows[r].a : (c < 8 ? rows[r].b : rows[r].c);
+                const float delta = byte_f32(wvv, c & 3) - avg;
                 sd += delta * delta;
             }
         }
