@@ -550,6 +550,7 @@ constexpr float S2_DELTA = 2.5e-5f;     // >= 393 * 2^-24 (see above)
 //   bits [0, 60): up to four 15-bit candidate codes (stripe index << 11 | i - r0), oldest first
 //   bits [60, 63): count 0..4; CW_WHOLE = re-evaluate the whole corridor exactly
 constexpr unsigned long long CW_WHOLE = 5ull;
+constexpr unsigned long long CW_FALLBACK = 6ull; // search3_box_kernel -> search2_filter_kernel(only_fallback)
 constexpr uint32_t CW_MAX_LEN = 2048u;  // i - r0 must fit in 11 bits
 constexpr uint32_t S2_FIXED_PITCH = 128u;
 
@@ -607,7 +608,8 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
                                                                  const uint32_t *__restrict__ range,
                                                                  unsigned long long *__restrict__ contenders,
                                                                  uint2 *__restrict__ out,
-                                                                 unsigned long long *__restrict__ counters)
+                                                                 unsigned long long *__restrict__ counters,
+                                                                 int only_fallback)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[S2_LDS_BYTES];
     __shared__ int bb[4]; // min x, min y, max x, max y of in-bounds candidate centres
@@ -628,7 +630,14 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
     ps.e.cx = ps.e.cy = ps.e.ax = ps.e.ay = 0.0;
     ps.e.ox = ps.e.oy = 0;
     ps.r0 = ps.r1 = 0;
-    const bool active = in_image && pixel_setup(p, x, y, stats1, range, ps);
+    // only_fallback: second stage behind search3_box_kernel, which left the pixels it could not walk as a box
+    // marked CW_FALLBACK; everything else is already settled and must not be touched
+    bool mine = in_image;
+    if (only_fallback) {
+        mine = in_image && (uint32_t)(contenders[(size_t)y * p.w1 + x] >> 60) == (uint32_t)CW_FALLBACK;
+        if (!__syncthreads_or(mine ? 1 : 0)) return;
+    }
+    const bool active = mine && pixel_setup(p, x, y, stats1, range, ps);
     const Line &e = ps.e;
     const uint32_t r0 = ps.r0, r1 = ps.r1;
     const uint32_t len = active ? r1 - r0 : 0u;
@@ -914,12 +923,433 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
             if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
         }
     }
-    if (in_image) {
+    if (mine) {
         contenders[(size_t)y * p.w1 + x] = word;
         if (!whole) out[(size_t)y * p.w1 + x] = cell;
     }
     if (counters) {
         uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = whole;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            v0 += __shfl_down(v0, sft, 64);
+            v1 += __shfl_down(v1, sft, 64);
+            v2 += __shfl_down(v2, sft, 64);
+            v3 += __shfl_down(v3, sft, 64);
+        }
+        if (lane == 0) {
+            if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
+            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
+            if (v2) atomicAdd(&counters[2], (unsigned long long)v2);
+            if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
+        }
+    }
+}
+
+// ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
+//
+// Same decision rule and the same exact integer N as search2_filter_kernel, but S12 is no longer a 121-term
+// dot product per (pixel, candidate).  For a displacement (dx, dy) shared by a whole row segment,
+//     S12(x; dx, dy) = sum_{c = x-5}^{x+5} C(c; dx, dy),   C(c; dx, dy) = sum_{j=-5}^{5} img1(c, y+j) * img2(c+dx, y+dy+j)
+// i.e. an 11-tap horizontal box sum of per-column products.  One lane owns one image column: C is 3-4
+// v_dot4_u32_u8 of column-packed bytes, the box sum is a wave-wide prefix sum (6 DPP adds) and
+// P(l) - P(l-11) (one ds_bpermute): ~16 VALU + 3 LDS operations per (pixel, displacement) instead of 33 dot4 +
+// ~30 VALU + 12 LDS.  A wave walks the bounding box of its pixels' displacement sets; a pixel records only the
+// displacements that are candidates of its own corridor (mod.rs:411-429), so the contender set is the same
+// superset-of-the-band as before, and the exact re-evaluation below decides exactly as the reference does.
+//
+// The box walk needs every pixel's candidate set to be a rectangle of displacements: all 2*cs+1 stripes keep
+// their minor coordinate over the pixel's interval (rectified pairs: always; tilted epipolar lines: only where
+// the line does not step inside the interval).  A workgroup where that fails, or whose box is much larger
+// than its pixels' own sets (disparity discontinuities, the first pass), taller than 9 rows or wider than 61
+// columns, marks its pixels CW_FALLBACK and search2_filter_kernel (only_fallback = 1) walks them candidate
+// by candidate.
+//
+// Layout: lane l <-> image column X0 - 6 + l, and lanes 11..63 also own the searched pixel whose window ENDS
+// in that column (x = X0 - 11 + l), so S12 = P(l) - P(l - 11).  The target image is staged TRANSPOSED, once per
+// wave row: copy w holds, for every column, the 20 bytes of rows Y0 + w + dy0 - 5 ... as 5 dwords (one
+// ds_read_b128 + one ds_read_b32 per lane and dx serve all <= 9 dy planes); plane s = dy - dy0 multiplies them
+// with the searched column pre-shifted by s & 3 bytes (a[s & 3][k] against dword (s >> 2) + k).
+constexpr int S3_LANE0 = 11;
+constexpr int S3_OUT = 53;
+constexpr int S3_COLS = 128;  // staged columns per copy / per statistics row
+constexpr int S3_MAXH = 9;    // dy planes: 20 staged rows = 9 + 10 window rows (+1)
+constexpr int S3_B16_OFF = 0;                             // [4][128] uint4: rows 0..15 of the copy
+constexpr int S3_B4_OFF = 4 * S3_COLS * 16;               // [4][128] u32:   rows 16..19
+constexpr int S3_IS_OFF = S3_B4_OFF + 4 * S3_COLS * 4;    // [12][128] uint2: candidate statistics
+constexpr int S3_LDS_BYTES = S3_IS_OFF + (S3_MAXH + 3) * S3_COLS * 8;
+
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t v)
+{
+    // inclusive prefix sum over the 64 lanes: Kogge-Stone inside each row of 16 (row_shr 1, 2, 4, 8; lanes
+    // shifted in from outside the row read 0), then the row totals (row_bcast:15 -> rows 1 and 3, row_bcast:31
+    // -> rows 2 and 3).  EXEC must be all ones.
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+// wave-wide min / max with the same DPP pattern (lane 63 ends up with the total); EXEC all ones
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    const int id = 0x7FFFFFFF;
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x111, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x112, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x114, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x118, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x142, 0xA, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
+
+__device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict__ img, int w, int h, int row, int col)
+{
+    uint32_t v = 0;
+    if (row < 0 || row >= h) return 0u;
+    const uint8_t *p = img + (size_t)row * (size_t)w;
+    if (col >= 0 && col + 3 < w) {
+        __builtin_memcpy(&v, p + col, 4);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (col + b >= 0 && col + b < w) v |= (uint32_t)p[col + b] << (8 * b);
+    }
+    return v;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                           const uint8_t *__restrict__ img2,
+                                                           const float2 *__restrict__ stats1,
+                                                           const uint2 *__restrict__ istats1,
+                                                           const uint2 *__restrict__ istats2,
+                                                           const uint32_t *__restrict__ range,
+                                                           unsigned long long *__restrict__ contenders,
+                                                           uint2 *__restrict__ out,
+                                                           unsigned long long *__restrict__ counters)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[S3_LDS_BYTES];
+    __shared__ int bb[6]; // min dx, min dy, max dx, max dy, max candidates of one pixel, 1 = some pixel is not a rectangle
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int X0 = (int)blockIdx.x * S3_OUT;
+    const int xc = X0 - 6 + (int)lane;        // image column of this lane
+    const int xi = X0 - S3_LANE0 + (int)lane; // searched pixel of this lane (its window ends in column xc)
+    const uint32_t Y0 = p.row0 + blockIdx.y * 4;
+    const uint32_t y = Y0 + w;
+    const bool is_out = lane >= (uint32_t)S3_LANE0 && xi < (int)p.w1 && y < p.row1;
+    const uint32_t x = (uint32_t)xi;
+    if (threadIdx.x == 0) {
+        bb[0] = 0x7FFFFFFF;
+        bb[1] = 0x7FFFFFFF;
+        bb[2] = -0x7FFFFFFF;
+        bb[3] = -0x7FFFFFFF;
+        bb[4] = 0;
+        bb[5] = 0;
+    }
+
+    PixelSetup ps;
+    ps.st1 = make_float2(0.0f, 1.0f);
+    ps.e.cx = ps.e.cy = ps.e.ax = ps.e.ay = 0.0;
+    ps.e.ox = ps.e.oy = 0;
+    ps.r0 = ps.r1 = 0;
+    const bool active = is_out && pixel_setup(p, x, y, stats1, range, ps);
+    const Line &e = ps.e;
+    const uint32_t r0 = ps.r0, r1 = ps.r1;
+    const int cs = p.corridor_size;
+    const bool major_x = e.ox == 0; // candidates advance along x (x2 == i exactly), stripes shift y
+
+    // ---- this pixel's candidate set as a rectangle of displacements [lox, lox+wx) x [loy, loy+wy) ----------
+    bool simple = true;
+    int lox = 0, loy = 0;
+    uint32_t wx = 0, wy = 0;
+    if (active) {
+        uint32_t m0 = 0;
+        for (int off = -cs; off <= cs; off++) {
+            const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
+            const uint32_t mf = major_x ? cf.y : cf.x, ml = major_x ? cl.y : cl.x;
+            if (off == -cs) m0 = mf;
+            simple = simple && mf == ml && mf == m0 + (uint32_t)(off + cs);
+        }
+        const uint32_t lim2 = major_x ? p.w2 : p.h2;
+        const uint32_t ilo = max(r0, (uint32_t)KERNEL_SIZE), ihi = min(r1, sat_sub_u32(lim2, KERNEL_SIZE));
+        const uint32_t nmaj = ihi > ilo ? ihi - ilo : 0u;
+        simple = simple && (r1 - r0) <= CW_MAX_LEN && m0 < 0x40000000u && ilo < 0x40000000u;
+        if (major_x) {
+            lox = (int)ilo - xi;
+            wx = nmaj;
+            loy = (int)m0 - (int)y;
+            wy = (uint32_t)(2 * cs + 1);
+        } else {
+            loy = (int)ilo - (int)y;
+            wy = nmaj;
+            lox = (int)m0 - xi;
+            wx = (uint32_t)(2 * cs + 1);
+        }
+    }
+    const bool has = active && simple && wx > 0u && wy > 0u;
+    // wave-uniform bounds of the wave's displacement box
+    const int mnx = wave_min_i32(has ? lox : 0x7FFFFFFF), mny = wave_min_i32(has ? loy : 0x7FFFFFFF);
+    const int mxx = wave_max_i32(has ? lox + (int)wx - 1 : -0x7FFFFFFF), mxy = wave_max_i32(has ? loy + (int)wy - 1 : -0x7FFFFFFF);
+    const int need = wave_max_i32(has ? (int)min(wx * wy, 0x3FFFFFFFu) : 0);
+    const bool wave_has = mxx >= mnx;
+    const bool wave_odd = __any(active && !simple);
+    __syncthreads(); // bb initialised
+    if (lane == 0) {
+        if (wave_has) {
+            atomicMin(&bb[0], mnx);
+            atomicMin(&bb[1], mny);
+            atomicMax(&bb[2], mxx);
+            atomicMax(&bb[3], mxy);
+            atomicMax(&bb[4], need);
+        }
+        if (wave_odd) atomicOr(&bb[5], 1);
+    }
+    __syncthreads();
+    const size_t pix = (size_t)y * p.w1 + x;
+    const bool any_has = bb[2] >= bb[0];
+    const int dx0 = bb[0], dy0 = bb[1];
+    const int W = bb[2] - bb[0] + 1, H = bb[3] - bb[1] + 1;
+    const int C0 = X0 - 6 + dx0; // target column of lane 0 at dx0
+    const int C0a = C0 & ~3;
+    const int colshift = C0 - C0a;
+    const int ncol = colshift + 64 + W - 1;
+    bool eligible = !bb[5] && !(p.debug & 4);
+    if (any_has) eligible = eligible && ncol <= S3_COLS && H <= S3_MAXH && (long long)W * H <= 3ll * bb[4] + 16;
+    if (!eligible || !any_has) {
+        // nothing to search (every pixel None), or left to the candidate-by-candidate kernel
+        if (is_out) {
+            const bool fb = active && !eligible;
+            contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
+            if (!fb) out[pix] = make_uint2(CELL_NONE, 0x7FC00000u);
+        }
+        return;
+    }
+    const int NPL = H > 5 ? S3_MAXH : 5; // planes computed (group A: 0..4, group B: 5..8)
+
+    // ---- stage the transposed target copies and the candidate statistics -----------------------------------
+    {
+        const int R0 = (int)Y0 + dy0 - KERNEL_SIZE;
+        const int nb = (ncol + 3) >> 2;
+        const int units = 4 * 5 * nb;
+        for (int u = (int)threadIdx.x; u < units; u += 256) {
+            const int wk = u / nb, b = u - wk * nb; // wk = copy * 5 + k
+            const int cw = wk / 5, k = wk - cw * 5;
+            const int rr = R0 + cw + 4 * k, col = C0a + 4 * b;
+            const uint32_t d0 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 0, col);
+            const uint32_t d1 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 1, col);
+            const uint32_t d2 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 2, col);
+            const uint32_t d3 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 3, col);
+            uint4 t; // 4x4 byte transpose: t.c = rows rr..rr+3 of column col + c
+            t.x = (d0 & 0xFFu) | ((d1 & 0xFFu) << 8) | ((d2 & 0xFFu) << 16) | (d3 << 24);
+            t.y = ((d0 >> 8) & 0xFFu) | (d1 & 0xFF00u) | ((d2 & 0xFF00u) << 8) | ((d3 & 0xFF00u) << 16);
+            t.z = ((d0 >> 16) & 0xFFu) | ((d1 >> 8) & 0xFF00u) | (d2 & 0xFF0000u) | ((d3 & 0xFF0000u) << 8);
+            t.w = (d0 >> 24) | ((d1 >> 16) & 0xFF00u) | ((d2 >> 8) & 0xFF0000u) | (d3 & 0xFF000000u);
+            if (k < 4) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(lds + S3_B16_OFF + (size_t)(cw * S3_COLS + 4 * b) * 16u) + k;
+                dst[0] = t.x;
+                dst[4] = t.y;
+                dst[8] = t.z;
+                dst[12] = t.w;
+            } else {
+                *reinterpret_cast<uint4 *>(lds + S3_B4_OFF + (size_t)(cw * S3_COLS + 4 * b) * 4u) = t;
+            }
+        }
+        const int isp = 64 + W - 1, isrows = NPL + 3;
+        const int gx0 = X0 - S3_LANE0 + dx0; // target column of lane 0's pixel at dx0
+        for (int u = (int)threadIdx.x; u < isp * isrows; u += 256) {
+            const int r = u / isp, c = u - r * isp;
+            const int gy = (int)Y0 + dy0 + r, gx = gx0 + c;
+            // {window sum, f32 stdev}; centres outside the image or skipped by the reference (stdev non-finite or
+            // < min_stdev, mod.rs:430-441) get stdev = +inf: their acceptance threshold can never be reached
+            uint2 v = make_uint2(0u, 0x7F800000u);
+            if (gy >= 0 && gy < (int)p.h2 && gx >= 0 && gx < (int)p.w2) {
+                const uint2 tt = istats2[(size_t)gy * p.w2 + (size_t)gx];
+                if (tt.x & 0x80000000u) v = make_uint2(tt.x & 0x7FFFFFFFu, tt.y);
+            }
+            *reinterpret_cast<uint2 *>(lds + S3_IS_OFF + (size_t)(r * S3_COLS + c) * 8u) = v;
+        }
+    }
+    // this lane's searched column, rows y-5 .. y+5, packed and pre-shifted by 0..3 bytes
+    uint32_t a[4][4];
+    {
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+        if (xc >= 0 && xc < (int)p.w1 && y >= (uint32_t)KERNEL_SIZE && y + KERNEL_SIZE < p.h1) {
+            const uint8_t *pc = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (size_t)xc;
+            uint32_t b[KERNEL_WIDTH];
+#pragma unroll
+            for (int r = 0; r < KERNEL_WIDTH; r++) b[r] = pc[(size_t)r * p.w1];
+            a0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            a1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            a2 = b[8] | (b[9] << 8) | (b[10] << 16);
+        }
+        a[0][0] = a0;
+        a[0][1] = a1;
+        a[0][2] = a2;
+        a[0][3] = 0u;
+#pragma unroll
+        for (int q = 1; q < 4; q++) { // 128-bit left shift by q bytes
+            a[q][0] = a0 << (8 * q);
+            a[q][1] = __builtin_amdgcn_alignbyte(a1, a0, 4 - q);
+            a[q][2] = __builtin_amdgcn_alignbyte(a2, a1, 4 - q);
+            a[q][3] = __builtin_amdgcn_alignbyte(0u, a2, 4 - q);
+        }
+    }
+    const uint32_t s1 = has ? (istats1[pix].x & 0x7FFFFFFFu) : 0u;
+    const float k1 = ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT); // 121*121*sd1
+    const float c1 = 1.0f / k1;
+    __syncthreads();
+
+    unsigned long long word = 0ull;
+    uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
+    uint32_t evaluated = 0, multi = 0, whole = 0, exact_evals = 0;
+    float runmax = -__builtin_inff();
+    const float thr_lo = p.threshold - S2_DELTA;
+    unsigned long long clist = 0ull;
+    uint32_t count = 0;
+    // acceptance band in the integer domain, as in search2_filter_kernel; lanes without candidates never pass
+    float limk = has ? thr_lo * k1 * (1.0f - 9.5367431640625e-7f) : __builtin_inff();
+    auto score = [&](int num, float sd2) -> float { return (float)num * (c1 * __builtin_amdgcn_rcpf(sd2)); };
+    auto record = [&](float g, uint32_t code) {
+        const float lim = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo);
+        if (g >= lim) {
+            if (g > runmax + 2.0f * S2_DELTA) { // everything recorded so far is out of the band
+                count = 0;
+                clist = 0ull;
+            }
+            runmax = fmaxf(runmax, g);
+            limk = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo) * k1 * (1.0f - 9.5367431640625e-7f);
+            if (count < (uint32_t)S2_K) clist |= (unsigned long long)code << (15u * count);
+            count = min(count + 1u, (uint32_t)S2_K + 1u);
+        }
+    };
+
+    if (wave_has && !(p.debug & 8)) {
+        const uint32_t col0 = lane + (uint32_t)colshift + (uint32_t)(mnx - dx0);
+        const uint8_t *pB16 = lds + S3_B16_OFF + (w * S3_COLS + col0) * 16u;
+        const uint8_t *pB4 = lds + S3_B4_OFF + (w * S3_COLS + col0) * 4u;
+        const uint8_t *pIS = lds + S3_IS_OFF + (w * S3_COLS + lane + (uint32_t)(mnx - dx0)) * 8u;
+        const int idx_lo = (int)(lane >= 11u ? lane - 11u : 0u) * 4;
+        const int nsteps = mxx - mnx + 1;
+        for (int step = 0; step < nsteps; step++, pB16 += 16, pB4 += 4, pIS += 8) {
+            const int dx = mnx + step;
+            const bool mx = has && (uint32_t)(dx - lox) < wx;
+            const uint4 r4 = *reinterpret_cast<const uint4 *>(pB16);
+            uint32_t raw[5] = {r4.x, r4.y, r4.z, r4.w, *reinterpret_cast<const uint32_t *>(pB4)};
+            // one group of planes: s = S0 .. S0 + N - 1 (dy = dy0 + s), all independent until the rare branch
+            auto group = [&](auto s0_tag, auto n_tag) {
+                constexpr int S0 = decltype(s0_tag)::value, N = decltype(n_tag)::value;
+                int num[N];
+                float sd[N];
+#pragma unroll
+                for (int q = 0; q < N; q++) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int s = S0 + q, sh = s & 3, o = s >> 2;
+                    const uint2 is2 = *reinterpret_cast<const uint2 *>(pIS + s * (S3_COLS * 8));
+                    uint32_t c = __builtin_amdgcn_udot4(a[sh][0], raw[o], 0u, false);
+                    c = __builtin_amdgcn_udot4(a[sh][1], raw[o + 1], c, false);
+                    c = __builtin_amdgcn_udot4(a[sh][2], raw[o + 2], c, false);
+                    if (sh >= 2) c = __builtin_amdgcn_udot4(a[sh][3], raw[o + 3 < 5 ? o + 3 : 4], c, false);
+                    const uint32_t pre = wave_prefix_sum(c);
+                    const uint32_t s12 = pre - (uint32_t)__builtin_amdgcn_ds_bpermute(idx_lo, (int)pre);
+                    num[q] = (int)__umul24(s12, (uint32_t)KERNEL_POINT_COUNT) - (int)__umul24(s1, is2.x);
+                    sd[q] = __uint_as_float(is2.y);
+                }
+                // one rarely taken branch for the group: the largest margin (float)N - limk*sd2 decides.  The fused
+                // multiply-add only pre-screens (limk is shaved by 2^-20); a hit is re-tested below.
+                float margin = __builtin_fmaf(-limk, sd[0], (float)num[0]);
+#pragma unroll
+                for (int q = 1; q < N; q++) margin = fmaxf(margin, __builtin_fmaf(-limk, sd[q], (float)num[q]));
+                if (COUNT) {
+#pragma unroll
+                    for (int q = 0; q < N; q++)
+                        if (mx && (uint32_t)(dy0 + S0 + q - loy) < wy && sd[q] < __builtin_inff()) evaluated++;
+                }
+                if (margin >= 0.0f) {
+#pragma unroll
+                    for (int q = 0; q < N; q++) {
+                        const int dy = dy0 + S0 + q;
+                        if (mx && (uint32_t)(dy - loy) < wy && sd[q] < __builtin_inff() && (float)num[q] >= limk * sd[q]) {
+                            const uint32_t code = major_x ? ((uint32_t)(dy - loy) << 11) | (uint32_t)(xi + dx - (int)r0)
+                                                          : ((uint32_t)(dx - lox) << 11) | (uint32_t)((int)y + dy - (int)r0);
+                            record(score(num[q], sd[q]), code);
+                        }
+                    }
+                }
+            };
+            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+            if (NPL > 5) group(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+        }
+    }
+
+    if (has) {
+        if (count > (uint32_t)S2_K) {
+            word = CW_WHOLE << 60;
+            whole = 1;
+            evaluated = 0; // the exact kernel walks (and counts) the whole corridor
+        } else if (count > 0u && !(p.debug & 16)) {
+            // ---- exact re-evaluation of the contenders: mod.rs:442-464, the reference's serial f32 chain and
+            // acceptance rule; the list is unordered here, so "first maximum" is the smallest code among equals
+            multi = count > 1 ? 1u : 0u;
+            bool have = false;
+            float bcorr = 0.0f;
+            uint32_t bxy = 0, bcode = 0;
+            const float avg1 = ps.st1.x, sdev1 = ps.st1.y;
+            Row12 ar[KERNEL_WIDTH];
+            {
+                const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
+#pragma unroll
+                for (int r = 0; r < KERNEL_WIDTH; r++) ar[r] = load_row12(base + (size_t)r * p.w1);
+            }
+            for (uint32_t j = 0; j < count; j++) {
+                const uint32_t code = (uint32_t)(clist >> (15u * j)) & 0x7FFFu;
+                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                const uint2 is2 = istats2[(size_t)c.y * p.w2 + c.x];
+                const float avg2 = (float)(is2.x & 0x7FFFFFFFu) / (float)KERNEL_POINT_COUNT; // == compute_point_avg
+                const float sdev2 = __uint_as_float(is2.y);
+                const uint8_t *base2 = img2 + (size_t)(c.y - KERNEL_SIZE) * p.w2 + (c.x - KERNEL_SIZE);
+                float corr = 0.0f;
+#pragma unroll
+                for (int r = 0; r < KERNEL_WIDTH; r++) {
+                    const Row12 br = load_row12(base2 + (size_t)r * p.w2);
+                    Row12 av = ar[r];
+                    asm volatile("" : "+v"(av.a), "+v"(av.b), "+v"(av.c));
+#pragma unroll
+                    for (int cc = 0; cc < KERNEL_WIDTH; cc++) {
+                        const uint32_t wa = cc < 4 ? av.a : (cc < 8 ? av.b : av.c);
+                        const uint32_t wb = cc < 4 ? br.a : (cc < 8 ? br.b : br.c);
+                        const float delta1 = byte_f32(wa, cc & 3) - avg1;
+                        const float delta2 = byte_f32(wb, cc & 3) - avg2;
+                        corr += delta1 * delta2;
+                    }
+                }
+                corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
+                exact_evals++;
+                if (corr >= p.threshold && (!have || corr > bcorr || (corr == bcorr && code < bcode))) { // mod.rs:456-464
+                    have = true;
+                    bcorr = corr;
+                    bcode = code;
+                    bxy = c.x | (c.y << 16);
+                }
+            }
+            if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
+        }
+    }
+    if (is_out) {
+        contenders[pix] = word;
+        if (!whole) out[pix] = cell;
+    }
+    if (counters) {
+        uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = whole;
+        if (p.debug & 32) { // diagnostics: displacements walked per wave, waves that walked
+            v1 = lane == 0 && wave_has ? (uint32_t)((mxx - mnx + 1) * NPL) : 0u;
+            v2 = lane == 0 && wave_has ? 1u : 0u;
+        }
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) {
             v0 += __shfl_down(v0, sft, 64);
@@ -1061,15 +1491,30 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
 
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s)
+                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, int only_fallback,
+                           hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
     if (counters)
         hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters);
+                           range, contenders, out, counters, only_fallback);
     else
         hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
+                           range, contenders, out, counters, only_fallback);
+}
+
+void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                        const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s)
+{
+    if (p.row1 <= p.row0) return;
+    dim3 grid((p.w1 + S3_OUT - 1) / S3_OUT, (p.row1 - p.row0 + 3) / 4);
+    if (counters)
+        hipLaunchKernelGGL(search3_box_kernel<true>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
+                           range, contenders, out, counters);
+    else
+        hipLaunchKernelGGL(search3_box_kernel<false>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
                            range, contenders, out, counters);
 }
 

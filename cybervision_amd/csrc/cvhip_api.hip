@@ -186,8 +186,11 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     } else {
         if (!(p.debug & 2))
             CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
+                if (c->search_version >= 3)
+                    launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
+                                       c->contenders, ds.cells[next], cnt, s);
                 launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                      c->contenders, ds.cells[next], cnt, s);
+                                      c->contenders, ds.cells[next], cnt, c->search_version >= 3 ? 1 : 0, s);
             }));
         if (!(p.debug & 1))
             CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
@@ -359,7 +362,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     c->dir[0].gh = h1;
     c->dir[1].gw = w2;
     c->dir[1].gh = h2;
-    if (const char *v = std::getenv("CVHIP_SEARCH")) c->search_version = (v[0] == '1') ? 1 : 2;
+    if (const char *v = std::getenv("CVHIP_SEARCH")) c->search_version = (v[0] >= '1' && v[0] <= '3') ? v[0] - '0' : 3;
     const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
     c->max_px = std::max(n1, n2);
     // Level grids are gathered in equal row chunks when sharded, so leave room for one padded
@@ -783,7 +786,7 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset)
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
-    if (version != 1 && version != 2) return fail(CVHIP_ERR_INVALID, "search version must be 1 or 2");
+    if (version < 1 || version > 3) return fail(CVHIP_ERR_INVALID, "search version must be 1, 2 or 3");
     ctx->search_version = version;
     return CVHIP_OK;
 }

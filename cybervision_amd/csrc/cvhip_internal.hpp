@@ -54,7 +54,8 @@ struct CorrParams {
     uint32_t k;              // this level's k
     uint32_t row0, row1;     // rows of the searched image handled by this launch
     int first_pass;
-    int debug; // profiling aid (CVHIP_DEBUG): 1 = skip exact phase, 2 = skip filter phase, 4 = skip staging
+    int debug; // profiling aid (CVHIP_DEBUG): 1 = skip exact phase, 2 = skip filter phase, 4 = search version 3 sends every workgroup to the fallback kernel,
+               // 8 / 16 = box kernel skips its walk / its exact phase, 32 = box statistics in counters 1, 2
 };
 
 // ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------
@@ -68,7 +69,10 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                            unsigned long long *contenders, uint2 *out, unsigned long long *counters,
-                           hipStream_t s);
+                           int only_fallback, hipStream_t s);
+void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                        const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s);
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
                           uint2 *out, unsigned long long *counters, hipStream_t s);
@@ -119,7 +123,9 @@ struct cvhip_ctx {
     uint8_t *img[2] = {nullptr, nullptr}; // level image staging (padded), [0]=searched [1]=target of the call
     float2 *stats[2] = {nullptr, nullptr};
     uint2 *istats[2] = {nullptr, nullptr};
-    int search_version = 2; // 1 = per-candidate exact kernel, 2 = integer filter + exact re-evaluation
+    // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,
+    // 3 = displacement-plane box filter (falls back to 2 per workgroup) + exact re-evaluation
+    int search_version = 3;
     uint32_t *range = nullptr;
     unsigned long long *contenders = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
     size_t max_px = 0;

@@ -175,8 +175,10 @@ int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[6], uint32_t launches[6
  * out[3] pixels that re-evaluated their whole corridor exactly (tile too large for LDS, or more
  * than 4 contenders).  Synchronises. */
 int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
-/* Select the search kernel: 1 = every candidate through the exact serial f32 chain, 2 (default) =
- * exact-integer filter + exact re-evaluation of the contenders.  Both give identical results. */
+/* Select the search kernel: 1 = every candidate through the exact serial f32 chain, 2 = exact-integer
+ * filter per candidate + exact re-evaluation of the contenders, 3 (default) = the same filter evaluated
+ * as displacement-plane box sums for whole row segments, with 2 as the per-workgroup fallback.  All
+ * three give identical results. */
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
 
 /* ------------------------------------------------------------------------------------------

@@ -89,6 +89,17 @@ def test_exact_kernel_v1_matches_oracle(gpu_device, oracle, name):
     assert_same_grid(run_gpu(gpu_device, c, version=1), run_oracle(oracle, c), f"{name} v1")
 
 
+@pytest.mark.parametrize("name", cases.CASES)
+def test_candidate_filter_v2_matches_oracle(gpu_device, oracle, name):
+    """Version 2 (the per-candidate integer filter) is the per-workgroup fallback of the default box
+    filter (version 3), so it has to stay exact on its own."""
+    c = cases.make_case(name)
+    got_f, got_r = run_gpu(gpu_device, c, both=True, version=2)
+    want_f, want_r = run_oracle(oracle, c, both=True)
+    assert_same_grid(got_f, want_f, f"{name} v2 forward")
+    assert_same_grid(got_r, want_r, f"{name} v2 reverse")
+
+
 def adversarial_case(kind):
     """Inputs built to stress the filter's decision rule: exact ties (periodic texture: many
     candidates with IDENTICAL scores, the first must win), near-threshold scores and windows whose
@@ -370,8 +381,8 @@ def test_two_rank_sharded_level_calls(case, mode):
         assert p.returncode == 0 and f"rank {rank} ok" in out, out
 
 
-def test_full_size_4096_v2_equals_exact_kernel():
-    """BASELINE's 4096^2 pair: the filter + exact-re-evaluation search (v2) must reproduce, bit for bit,
+def test_full_size_4096_filters_equal_exact_kernel():
+    """BASELINE's 4096^2 pair: the filter + exact-re-evaluation searches (v3 box filter, v2) must reproduce, bit for bit,
     the plain kernel that sends every one of the 3.2e9 candidates through the reference's serial f32
     chain (v1, itself bit-exact against the oracle on every small case) — match coordinates and scores,
     both directions.  Plus the size-independent properties: known disparity recovered, empty border."""
@@ -383,13 +394,16 @@ def test_full_size_4096_v2_equals_exact_kernel():
         steps = synth.optimal_scale_steps(4096, 4096)
         c = dict(img1=a, img2=b, F=synth.F_HORIZONTAL, projection=0, steps=steps)
         cnt = {}
-        (fxy, fc), (rxy, rc) = run_gpu(dev, c, both=True, version=2, counters=cnt)
+        (fxy, fc), (rxy, rc) = run_gpu(dev, c, both=True, version=3, counters=cnt)
+        (fxy2, fc2), (rxy2, rc2) = run_gpu(dev, c, both=True, version=2)
         (fxy1, fc1), (rxy1, rc1) = run_gpu(dev, c, both=True, version=1)
     finally:
         dev.close()
-    assert (fxy == fxy1).all() and (rxy == rxy1).all(), "v2 match coordinates differ from the exact kernel"
+    assert (fxy == fxy1).all() and (rxy == rxy1).all(), "v3 match coordinates differ from the exact kernel"
+    assert (fxy2 == fxy1).all() and (rxy2 == rxy1).all(), "v2 match coordinates differ from the exact kernel"
     vf, vr = fxy1[..., 0] >= 0, rxy1[..., 0] >= 0
-    assert (bits(fc)[vf] == bits(fc1)[vf]).all() and (bits(rc)[vr] == bits(rc1)[vr]).all(), "scores differ"
+    assert (bits(fc)[vf] == bits(fc1)[vf]).all() and (bits(rc)[vr] == bits(rc1)[vr]).all(), "v3 scores differ"
+    assert (bits(fc2)[vf] == bits(fc1)[vf]).all() and (bits(rc2)[vr] == bits(rc1)[vr]).all(), "v2 scores differ"
     assert cnt["candidates"] > 3_000_000_000 and cnt["exact_evals"] < 0.02 * cnt["candidates"]
     assert vf.mean() > 0.8
     assert not vf[:5].any() and not vf[-5:].any() and not vf[:, :5].any() and not vf[:, -5:].any()
