@@ -37,8 +37,11 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DOT4_PEAK_TMACS = 256 * 4 * 64 * 4 / 4 * 2.4e9 / 1e12   # = 157.3 T multiply-adds/s, the filter kernel's roof
 
 
+SEARCH_KERNEL = "search3_box_kernel"   # the kernel class "search" times (search version 3, the default)
+
+
 def algorithmic_work(level_dims, candidates):
-    """Algorithmic bytes / multiply-adds of ALL search2_filter_kernel launches of one step
+    """Algorithmic bytes / multiply-adds of ALL search-kernel launches of one step
     (DESIGN.md §4).  Per (level, direction) pass, each array touched once: searched pixel = img1 u8 (1)
     + stats1 (8) + istats1 (8) + range (4) + contender word written (8) + result cell written (8) = 37 B;
     target pixel = img2 u8 (1) + istats2 (8) = 9 B.  Multiply-adds: 121 per evaluated candidate (the
@@ -52,13 +55,13 @@ def algorithmic_work(level_dims, candidates):
 
 
 def traffic_per_launch(world):
-    """HBM bytes per search2_filter_kernel launch from the rocprofv3 PMC passes of this same command
+    """HBM bytes per search-kernel launch from the rocprofv3 PMC passes of this same command
     (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied: scripts/collect_traffic.py);
     committed under profiles/.  None when no PMC data matches this configuration."""
     f = ROOT / "profiles" / "current_traffic.json"
     if world != 1 or not f.exists():
         return None
-    k = json.loads(f.read_text())["kernels"].get("search2_filter_kernel")
+    k = json.loads(f.read_text())["kernels"].get(SEARCH_KERNEL)
     return round(k["hbm_bytes_per_step"] / k["launches_per_step"]) if k else None
 
 
@@ -199,7 +202,7 @@ def main():
                                       + (f" [EMULATION of shard {sim[0]}/{sim[1]} on one GPU, no collective]" if sim else ""),
                        "candidates_per_step": candidates},
             "roofline": {
-                "kernel": "search2_filter_kernel",
+                "kernel": SEARCH_KERNEL,
                 "bound": "hbm",
                 "achieved": round(ach_gbs, 2),
                 "peak": HBM_PEAK_GBS,
@@ -209,9 +212,11 @@ def main():
                 "launches_per_step": launches_per_step,
                 "avg_launch_ms": round(search_ms_per_step / max(launches_per_step, 1), 4),
                 "algorithmic_bytes_per_step": bytes_alg,
-                "note": "the search is compute-bound by construction (121 multiply-adds per candidate on ~0.5 B of "
-                        "compulsory traffic); `compute` prices it against the v_dot4_u32_u8 issue roof",
-                "compute": {"bound": "valu_dot4_u8", "achieved": round(ach_tmacs, 3),
+                "note": "the search is compute-bound by construction (the reference spends 121 multiply-adds per "
+                        "candidate on ~0.5 B of compulsory traffic); `compute` prices the reference-equivalent "
+                        "multiply-adds against the v_dot4_u32_u8 issue roof - the box filter itself needs ~14 per "
+                        "candidate plus a wave prefix sum, so this is a rate of useful work, not of issued dot4",
+                "compute": {"bound": "valu_dot4_u8", "achieved": round(ach_tmacs, 3),  # reference-equivalent MACs
                             "peak": round(DOT4_PEAK_TMACS, 1), "unit": "T multiply-adds/s",
                             "frac": round(ach_tmacs / DOT4_PEAK_TMACS, 4), "algorithmic_macs_per_step": macs_alg},
             },

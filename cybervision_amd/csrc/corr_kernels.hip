@@ -53,6 +53,43 @@ __device__ __forceinline__ Row12 load_row12(const uint8_t *p)
 }
 __device__ __forceinline__ float byte_f32(uint32_t v, int i) { return (float)((v >> (8 * i)) & 0xFFu); }
 
+// Serial row-major accumulation over one 11-byte window row, exactly as the reference's scalar loops do it
+// (every subtraction, product and addition separately rounded, additions in element order); the independent
+// subtractions and products go through the packed-f32 pipe two at a time (v_pk_add_f32 / v_pk_mul_f32 round
+// each half like the scalar instructions).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t row12_word(const Row12 &r, int c) { return c < 4 ? r.a : (c < 8 ? r.b : r.c); }
+// corr += (a_k - avg1) * (b_k - avg2), k = 0..10   (mod.rs:447-452 with the deltas of mod.rs:727-731)
+__device__ __forceinline__ float row_corr_acc(float corr, const Row12 &ra, const Row12 &rb, float avg1, float avg2)
+{
+    const v2f a1 = {avg1, avg1}, a2 = {avg2, avg2};
+#pragma unroll
+    for (int c = 0; c < KERNEL_WIDTH - 1; c += 2) {
+        const v2f fa = {byte_f32(row12_word(ra, c), c & 3), byte_f32(row12_word(ra, c + 1), (c + 1) & 3)};
+        const v2f fb = {byte_f32(row12_word(rb, c), c & 3), byte_f32(row12_word(rb, c + 1), (c + 1) & 3)};
+        const v2f pr = (fa - a1) * (fb - a2);
+        corr += pr.x;
+        corr += pr.y;
+    }
+    const float d1 = byte_f32(ra.c, 2) - avg1, d2 = byte_f32(rb.c, 2) - avg2;
+    return corr + d1 * d2;
+}
+// sd += (a_k - avg)^2, k = 0..10   (mod.rs:727-733)
+__device__ __forceinline__ float row_sq_acc(float sd, const Row12 &ra, float avg)
+{
+    const v2f a1 = {avg, avg};
+#pragma unroll
+    for (int c = 0; c < KERNEL_WIDTH - 1; c += 2) {
+        const v2f fa = {byte_f32(row12_word(ra, c), c & 3), byte_f32(row12_word(ra, c + 1), (c + 1) & 3)};
+        const v2f d = fa - a1;
+        const v2f pr = d * d;
+        sd += pr.x;
+        sd += pr.y;
+    }
+    const float d1 = byte_f32(ra.c, 2) - avg;
+    return sd + d1 * d1;
+}
+
 // EpipolarLine (mod.rs:83-87) for level pixel (px, py); get_epipolar_line, mod.rs:386-409.
 // F*p1 in nalgebra's gemv order: ((F[i][0]*p0) + F[i][1]*p1) + F[i][2]*p2.
 struct Line {
@@ -156,14 +193,7 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
         const float avg = (float)isum / (float)KERNEL_POINT_COUNT;
         float sd = 0.0f;
 #pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH; r++) {
-#pragma unroll
-            for (int c = 0; c < KERNEL_WIDTH; c++) {
-                const uint32_t wvv = c < 4 ? rows[r].a : (c < 8 ? rows[r].b : rows[r].c);
-                const float delta = byte_f32(wvv, c & 3) - avg;
-                sd += delta * delta;
-            }
-        }
+        for (int r = 0; r < KERNEL_WIDTH; r++) sd = row_sq_acc(sd, rows[r], avg);
         out = make_float2(avg, sqrtf(sd / (float)KERNEL_POINT_COUNT));
         const bool valid = finite_f32(out.y) && !(fabsf(out.y) < min_stdev);
         iout = make_uint2(isum | (valid ? 0x80000000u : 0u), __float_as_uint(out.y));
@@ -903,14 +933,11 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
                     // opaque per iteration: keeps the 121 searched-window deltas from being hoisted out of the
                     // contender loop into 121 live registers
                     asm volatile("" : "+v"(ar.a), "+v"(ar.b), "+v"(ar.c));
-#pragma unroll
-                    for (int cc = 0; cc < KERNEL_WIDTH; cc++) {
-                        const uint32_t wa = cc < 4 ? ar.a : (cc < 8 ? ar.b : ar.c);
-                        const uint32_t wb = cc < 4 ? lo.x : (cc < 8 ? lo.y : hi);
-                        const float delta1 = byte_f32(wa, cc & 3) - avg1;
-                        const float delta2 = byte_f32(wb, cc & 3) - avg2;
-                        corr += delta1 * delta2;
-                    }
+                    Row12 br;
+                    br.a = lo.x;
+                    br.b = lo.y;
+                    br.c = hi;
+                    corr = row_corr_acc(corr, ar, br, avg1, avg2);
                 }
                 corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
                 exact_evals++;
@@ -1021,7 +1048,7 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+__global__ __launch_bounds__(256, 6) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                            const uint8_t *__restrict__ img2,
                                                            const float2 *__restrict__ stats1,
                                                            const uint2 *__restrict__ istats1,
@@ -1130,9 +1157,10 @@ __global__ __launch_bounds__(256) void search3_box_kernel(CorrParams p, const ui
         return;
     }
     const int NPL = H > 5 ? S3_MAXH : 5; // planes computed (group A: 0..4, group B: 5..8)
+    if (p.debug & 256) return; // profiling: per-pixel setup and box reduction only
 
     // ---- stage the transposed target copies and the candidate statistics -----------------------------------
-    {
+    if (!(p.debug & 512)) {
         const int R0 = (int)Y0 + dy0 - KERNEL_SIZE;
         const int nb = (ncol + 3) >> 2;
         const int units = 4 * 5 * nb;
@@ -1319,14 +1347,7 @@ __global__ __launch_bounds__(256) void search3_box_kernel(CorrParams p, const ui
                     const Row12 br = load_row12(base2 + (size_t)r * p.w2);
                     Row12 av = ar[r];
                     asm volatile("" : "+v"(av.a), "+v"(av.b), "+v"(av.c));
-#pragma unroll
-                    for (int cc = 0; cc < KERNEL_WIDTH; cc++) {
-                        const uint32_t wa = cc < 4 ? av.a : (cc < 8 ? av.b : av.c);
-                        const uint32_t wb = cc < 4 ? br.a : (cc < 8 ? br.b : br.c);
-                        const float delta1 = byte_f32(wa, cc & 3) - avg1;
-                        const float delta2 = byte_f32(wb, cc & 3) - avg2;
-                        corr += delta1 * delta2;
-                    }
+                    corr = row_corr_acc(corr, av, br, avg1, avg2);
                 }
                 corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
                 exact_evals++;

@@ -184,14 +184,20 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
             launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.cells[next], cnt, s);
         }));
     } else {
-        if (!(p.debug & 2))
-            CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                if (c->search_version >= 3)
+        if (!(p.debug & 2)) {
+            // version 3: the box filter is the search; the candidate filter only walks the workgroups it declined
+            // and is timed with the other fallback kernel (class K_EXACT)
+            const bool v3 = c->search_version >= 3;
+            if (v3)
+                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
                                        c->contenders, ds.cells[next], cnt, s);
+                }));
+            CVHIP_TRY(timed(c, v3 ? cvhip_ctx::K_EXACT : cvhip_ctx::K_SEARCH, [&] {
                 launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                      c->contenders, ds.cells[next], cnt, c->search_version >= 3 ? 1 : 0, s);
+                                      c->contenders, ds.cells[next], cnt, v3 ? 1 : 0, s);
             }));
+        }
         if (!(p.debug & 1))
             CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
                 launch_search2_exact(p, c->img[a], c->img[b], c->stats[a], c->istats[b], c->range, c->contenders,

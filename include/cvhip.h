@@ -166,8 +166,9 @@ int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms,
 
 /* Per-kernel-class device time since the last reset (needs time_kernels = 1), measured with HIP
  * events on the context's stream: [0] window statistics, [1] search-range estimation, [2] search
- * (filter kernel, or the whole search for version 1), [3] exact re-evaluation, [4] cross-check,
- * [5] grid expansion in complete().  Synchronises. */
+ * (version 3: box filter; 2: candidate filter; 1: the whole search), [3] fallback kernels (whole-corridor
+ * exact re-evaluation; for version 3 also the candidate filter on the workgroups the box filter
+ * declined), [4] cross-check, [5] grid expansion in complete().  Synchronises. */
 int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[6], uint32_t launches[6], int reset);
 /* Device counters of the search kernel since the last reset (needs count_candidates = 1):
  * out[0] candidates that passed the reference's bounds/stdev tests (== candidates above),

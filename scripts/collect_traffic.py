@@ -38,4 +38,4 @@ for name in sorted(F):
                             "write_size_kib_per_step": w / steps_in_run,
                             "hbm_bytes_per_step": (2 * f + w) * 1024 / steps_in_run}
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res["kernels"].get("search2_filter_kernel"), indent=1))
+print(json.dumps(res["kernels"].get("search3_box_kernel", res["kernels"].get("search2_filter_kernel")), indent=1))
