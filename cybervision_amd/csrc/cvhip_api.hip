@@ -187,7 +187,19 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         if (!(p.debug & 2)) {
             // version 3: the box filter is the search; the candidate filter only walks the workgroups it declined
             // and is timed with the other fallback kernel (class K_EXACT)
-            const bool v3 = c->search_version >= 3;
+            // The box walk only pays where every stripe keeps its minor coordinate over a pixel's whole interval,
+            // i.e. for rectified pairs.  For an affine F (F*p = (a, b, .) for every pixel) that is known up front:
+            // a line with any slope steps at zero displacement for every pixel, so unless the lines are (within
+            // 2^-40) axis-parallel nearly every workgroup would decline; perspective F: lines differ per pixel.
+            // Purely a performance choice - both paths are exact.
+            bool v3 = c->search_version >= 3;
+            if (v3 && !c->force_box) {
+                const double *F = p.F;
+                const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
+                const double f0 = std::fabs(F[2]), f1 = std::fabs(F[5]);
+                const double hi = std::max(f0, f1), lo = std::min(f0, f1);
+                v3 = affine_form && hi > 0.0 && lo * 1099511627776.0 <= hi;
+            }
             if (v3)
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
@@ -369,6 +381,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     c->dir[1].gw = w2;
     c->dir[1].gh = h2;
     if (const char *v = std::getenv("CVHIP_SEARCH")) c->search_version = (v[0] >= '1' && v[0] <= '3') ? v[0] - '0' : 3;
+    if (const char *v = std::getenv("CVHIP_FORCE_BOX")) c->force_box = v[0] == '1';
     const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
     c->max_px = std::max(n1, n2);
     // Level grids are gathered in equal row chunks when sharded, so leave room for one padded
@@ -792,8 +805,10 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset)
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
-    if (version < 1 || version > 3) return fail(CVHIP_ERR_INVALID, "search version must be 1, 2 or 3");
-    ctx->search_version = version;
+    // 4 = version 3 with the box kernel launched for every geometry (tests: exercises its per-workgroup decline)
+    if (version < 1 || version > 4) return fail(CVHIP_ERR_INVALID, "search version must be 1, 2 or 3");
+    ctx->force_box = version == 4;
+    ctx->search_version = version == 4 ? 3 : version;
     return CVHIP_OK;
 }
 

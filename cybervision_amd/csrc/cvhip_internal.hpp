@@ -126,6 +126,7 @@ struct cvhip_ctx {
     // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,
     // 3 = displacement-plane box filter (falls back to 2 per workgroup) + exact re-evaluation
     int search_version = 3;
+    bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
     uint32_t *range = nullptr;
     unsigned long long *contenders = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
     size_t max_px = 0;

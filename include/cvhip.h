@@ -178,8 +178,9 @@ int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[6], uint32_t launches[6
 int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
 /* Select the search kernel: 1 = every candidate through the exact serial f32 chain, 2 = exact-integer
  * filter per candidate + exact re-evaluation of the contenders, 3 (default) = the same filter evaluated
- * as displacement-plane box sums for whole row segments, with 2 as the per-workgroup fallback.  All
- * three give identical results. */
+ * as displacement-plane box sums for whole row segments where the pair is rectified (axis-parallel
+ * epipolar lines), with 2 for every other geometry and as the per-workgroup fallback; 4 = 3 with the
+ * box kernel launched for every geometry (testing).  All give identical results. */
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
 
 /* ------------------------------------------------------------------------------------------

@@ -37,6 +37,16 @@ def make_case(name):
     elif name == "tilt60_150x200":
         a, b, _ = synth.make_pair(150, 200, seed=8)
         F, proj = synth.f_tilt(60.0), 0
+    elif name == "tilt05_400x300":
+        # slightly unrectified pair: the box filter handles most workgroups, the ones where a line steps inside a
+        # pixel's interval go to the candidate filter (both kernels contribute to one grid)
+        a, b, _ = synth.make_pair(400, 300, seed=13)
+        F, proj = synth.f_tilt(0.5), 0
+    elif name == "vert_200x260":
+        # vertical epipolar lines: tall displacement boxes, declined by the box filter
+        a0, b0, _ = synth.make_pair(260, 200, seed=17)
+        a, b = np.ascontiguousarray(a0.T), np.ascontiguousarray(b0.T)
+        F, proj = synth.f_tilt(90.0), 0
     elif name == "ragged_dims":
         # the two images have different sizes (the reverse grid has its own dims)
         a, b0, _ = synth.make_pair(190, 170, seed=11)
@@ -58,8 +68,8 @@ def make_case(name):
     return dict(name=name, img1=a, img2=b, F=np.asarray(F, dtype=np.float64), projection=proj, steps=steps)
 
 
-CASES = ["h256", "sem320x200", "tilt3_200x150", "tilt60_150x200", "ragged_dims", "persp_240x180", "flat",
-         "tiny_single_level"]
+CASES = ["h256", "sem320x200", "tilt3_200x150", "tilt60_150x200", "tilt05_400x300", "vert_200x260", "ragged_dims",
+         "persp_240x180", "flat", "tiny_single_level"]
 GOLDEN_CASES = ["tilt3_200x150", "persp_240x180", "ragged_dims"]
 
 

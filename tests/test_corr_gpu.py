@@ -100,6 +100,18 @@ def test_candidate_filter_v2_matches_oracle(gpu_device, oracle, name):
     assert_same_grid(got_r, want_r, f"{name} v2 reverse")
 
 
+@pytest.mark.parametrize("name", ["tilt05_400x300", "tilt3_200x150", "persp_240x180", "ragged_dims"])
+def test_box_filter_declines_per_workgroup(gpu_device, oracle, name):
+    """Version 4 = the box filter launched for every geometry: on unrectified pairs it settles the workgroups
+    whose pixels all have rectangular candidate sets and hands the rest to the candidate filter, so one grid
+    is written by both kernels."""
+    c = cases.make_case(name)
+    got_f, got_r = run_gpu(gpu_device, c, both=True, version=4)
+    want_f, want_r = run_oracle(oracle, c, both=True)
+    assert_same_grid(got_f, want_f, f"{name} v4 forward")
+    assert_same_grid(got_r, want_r, f"{name} v4 reverse")
+
+
 def adversarial_case(kind):
     """Inputs built to stress the filter's decision rule: exact ties (periodic texture: many
     candidates with IDENTICAL scores, the first must win), near-threshold scores and windows whose
