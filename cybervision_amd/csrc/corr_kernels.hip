@@ -39,6 +39,23 @@ __device__ __forceinline__ uint32_t sat_sub_u32(uint32_t a, uint32_t b) { return
 __device__ __forceinline__ bool finite_f32(float v) { return fabsf(v) < __builtin_inff(); }
 __device__ __forceinline__ bool finite_f64(double v) { return fabs(v) < __builtin_inf(); }
 
+// Workgroups are handed to the 8 XCDs round-robin in launch order, and every XCD has its own L2.  The tiled
+// kernels below re-read their neighbours' halo rows/columns, so tile ids are remapped so that one XCD walks a
+// contiguous run of tiles (bijective for any grid size): the halos then hit in that XCD's L2 instead of HBM.
+struct TileId {
+    uint32_t x, y;
+};
+__device__ __forceinline__ TileId xcd_tile()
+{
+    const uint32_t nx = gridDim.x, nwg = nx * gridDim.y, orig = blockIdx.y * nx + blockIdx.x;
+    const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+    const uint32_t id = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (orig >> 3);
+    TileId t;
+    t.y = id / nx;
+    t.x = id - t.y * nx;
+    return t;
+}
+
 // 12 bytes starting at an arbitrary byte address (gfx950 global loads may be unaligned).
 struct Row12 {
     uint32_t a, b, c;
@@ -157,7 +174,8 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
     // unaligned loads per pixel, which made the kernel address-unit-bound); each lane then reads its 12
     // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.
     __shared__ uint32_t tile[14 * (WS_PITCH / 4)];
-    const uint32_t x0 = blockIdx.x * 64, y0 = row0 + blockIdx.y * 4;
+    const TileId tid = xcd_tile();
+    const uint32_t x0 = tid.x * 64, y0 = row0 + tid.y * 4;
     const int sx = (int)x0 - 8, sy = (int)y0 - KERNEL_SIZE; // staged origin; sx is 0 mod 4 relative to x0
     for (uint32_t u = threadIdx.x; u < 14u * (WS_PITCH / 4); u += 256) {
         const uint32_t r = u / (WS_PITCH / 4), c4 = (u - r * (WS_PITCH / 4)) * 4;
@@ -260,9 +278,10 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
 {
     __shared__ uint32_t cells[SR_TILE_W * SR_TILE_H + SR_WIN]; // + slack for the predicated row reads
     // tile of 64 x 4 blocks = pixels [128*bx0 - 1, 128*bx0 + 127] x [by_first*2 - 1, ...]
-    const uint32_t bxi = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t byi = (p.row0 >> 1) + blockIdx.y * 4 + (threadIdx.x >> 6);
-    const uint32_t tile_x0 = blockIdx.x * 128, tile_y0 = ((p.row0 >> 1) + blockIdx.y * 4) * 2;
+    const TileId tid = xcd_tile();
+    const uint32_t bxi = tid.x * 64 + (threadIdx.x & 63);
+    const uint32_t byi = (p.row0 >> 1) + tid.y * 4 + (threadIdx.x >> 6);
+    const uint32_t tile_x0 = tid.x * 128, tile_y0 = ((p.row0 >> 1) + tid.y * 4) * 2;
     // window of the whole tile = union of its corner pixels' windows (the bounds are monotone in x, y)
     uint32_t tx0, tx1, ty0, ty1, ux0, ux1, uy0, uy1;
     neighbor_window(p, sat_sub_u32(tile_x0, 1), sat_sub_u32(tile_y0, 1), tx0, ux1, ty0, uy1);
@@ -645,8 +664,9 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
     __shared__ int bb[4]; // min x, min y, max x, max y of in-bounds candidate centres
 
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t x = blockIdx.x * 64 + lane;
-    const uint32_t y = p.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const TileId tid = xcd_tile();
+    const uint32_t x = tid.x * 64 + lane;
+    const uint32_t y = p.row0 + tid.y * 4 + (threadIdx.x >> 6);
     const bool in_image = x < p.w1 && y < p.row1;
     if (threadIdx.x == 0) {
         bb[0] = 0x7FFFFFFF;
@@ -1048,7 +1068,7 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256, 6) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+__global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                            const uint8_t *__restrict__ img2,
                                                            const float2 *__restrict__ stats1,
                                                            const uint2 *__restrict__ istats1,
@@ -1063,10 +1083,11 @@ __global__ __launch_bounds__(256, 6) void search3_box_kernel(CorrParams p, const
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int X0 = (int)blockIdx.x * S3_OUT;
+    const TileId tid = xcd_tile();
+    const int X0 = (int)tid.x * S3_OUT;
     const int xc = X0 - 6 + (int)lane;        // image column of this lane
     const int xi = X0 - S3_LANE0 + (int)lane; // searched pixel of this lane (its window ends in column xc)
-    const uint32_t Y0 = p.row0 + blockIdx.y * 4;
+    const uint32_t Y0 = p.row0 + tid.y * 4;
     const uint32_t y = Y0 + w;
     const bool is_out = lane >= (uint32_t)S3_LANE0 && xi < (int)p.w1 && y < p.row1;
     const uint32_t x = (uint32_t)xi;
@@ -1562,8 +1583,9 @@ __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ ow
                                                            uint32_t row0)
 {
     // oh = end of the row range handled by this launch, row0 its start
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y0 = row0 + (blockIdx.y * 4 + (threadIdx.x >> 6)) * CC_ROWS;
+    const TileId tid = xcd_tile();
+    const uint32_t x = tid.x * 64 + (threadIdx.x & 63);
+    const uint32_t y0 = row0 + (tid.y * 4 + (threadIdx.x >> 6)) * CC_ROWS;
     if (x >= ow) return;
     const uint32_t sa = CROSS_CHECK_SEARCH_AREA;
     uint32_t cell[CC_ROWS], probe[CC_ROWS];
