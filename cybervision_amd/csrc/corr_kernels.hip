@@ -1067,7 +1067,9 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
     return v;
 }
 
-template <bool COUNT>
+// STEP = false: rectified pairs only (every candidate set a rectangle; anything else is declined);
+// STEP = true: additionally row-major lines that step inside a pixel's interval (per-dx row offset and plane window).
+template <bool COUNT, bool STEP>
 __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                            const uint8_t *__restrict__ img2,
                                                            const float2 *__restrict__ stats1,
@@ -1111,41 +1113,70 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
     const int cs = p.corridor_size;
     const bool major_x = e.ox == 0; // candidates advance along x (x2 == i exactly), stripes shift y
 
-    // ---- this pixel's candidate set as a rectangle of displacements [lox, lox+wx) x [loy, loy+wy) ----------
-    bool simple = true;
-    int lox = 0, loy = 0;
+    // ---- this pixel's candidate set in displacement space ---------------------------------------------------
+    // rectangle [lox, lox+wx) x [loy, loy+wy): every stripe keeps its minor coordinate over the interval; or, for
+    // row-major lines that step inside the interval ("stepped"), the same rectangle with a row offset loy(dx)
+    // that is re-evaluated per dx with the reference's own f64 expression (mod.rs:424-429).
+    bool simple = true, stepped = false;
+    int lox = 0, loy = 0, loy_hi = 0;
     uint32_t wx = 0, wy = 0;
     if (active) {
-        uint32_t m0 = 0;
+        uint32_t m0 = 0, m0l = 0;
+        bool constant = true, consecutive = true;
         for (int off = -cs; off <= cs; off++) {
             const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
             const uint32_t mf = major_x ? cf.y : cf.x, ml = major_x ? cl.y : cl.x;
-            if (off == -cs) m0 = mf;
-            simple = simple && mf == ml && mf == m0 + (uint32_t)(off + cs);
+            if (off == -cs) {
+                m0 = mf;
+                m0l = ml;
+            }
+            constant = constant && mf == ml;
+            consecutive = consecutive && mf == m0 + (uint32_t)(off + cs) && ml == m0l + (uint32_t)(off + cs);
         }
         const uint32_t lim2 = major_x ? p.w2 : p.h2;
         const uint32_t ilo = max(r0, (uint32_t)KERNEL_SIZE), ihi = min(r1, sat_sub_u32(lim2, KERNEL_SIZE));
         const uint32_t nmaj = ihi > ilo ? ihi - ilo : 0u;
-        simple = simple && (r1 - r0) <= CW_MAX_LEN && m0 < 0x40000000u && ilo < 0x40000000u;
+        const bool sane = (r1 - r0) <= CW_MAX_LEN && m0 < 0x40000000u && m0l < 0x40000000u && ilo < 0x40000000u;
+        simple = constant && consecutive && sane;
+        if (STEP && !simple && major_x && consecutive && sane && m0 >= (uint32_t)KERNEL_SIZE && m0l >= (uint32_t)KERNEL_SIZE &&
+            nmaj > 0u && nmaj <= 64u) {
+            // the stripes must be consecutive rows at EVERY candidate, exactly as the reference rounds them:
+            // floor((cy*i + ay) + off) == floor((cy*i + ay) - cs) + off + cs.  Where the fractional part is away
+            // from 0 and 1 that is implied (the addition of a small integer is then exact enough); the few
+            // positions where the line passes through an integer row are checked stripe by stripe.
+            bool ok = true;
+            for (uint32_t i = ilo; i < ihi; i++) {
+                const double v = e.cy * (double)i + e.ay;
+                const double fr = v - floor(v);
+                if (!(fr >= 9.5367431640625e-7 && fr <= 1.0 - 9.5367431640625e-7)) {
+                    const uint32_t b0 = candidate_xy(e, i, -cs).y;
+                    for (int off = -cs + 1; off <= cs; off++) ok = ok && candidate_xy(e, i, off).y == b0 + (uint32_t)(off + cs);
+                }
+            }
+            stepped = ok;
+        }
         if (major_x) {
             lox = (int)ilo - xi;
             wx = nmaj;
-            loy = (int)m0 - (int)y;
+            loy = (int)min(m0, m0l) - (int)y;
+            loy_hi = (int)max(m0, m0l) - (int)y;
             wy = (uint32_t)(2 * cs + 1);
         } else {
             loy = (int)ilo - (int)y;
+            loy_hi = loy;
             wy = nmaj;
             lox = (int)m0 - xi;
             wx = (uint32_t)(2 * cs + 1);
         }
     }
-    const bool has = active && simple && wx > 0u && wy > 0u;
+    const bool has = active && (simple || stepped) && wx > 0u && wy > 0u;
     // wave-uniform bounds of the wave's displacement box
     const int mnx = wave_min_i32(has ? lox : 0x7FFFFFFF), mny = wave_min_i32(has ? loy : 0x7FFFFFFF);
-    const int mxx = wave_max_i32(has ? lox + (int)wx - 1 : -0x7FFFFFFF), mxy = wave_max_i32(has ? loy + (int)wy - 1 : -0x7FFFFFFF);
+    const int mxx = wave_max_i32(has ? lox + (int)wx - 1 : -0x7FFFFFFF), mxy = wave_max_i32(has ? loy_hi + (int)wy - 1 : -0x7FFFFFFF);
     const int need = wave_max_i32(has ? (int)min(wx * wy, 0x3FFFFFFFu) : 0);
     const bool wave_has = mxx >= mnx;
-    const bool wave_odd = __any(active && !simple);
+    const bool wave_odd = __any(active && !(simple || stepped));
+    const bool wave_step = STEP && __any(has && stepped);
     __syncthreads(); // bb initialised
     if (lane == 0) {
         if (wave_has) {
@@ -1284,9 +1315,19 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
         const uint8_t *pIS = lds + S3_IS_OFF + (w * S3_COLS + lane + (uint32_t)(mnx - dx0)) * 8u;
         const int idx_lo = (int)(lane >= 11u ? lane - 11u : 0u) * 4;
         const int nsteps = mxx - mnx + 1;
+        const int ws0 = mny - dy0, wn = mxy - mny + 1; // the wave's plane window while no line steps
         for (int step = 0; step < nsteps; step++, pB16 += 16, pB4 += 4, pIS += 8) {
             const int dx = mnx + step;
             const bool mx = has && (uint32_t)(dx - lox) < wx;
+            // first row offset of this lane's candidates at this dx, and the planes the wave needs for it
+            int bl = loy, s0 = ws0, n = wn;
+            if (wave_step) {
+                if (stepped && mx) bl = (int)candidate_xy(e, (uint32_t)(xi + dx), -cs).y - (int)y; // mod.rs:424-429
+                const int lo = wave_min_i32(mx ? bl : 0x7FFFFFFF), hi = wave_max_i32(mx ? bl + (int)wy - 1 : -0x7FFFFFFF);
+                if (hi < lo) continue; // nobody searches this dx
+                s0 = lo - dy0;
+                n = hi - lo + 1;
+            }
             const uint4 r4 = *reinterpret_cast<const uint4 *>(pB16);
             uint32_t raw[5] = {r4.x, r4.y, r4.z, r4.w, *reinterpret_cast<const uint32_t *>(pB4)};
             // one group of planes: s = S0 .. S0 + N - 1 (dy = dy0 + s), all independent until the rare branch
@@ -1317,22 +1358,49 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
                 if (COUNT) {
 #pragma unroll
                     for (int q = 0; q < N; q++)
-                        if (mx && (uint32_t)(dy0 + S0 + q - loy) < wy && sd[q] < __builtin_inff()) evaluated++;
+                        if (mx && (uint32_t)(dy0 + S0 + q - bl) < wy && sd[q] < __builtin_inff()) evaluated++;
                 }
                 if (margin >= 0.0f) {
 #pragma unroll
                     for (int q = 0; q < N; q++) {
                         const int dy = dy0 + S0 + q;
-                        if (mx && (uint32_t)(dy - loy) < wy && sd[q] < __builtin_inff() && (float)num[q] >= limk * sd[q]) {
-                            const uint32_t code = major_x ? ((uint32_t)(dy - loy) << 11) | (uint32_t)(xi + dx - (int)r0)
+                        if (mx && (uint32_t)(dy - bl) < wy && sd[q] < __builtin_inff() && (float)num[q] >= limk * sd[q]) {
+                            const uint32_t code = major_x ? ((uint32_t)(dy - bl) << 11) | (uint32_t)(xi + dx - (int)r0)
                                                           : ((uint32_t)(dx - lox) << 11) | (uint32_t)((int)y + dy - (int)r0);
                             record(score(num[q], sd[q]), code);
                         }
                     }
                 }
             };
-            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-            if (NPL > 5) group(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+            // five planes from `start` in one interleaved group, any further ones singly (planes are register-
+            // indexed, so the window position selects an instantiation)
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            using I4 = std::integral_constant<int, 4>;
+            using I5 = std::integral_constant<int, 5>;
+            if (!STEP) { // rectangles only: the workgroup's planes 0..4, and 5..8 when its box is taller
+                group(I0{}, I5{});
+                if (NPL > 5) group(I5{}, std::integral_constant<int, 4>{});
+                continue;
+            }
+            const int start = min(s0, NPL - 5);
+            switch (start) {
+            case 0: group(I0{}, I5{}); break;
+            case 1: group(I1{}, I5{}); break;
+            case 2: group(I2{}, I5{}); break;
+            case 3: group(I3{}, I5{}); break;
+            default: group(I4{}, I5{}); break;
+            }
+            for (int sx = start + 5; sx < s0 + n; sx++) {
+                switch (sx) {
+                case 5: group(I5{}, I1{}); break;
+                case 6: group(std::integral_constant<int, 6>{}, I1{}); break;
+                case 7: group(std::integral_constant<int, 7>{}, I1{}); break;
+                default: group(std::integral_constant<int, 8>{}, I1{}); break;
+                }
+            }
         }
     }
 
@@ -1548,16 +1616,19 @@ void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8
 
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s)
+                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
+                        hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + S3_OUT - 1) / S3_OUT, (p.row1 - p.row0 + 3) / 4);
-    if (counters)
-        hipLaunchKernelGGL(search3_box_kernel<true>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2, range, contenders, out,
+                           counters);
+    };
+    if (stepped_lines)
+        counters ? launch(search3_box_kernel<true, true>) : launch(search3_box_kernel<false, true>);
     else
-        hipLaunchKernelGGL(search3_box_kernel<false>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters);
+        counters ? launch(search3_box_kernel<true, false>) : launch(search3_box_kernel<false, false>);
 }
 
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,

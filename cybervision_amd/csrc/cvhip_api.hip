@@ -187,23 +187,23 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         if (!(p.debug & 2)) {
             // version 3: the box filter is the search; the candidate filter only walks the workgroups it declined
             // and is timed with the other fallback kernel (class K_EXACT)
-            // The box walk only pays where every stripe keeps its minor coordinate over a pixel's whole interval,
-            // i.e. for rectified pairs.  For an affine F (F*p = (a, b, .) for every pixel) that is known up front:
-            // a line with any slope steps at zero displacement for every pixel, so unless the lines are (within
-            // 2^-40) axis-parallel nearly every workgroup would decline; perspective F: lines differ per pixel.
+            // The box walk pays where the candidate sets of neighbouring pixels are (nearly) the same few image
+            // rows: row-major epipolar lines of small slope.  For an affine F (F*p = (a, b, .) for every pixel)
+            // that is known up front: lines within ~4.5 degrees of the x axis (each extra row a line crosses inside
+            // a workgroup's displacement box is one more plane per dx; beyond 9 rows the workgroups decline anyway).
+            // Column-major lines and perspective F (lines differ per pixel) go to the candidate filter directly.
             // Purely a performance choice - both paths are exact.
             bool v3 = c->search_version >= 3;
             if (v3 && !c->force_box) {
                 const double *F = p.F;
                 const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
-                const double f0 = std::fabs(F[2]), f1 = std::fabs(F[5]);
-                const double hi = std::max(f0, f1), lo = std::min(f0, f1);
-                v3 = affine_form && hi > 0.0 && lo * 1099511627776.0 <= hi;
+                v3 = affine_form && std::fabs(F[5]) > 0.0 && std::fabs(F[2]) <= 0.08 * std::fabs(F[5]);
             }
             if (v3)
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
+                    // exactly axis-parallel lines never step: the leaner instantiation
                     launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                       c->contenders, ds.cells[next], cnt, s);
+                                       c->contenders, ds.cells[next], cnt, p.F[2] != 0.0 || c->force_box, s);
                 }));
             CVHIP_TRY(timed(c, v3 ? cvhip_ctx::K_EXACT : cvhip_ctx::K_SEARCH, [&] {
                 launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,

@@ -72,7 +72,8 @@ void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8
                            int only_fallback, hipStream_t s);
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s);
+                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
+                        hipStream_t s);
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
                           uint2 *out, unsigned long long *counters, hipStream_t s);
