@@ -599,7 +599,18 @@ constexpr float S2_DELTA = 2.5e-5f;     // >= 393 * 2^-24 (see above)
 //   bits [0, 60): up to four 15-bit candidate codes (stripe index << 11 | i - r0), oldest first
 //   bits [60, 63): count 0..4; CW_WHOLE = re-evaluate the whole corridor exactly
 constexpr unsigned long long CW_WHOLE = 5ull;
-constexpr unsigned long long CW_FALLBACK = 6ull; // search3_box_kernel -> search2_filter_kernel(only_fallback)
+constexpr unsigned long long CW_FALLBACK = 6ull; // search3_box_kernel -> search2_filter_list_kernel
+constexpr int S3_OUT_PX = 53;                     // pixels per box-kernel wave (see search3_box_kernel)
+
+// Tile work lists between the kernels of one search pass (search version 3): the box kernel appends the tiles it
+// declined (for the candidate filter) and both filters append the tiles that hold a CW_WHOLE pixel (for the
+// whole-corridor kernel); the consumers run as small persistent grids over the lists instead of dispatching a
+// workgroup per image tile just to find nothing to do.  Entry: x0 | row-tile index << 16 | (64-wide tile) << 31;
+// a box tile is 53 pixels wide.
+__device__ __forceinline__ void worklist_push(WorkList wl, uint32_t entry)
+{
+    if (wl.count) wl.items[atomicAdd(wl.count, 1u)] = entry;
+}
 constexpr uint32_t CW_MAX_LEN = 2048u;  // i - r0 must fit in 11 bits
 constexpr uint32_t S2_FIXED_PITCH = 128u;
 
@@ -648,26 +659,23 @@ __device__ __forceinline__ bool pixel_setup(const CorrParams &p, uint32_t x, uin
 }
 
 // ---- kernel A: filter ---------------------------------------------------------------------------------
+// One tile: `width` (<= 64) pixels from x0 in the four rows of row tile `ytile`.
 template <bool COUNT>
-__global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                                 const uint8_t *__restrict__ img2,
-                                                                 const float2 *__restrict__ stats1,
-                                                                 const uint2 *__restrict__ istats1,
-                                                                 const uint2 *__restrict__ istats2,
-                                                                 const uint32_t *__restrict__ range,
-                                                                 unsigned long long *__restrict__ contenders,
-                                                                 uint2 *__restrict__ out,
-                                                                 unsigned long long *__restrict__ counters,
-                                                                 int only_fallback)
+__device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const uint8_t *__restrict__ img1,
+                                                    const uint8_t *__restrict__ img2, const float2 *__restrict__ stats1,
+                                                    const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2,
+                                                    const uint32_t *__restrict__ range,
+                                                    unsigned long long *__restrict__ contenders, uint2 *__restrict__ out,
+                                                    unsigned long long *__restrict__ counters, int only_fallback,
+                                                    uint32_t x0, uint32_t width, uint32_t ytile, WorkList whole_list)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[S2_LDS_BYTES];
     __shared__ int bb[4]; // min x, min y, max x, max y of in-bounds candidate centres
 
     const uint32_t lane = threadIdx.x & 63;
-    const TileId tid = xcd_tile();
-    const uint32_t x = tid.x * 64 + lane;
-    const uint32_t y = p.row0 + tid.y * 4 + (threadIdx.x >> 6);
-    const bool in_image = x < p.w1 && y < p.row1;
+    const uint32_t x = x0 + lane;
+    const uint32_t y = p.row0 + ytile * 4 + (threadIdx.x >> 6);
+    const bool in_image = lane < width && x < p.w1 && y < p.row1;
     if (threadIdx.x == 0) {
         bb[0] = 0x7FFFFFFF;
         bb[1] = 0x7FFFFFFF;
@@ -990,6 +998,48 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
             if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
         }
     }
+    if (whole_list.count) { // uniform; every thread of the workgroup is still here
+        const int any_whole = __syncthreads_or(whole ? 1 : 0);
+        if (threadIdx.x == 0 && any_whole) worklist_push(whole_list, x0 | (ytile << 16) | (width == 64u ? 0x80000000u : 0u));
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                                 const uint8_t *__restrict__ img2,
+                                                                 const float2 *__restrict__ stats1,
+                                                                 const uint2 *__restrict__ istats1,
+                                                                 const uint2 *__restrict__ istats2,
+                                                                 const uint32_t *__restrict__ range,
+                                                                 unsigned long long *__restrict__ contenders,
+                                                                 uint2 *__restrict__ out,
+                                                                 unsigned long long *__restrict__ counters)
+{
+    const TileId tid = xcd_tile();
+    search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0, tid.x * 64u, 64u,
+                               tid.y, WorkList{nullptr, nullptr});
+}
+
+// The box kernel's declined tiles: a persistent grid walks the list (search version 3).
+template <bool COUNT>
+__global__ __launch_bounds__(256, 3) void search2_filter_list_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                                      const uint8_t *__restrict__ img2,
+                                                                      const float2 *__restrict__ stats1,
+                                                                      const uint2 *__restrict__ istats1,
+                                                                      const uint2 *__restrict__ istats2,
+                                                                      const uint32_t *__restrict__ range,
+                                                                      unsigned long long *__restrict__ contenders,
+                                                                      uint2 *__restrict__ out,
+                                                                      unsigned long long *__restrict__ counters,
+                                                                      WorkList declined, WorkList whole_list)
+{
+    const uint32_t n = *declined.count;
+    for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+        const uint32_t entry = declined.items[t];
+        search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 1,
+                                   entry & 0xFFFFu, (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, (entry >> 16) & 0x3FFFu, whole_list);
+        __syncthreads(); // the tile's LDS is reused by the next one
+    }
 }
 
 // ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
@@ -1017,7 +1067,7 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
 // ds_read_b128 + one ds_read_b32 per lane and dx serve all <= 9 dy planes); plane s = dy - dy0 multiplies them
 // with the searched column pre-shifted by s & 3 bytes (a[s & 3][k] against dword (s >> 2) + k).
 constexpr int S3_LANE0 = 11;
-constexpr int S3_OUT = 53;
+constexpr int S3_OUT = S3_OUT_PX;
 constexpr int S3_COLS = 128;  // staged columns per copy / per statistics row
 constexpr int S3_MAXH = 9;    // dy planes: 20 staged rows = 9 + 10 window rows (+1)
 constexpr int S3_B16_OFF = 0;                             // [4][128] uint4: rows 0..15 of the copy
@@ -1078,7 +1128,8 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
                                                            const uint32_t *__restrict__ range,
                                                            unsigned long long *__restrict__ contenders,
                                                            uint2 *__restrict__ out,
-                                                           unsigned long long *__restrict__ counters)
+                                                           unsigned long long *__restrict__ counters,
+                                                           WorkList declined, WorkList whole_list)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[S3_LDS_BYTES];
     __shared__ int bb[6]; // min dx, min dy, max dx, max dy, max candidates of one pixel, 1 = some pixel is not a rectangle
@@ -1206,6 +1257,7 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
             contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
             if (!fb) out[pix] = make_uint2(CELL_NONE, 0x7FC00000u);
         }
+        if (!eligible && threadIdx.x == 0) worklist_push(declined, (uint32_t)X0 | (tid.y << 16));
         return;
     }
     const int NPL = H > 5 ? S3_MAXH : 5; // planes computed (group A: 0..4, group B: 5..8)
@@ -1474,22 +1526,24 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
             if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
         }
     }
+    {
+        const int any_whole = __syncthreads_or(whole ? 1 : 0);
+        if (threadIdx.x == 0 && any_whole) worklist_push(whole_list, (uint32_t)X0 | (tid.y << 16));
+    }
 }
 
 // ---- kernel B: exact re-evaluation of the contenders (mod.rs:442-464), in corridor order --------------
-__global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                             const uint8_t *__restrict__ img2,
-                                                             const float2 *__restrict__ stats1,
-                                                             const uint2 *__restrict__ istats2,
-                                                             const uint32_t *__restrict__ range,
-                                                             const unsigned long long *__restrict__ contenders,
-                                                             uint2 *__restrict__ out,
-                                                             unsigned long long *__restrict__ counters)
+__device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const uint8_t *__restrict__ img1,
+                                                   const uint8_t *__restrict__ img2, const float2 *__restrict__ stats1,
+                                                   const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
+                                                   const unsigned long long *__restrict__ contenders,
+                                                   uint2 *__restrict__ out, unsigned long long *__restrict__ counters,
+                                                   uint32_t x0, uint32_t width, uint32_t ytile)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t x = blockIdx.x * 64 + lane;
-    const uint32_t y = p.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    const bool in_image = x < p.w1 && y < p.row1;
+    const uint32_t x = x0 + lane;
+    const uint32_t y = p.row0 + ytile * 4 + (threadIdx.x >> 6);
+    const bool in_image = lane < width && x < p.w1 && y < p.row1;
     // Only pixels the filter kernel marked CW_WHOLE are handled here (the filter kernel settles everything
     // else itself); a wave without such a pixel leaves after reading its contender words.
     const bool interior =
@@ -1599,36 +1653,88 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
     }
 }
 
+__global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                             const uint8_t *__restrict__ img2,
+                                                             const float2 *__restrict__ stats1,
+                                                             const uint2 *__restrict__ istats2,
+                                                             const uint32_t *__restrict__ range,
+                                                             const unsigned long long *__restrict__ contenders,
+                                                             uint2 *__restrict__ out,
+                                                             unsigned long long *__restrict__ counters)
+{
+    search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, blockIdx.x * 64u, 64u, blockIdx.y);
+}
+
+// The tiles that hold a CW_WHOLE pixel: a persistent grid walks the list (search version 3; no barriers inside).
+__global__ __launch_bounds__(256) void search2_exact_list_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                                  const uint8_t *__restrict__ img2,
+                                                                  const float2 *__restrict__ stats1,
+                                                                  const uint2 *__restrict__ istats2,
+                                                                  const uint32_t *__restrict__ range,
+                                                                  const unsigned long long *__restrict__ contenders,
+                                                                  uint2 *__restrict__ out,
+                                                                  unsigned long long *__restrict__ counters,
+                                                                  WorkList whole_list)
+{
+    const uint32_t n = *whole_list.count;
+    for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+        const uint32_t entry = whole_list.items[t];
+        search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, entry & 0xFFFFu,
+                           (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, (entry >> 16) & 0x3FFFu);
+    }
+}
+
+constexpr int LIST_GRID = 1024; // persistent workgroups of the work-list kernels
+
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, int only_fallback,
-                           hipStream_t s)
+                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
     if (counters)
         hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters, only_fallback);
+                           range, contenders, out, counters);
     else
         hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters, only_fallback);
+                           range, contenders, out, counters);
+}
+
+void launch_search2_filter_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                                const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                                unsigned long long *contenders, uint2 *out, unsigned long long *counters,
+                                WorkList declined, WorkList whole_list, hipStream_t s)
+{
+    if (p.row1 <= p.row0) return;
+    if (counters)
+        hipLaunchKernelGGL(search2_filter_list_kernel<true>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1,
+                           istats1, istats2, range, contenders, out, counters, declined, whole_list);
+    else
+        hipLaunchKernelGGL(search2_filter_list_kernel<false>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1,
+                           istats1, istats2, range, contenders, out, counters, declined, whole_list);
 }
 
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                         unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
-                        hipStream_t s)
+                        WorkList declined, WorkList whole_list, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + S3_OUT - 1) / S3_OUT, (p.row1 - p.row0 + 3) / 4);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2, range, contenders, out,
-                           counters);
+                           counters, declined, whole_list);
     };
     if (stepped_lines)
         counters ? launch(search3_box_kernel<true, true>) : launch(search3_box_kernel<false, true>);
     else
         counters ? launch(search3_box_kernel<true, false>) : launch(search3_box_kernel<false, false>);
+}
+
+size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h)
+{
+    // every box tile can be declined once and report CW_WHOLE once; every 64-wide tile can report CW_WHOLE once
+    return (size_t)((max_w + S3_OUT - 1) / S3_OUT) * ((max_h + 3) / 4 + 1);
 }
 
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
@@ -1639,6 +1745,15 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
     hipLaunchKernelGGL(search2_exact_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats2, range, contenders,
                        out, counters);
+}
+
+void launch_search2_exact_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                               const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
+                               uint2 *out, unsigned long long *counters, WorkList whole_list, hipStream_t s)
+{
+    if (p.row1 <= p.row0) return;
+    hipLaunchKernelGGL(search2_exact_list_kernel, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1, istats2, range,
+                       contenders, out, counters, whole_list);
 }
 
 // ---------------------------------------------------------------------------------------------

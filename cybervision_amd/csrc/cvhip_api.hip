@@ -74,6 +74,8 @@ static void free_ctx_buffers(cvhip_ctx *c)
     if (c->range) (void)hipFree(c->range);
     if (c->contenders) (void)hipFree(c->contenders);
     c->contenders = nullptr;
+    if (c->work) (void)hipFree(c->work);
+    c->work = nullptr;
     if (c->d_cand) (void)hipFree(c->d_cand);
     c->range = nullptr;
     c->d_cand = nullptr;
@@ -199,22 +201,37 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
                 const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
                 v3 = affine_form && std::fabs(F[5]) > 0.0 && std::fabs(F[2]) <= 0.08 * std::fabs(F[5]);
             }
-            if (v3)
+            if (v3) {
+                // box filter -> (declined tiles) candidate filter -> (tiles with CW_WHOLE pixels) whole-corridor
+                // kernel; the two followers are persistent grids over the work lists the producers fill
+                const WorkList declined{c->work, c->work + 2};
+                const WorkList whole{c->work + 1, c->work + 2 + c->work_cap};
+                CVHIP_TRY_HIP(hipMemsetAsync(c->work, 0, 2 * sizeof(uint32_t), s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     // exactly axis-parallel lines never step: the leaner instantiation
                     launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                       c->contenders, ds.cells[next], cnt, p.F[2] != 0.0 || c->force_box, s);
+                                       c->contenders, ds.cells[next], cnt, p.F[2] != 0.0 || c->force_box, declined, whole,
+                                       s);
                 }));
-            CVHIP_TRY(timed(c, v3 ? cvhip_ctx::K_EXACT : cvhip_ctx::K_SEARCH, [&] {
-                launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                      c->contenders, ds.cells[next], cnt, v3 ? 1 : 0, s);
-            }));
+                CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
+                    launch_search2_filter_list(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b],
+                                               c->range, c->contenders, ds.cells[next], cnt, declined, whole, s);
+                    if (!(p.debug & 1))
+                        launch_search2_exact_list(p, c->img[a], c->img[b], c->stats[a], c->istats[b], c->range,
+                                                  c->contenders, ds.cells[next], cnt, whole, s);
+                }));
+            } else {
+                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
+                    launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
+                                          c->contenders, ds.cells[next], cnt, s);
+                }));
+                if (!(p.debug & 1))
+                    CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
+                        launch_search2_exact(p, c->img[a], c->img[b], c->stats[a], c->istats[b], c->range, c->contenders,
+                                             ds.cells[next], cnt, s);
+                    }));
+            }
         }
-        if (!(p.debug & 1))
-            CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                launch_search2_exact(p, c->img[a], c->img[b], c->stats[a], c->istats[b], c->range, c->contenders,
-                                     ds.cells[next], cnt, s);
-            }));
     }
     CVHIP_TRY_HIP(hipGetLastError());
 
@@ -397,6 +414,8 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     }
     if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->contenders, c->max_px * sizeof(unsigned long long));
+    c->work_cap = 2 * search3_worklist_capacity(std::max(w1, w2), std::max(h1, h2));
+    if (e == hipSuccess) e = hipMalloc(&c->work, (2 + 2 * c->work_cap) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)

@@ -59,6 +59,11 @@ struct CorrParams {
 };
 
 // ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------
+// tile work list shared by the kernels of one search pass (search version 3)
+struct WorkList {
+    uint32_t *count;
+    uint32_t *items;
+};
 void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, uint32_t row0, uint32_t row1, float min_stdev,
                          float2 *stats, uint2 *istats, hipStream_t s);
 void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
@@ -68,15 +73,22 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
                    hipStream_t s);
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, uint2 *out, unsigned long long *counters,
-                           int only_fallback, hipStream_t s);
+                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s);
+void launch_search2_filter_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                                const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                                unsigned long long *contenders, uint2 *out, unsigned long long *counters,
+                                WorkList declined, WorkList whole_list, hipStream_t s);
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                         unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
-                        hipStream_t s);
+                        WorkList declined, WorkList whole_list, hipStream_t s);
+size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
                           uint2 *out, unsigned long long *counters, hipStream_t s);
+void launch_search2_exact_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                               const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
+                               uint2 *out, unsigned long long *counters, WorkList whole_list, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
 void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
@@ -130,6 +142,8 @@ struct cvhip_ctx {
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
     uint32_t *range = nullptr;
     unsigned long long *contenders = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
+    uint32_t *work = nullptr;                 // two tile work lists: [0], [1] counts, then the items (search version 3)
+    size_t work_cap = 0;                      // items per list
     size_t max_px = 0;
 
     uint32_t shard_num = 0, shard_den = 1;
