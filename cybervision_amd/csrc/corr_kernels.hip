@@ -1296,12 +1296,12 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
         for (int u = (int)threadIdx.x; u < isp * isrows; u += 256) {
             const int r = u / isp, c = u - r * isp;
             const int gy = (int)Y0 + dy0 + r, gx = gx0 + c;
-            // {window sum, f32 stdev}; centres outside the image or skipped by the reference (stdev non-finite or
+            // {-window sum, f32 stdev}; centres outside the image or skipped by the reference (stdev non-finite or
             // < min_stdev, mod.rs:430-441) get stdev = +inf: their acceptance threshold can never be reached
             uint2 v = make_uint2(0u, 0x7F800000u);
             if (gy >= 0 && gy < (int)p.h2 && gx >= 0 && gx < (int)p.w2) {
                 const uint2 tt = istats2[(size_t)gy * p.w2 + (size_t)gx];
-                if (tt.x & 0x80000000u) v = make_uint2(tt.x & 0x7FFFFFFFu, tt.y);
+                if (tt.x & 0x80000000u) v = make_uint2(0u - (tt.x & 0x7FFFFFFFu), tt.y); // -s2: N = 121*S12 + s1*(-s2) is one mul + one mad
             }
             *reinterpret_cast<uint2 *>(lds + S3_IS_OFF + (size_t)(r * S3_COLS + c) * 8u) = v;
         }
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
                     if (sh >= 2) c = __builtin_amdgcn_udot4(a[sh][3], raw[o + 3 < 5 ? o + 3 : 4], c, false);
                     const uint32_t pre = wave_prefix_sum(c);
                     const uint32_t s12 = pre - (uint32_t)__builtin_amdgcn_ds_bpermute(idx_lo, (int)pre);
-                    num[q] = (int)__umul24(s12, (uint32_t)KERNEL_POINT_COUNT) - (int)__umul24(s1, is2.x);
+                    num[q] = __mul24((int)s12, KERNEL_POINT_COUNT) + __mul24((int)s1, (int)is2.x);
                     sd[q] = __uint_as_float(is2.y);
                 }
                 // one rarely taken branch for the group: the largest margin (float)N - limk*sd2 decides.  The fused
@@ -1468,27 +1468,41 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
             bool have = false;
             float bcorr = 0.0f;
             uint32_t bxy = 0, bcode = 0;
-            const float avg1 = ps.st1.x, sdev1 = ps.st1.y;
-            Row12 ar[KERNEL_WIDTH];
-            {
-                const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
-#pragma unroll
-                for (int r = 0; r < KERNEL_WIDTH; r++) ar[r] = load_row12(base + (size_t)r * p.w1);
+            // Rectified instantiation: the epipolar line and the window statistics are not needed during the walk,
+            // so they are re-derived here (same expressions, same bits) instead of living in 10 registers across it.
+            Line ex = e;
+            float2 st1x = ps.st1;
+            if (!STEP) {
+                uint32_t xo = x, yo = y;
+                asm volatile("" : "+v"(xo), "+v"(yo));
+                ex = epipolar_line(p, xo, yo);
+                st1x = stats1[(size_t)yo * p.w1 + xo];
             }
+            const float avg1 = st1x.x, sdev1 = st1x.y;
+            const uint8_t *base1 = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
             for (uint32_t j = 0; j < count; j++) {
                 const uint32_t code = (uint32_t)(clist >> (15u * j)) & 0x7FFFu;
-                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                const CandXY c = candidate_xy(ex, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
                 const uint2 is2 = istats2[(size_t)c.y * p.w2 + c.x];
                 const float avg2 = (float)(is2.x & 0x7FFFFFFFu) / (float)KERNEL_POINT_COUNT; // == compute_point_avg
                 const float sdev2 = __uint_as_float(is2.y);
                 const uint8_t *base2 = img2 + (size_t)(c.y - KERNEL_SIZE) * p.w2 + (c.x - KERNEL_SIZE);
                 float corr = 0.0f;
+                // Both windows come straight from L1/L2 (one contender per pixel is the rule, so nothing is re-read),
+                // in three batches of rows (a real loop): all 22 row loads in flight at once would make this phase the
+                // kernel's register high-water mark (83 instead of ~50) and cost the walk its occupancy.
+#pragma unroll 1
+                for (int rb = 0; rb < 12; rb += 4) {
+                    Row12 av[4], bv[4];
 #pragma unroll
-                for (int r = 0; r < KERNEL_WIDTH; r++) {
-                    const Row12 br = load_row12(base2 + (size_t)r * p.w2);
-                    Row12 av = ar[r];
-                    asm volatile("" : "+v"(av.a), "+v"(av.b), "+v"(av.c));
-                    corr = row_corr_acc(corr, av, br, avg1, avg2);
+                    for (int r = 0; r < 4; r++) {
+                        const int rr = min(rb + r, KERNEL_WIDTH - 1);
+                        av[r] = load_row12(base1 + (size_t)rr * p.w1);
+                        bv[r] = load_row12(base2 + (size_t)rr * p.w2);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (rb + r < KERNEL_WIDTH) corr = row_corr_acc(corr, av[r], bv[r], avg1, avg2);
                 }
                 corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
                 exact_evals++;
