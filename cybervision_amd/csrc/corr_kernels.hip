@@ -1389,8 +1389,6 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
                 float sd[N];
 #pragma unroll
                 for (int q = 0; q < N; q++) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int s = S0 + q, sh = s & 3, o = s >> 2;
                     const uint2 is2 = *reinterpret_cast<const uint2 *>(pIS + s * (S3_COLS * 8));
                     uint32_t c = __builtin_amdgcn_udot4(a[sh][0], raw[o], 0u, false);

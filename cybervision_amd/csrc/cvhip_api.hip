@@ -571,7 +571,9 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
     if (e == hipSuccess && !xy_dev) e = hipMemcpyAsync(out_xy, d_xy, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && out_corr && !corr_dev)
         e = hipMemcpyAsync(out_corr, d_corr, n * sizeof(float), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    // Host destinations are complete on return; device destinations are written in stream order on the
+    // context's stream (no host synchronisation: the caller's next submission simply queues behind it).
+    if (e == hipSuccess && (!xy_dev || (out_corr && !corr_dev))) e = hipStreamSynchronize(s);
     if (!xy_dev) (void)hipFree(d_xy);
     if (out_corr && !corr_dev) (void)hipFree(d_corr);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("complete: ") + hipGetErrorString(e));

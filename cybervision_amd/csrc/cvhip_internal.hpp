@@ -54,8 +54,11 @@ struct CorrParams {
     uint32_t k;              // this level's k
     uint32_t row0, row1;     // rows of the searched image handled by this launch
     int first_pass;
-    int debug; // profiling aid (CVHIP_DEBUG): 1 = skip exact phase, 2 = skip filter phase, 4 = search version 3 sends every workgroup to the fallback kernel,
-               // 8 / 16 = box kernel skips its walk / its exact phase, 32 = box statistics in counters 1, 2
+    // Profiling ablations (env CVHIP_DEBUG, applied to the full-resolution level only; results are then wrong on
+    // purpose): 1 = skip the whole-corridor kernel, 2 = skip the filter kernels, 4 = the box kernel declines every
+    // workgroup, 8 / 16 = the box kernel skips its walk / its exact phase, 32 = box statistics in counters 1 and 2,
+    // 256 = the box kernel stops after per-pixel setup, 512 = it skips staging.
+    int debug;
 };
 
 // ---- kernel launchers (corr_kernels.hip) ----------------------------------------------------

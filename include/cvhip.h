@@ -106,7 +106,10 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
 
 /* GpuContext::complete_process (gpu/mod.rs:210-216; called mod.rs:208-215): write the forward
  * full-resolution grid.  out_xy: 2*w1*h1 int32, out_corr: w1*h1 float (may be NULL).
- * Synchronises.  The context can be destroyed or reused for cvhip_complete_dir afterwards. */
+ * Host destinations are complete on return (synchronises); DEVICE destinations are written in
+ * stream order on the context's stream without a host synchronisation (cvhip_device_synchronize,
+ * or any later work on that stream, orders after them).  The context can be destroyed or reused
+ * for cvhip_complete_dir afterwards. */
 int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr);
 /* Same for either direction (dir 1 = correlated_points_reverse, mod.rs:65); test hook. */
 int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr);

@@ -100,7 +100,8 @@ def test_candidate_filter_v2_matches_oracle(gpu_device, oracle, name):
     assert_same_grid(got_r, want_r, f"{name} v2 reverse")
 
 
-@pytest.mark.parametrize("name", ["tilt05_400x300", "tilt3_200x150", "persp_240x180", "ragged_dims"])
+@pytest.mark.parametrize("name", ["h256", "sem320x200", "tilt05_400x300", "tilt3_200x150", "persp_240x180", "ragged_dims",
+                                  "vert_200x260"])
 def test_box_filter_declines_per_workgroup(gpu_device, oracle, name):
     """Version 4 = the box filter launched for every geometry: on unrectified pairs it settles the workgroups
     whose pixels all have rectangular candidate sets and hands the rest to the candidate filter, so one grid
@@ -242,6 +243,7 @@ def test_device_resident_inputs_and_outputs(gpu_device, oracle):
         oxy = torch.empty((h1, w1, 2), dtype=torch.int32, device="cuda")
         oc = torch.empty((h1, w1), dtype=torch.float32, device="cuda")
         pc.complete(out_xy=oxy, out_corr=oc)
+        gpu_device.synchronize()  # device destinations are written in stream order on the context's own stream
         got = (oxy.cpu().numpy(), oc.cpu().numpy())
     finally:
         pc.close()
