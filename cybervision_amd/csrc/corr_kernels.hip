@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(256) void search2_exact_list_kernel(CorrParams p, c
     }
 }
 
-constexpr int LIST_GRID = 1024; // persistent workgroups of the work-list kernels
+constexpr int LIST_GRID = 512; // persistent workgroups of the work-list kernels (an empty list costs their dispatch)
 
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
@@ -1774,7 +1774,7 @@ void launch_search2_exact_list(const CorrParams &p, const uint8_t *img1, const u
 // match (x2, y2) is the full-res match (x2, y2) << k, so the window test reduces to +-4 level
 // cells.  Each thread owns one cell of `own` and only reads `other`.
 // ---------------------------------------------------------------------------------------------
-constexpr int CC_ROWS = 4; // rows per thread: independent load chains in flight (the kernel is latency-bound)
+constexpr int CC_ROWS = 2; // rows per thread: independent load chains in flight (the kernel is latency-bound)
 
 __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ own, const uint2 *__restrict__ other,
                                                            uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
@@ -1811,15 +1811,22 @@ __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ ow
             return rm != CELL_NONE && rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y;
         };
         bool found = points_back(probe[j]);
-        // fallback: whole rows at a time, nine independent loads in flight (no per-cell early exit)
-        for (uint32_t sy = min_y; sy < max_y && !found; sy++) {
-            const uint2 *row = other + (size_t)sy * rw;
-            uint32_t cellsr[2 * CROSS_CHECK_SEARCH_AREA + 1];
+        // fallback: three window rows at a time, 27 independent loads in flight (no per-cell early exit).  The
+        // kernel is a chain of dependent round trips - cell, probe, then these batches - so its time on small
+        // levels is (batches per cell) x (memory latency), not bytes.
+        constexpr uint32_t CCW = 2 * CROSS_CHECK_SEARCH_AREA + 1, CCB = 3;
+        for (uint32_t sy = min_y; sy < max_y && !found; sy += CCB) {
+            uint32_t cellsr[CCB][CCW];
 #pragma unroll
-            for (uint32_t t = 0; t < 2 * CROSS_CHECK_SEARCH_AREA + 1; t++)
-                cellsr[t] = min_x + t < max_x ? row[min_x + t].x : CELL_NONE;
+            for (uint32_t b = 0; b < CCB; b++) {
+                const uint2 *row = other + (size_t)min(sy + b, max_y - 1u) * rw;
 #pragma unroll
-            for (uint32_t t = 0; t < 2 * CROSS_CHECK_SEARCH_AREA + 1; t++) found = found || points_back(cellsr[t]);
+                for (uint32_t t = 0; t < CCW; t++) cellsr[b][t] = (sy + b < max_y && min_x + t < max_x) ? row[min_x + t].x : CELL_NONE;
+            }
+#pragma unroll
+            for (uint32_t b = 0; b < CCB; b++)
+#pragma unroll
+                for (uint32_t t = 0; t < CCW; t++) found = found || points_back(cellsr[b][t]);
         }
         if (!found) own[(size_t)y * ow + x] = make_uint2(CELL_NONE, 0x7FC00000u);
     }
