@@ -302,6 +302,15 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
     uint32_t cend[4];
     int axis[4]; // 1: corridor position = y of the previous match (the (1, 0)-offset branch), 0: x
     bool any_valid = false, shared = p.pk == p.k + 1;
+    // Affine F (first two columns zero): F*p = (F02, F12, f2(p)) for every pixel - the products with the zero
+    // entries are exact zeros - so the line's direction, axis and corridor end are the same everywhere and only
+    // the offset -scale*f2/f{0|1} differs.  It is finite (mod.rs:338-345) whenever |f2| and the divisor are far
+    // from the f64 range limits; then the two f64 divisions per pixel are skipped.  Anything else takes the
+    // per-pixel path below.
+    const bool affine_f = p.F[0] == 0.0 && p.F[1] == 0.0 && p.F[3] == 0.0 && p.F[4] == 0.0;
+    const Line e0 = epipolar_line(p, 0u, 0u);
+    const double fdom = fabs(p.F[2]) > fabs(p.F[5]) ? fabs(p.F[2]) : fabs(p.F[5]);
+    const bool quick = affine_f && fdom > 1e-150 && fdom < 1e150 && finite_f64(e0.cx) && finite_f64(e0.cy);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         px[q] = 2 * bxi + (q & 1) - 1; // wraps to 0xFFFFFFFF for bxi == 0, q even: rejected below
@@ -315,8 +324,19 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
         if (!interior) continue;
         const float2 st1 = stats1[(size_t)y * p.w1 + x];
         if (!(finite_f32(st1.y) && !(fabsf(st1.y) < p.min_stdev))) continue; // mod.rs:334 (same outcome)
-        const Line e = epipolar_line(p, x, y);
-        if (!line_finite(e)) continue;
+        Line e = e0;
+        bool line_ok = false;
+        if (quick) {
+            const double sc = (double)p.scale, p0 = (double)x / sc, p1 = (double)y / sc; // exact: scale = 2^-k
+            double f2 = p.F[6] * p0;
+            f2 = p.F[7] * p1 + f2;
+            f2 = p.F[8] * 1.0 + f2;
+            line_ok = fabs(f2) < 1e150;
+        }
+        if (!line_ok) {
+            e = epipolar_line(p, x, y);
+            if (!line_finite(e)) continue;
+        }
         valid[q] = true;
         cend[q] = corridor_end_of(p, e);
         axis[q] = e.ox == 1 ? 1 : 0;
