@@ -619,7 +619,7 @@ constexpr float S2_DELTA = 2.5e-5f;     // >= 393 * 2^-24 (see above)
 //   bits [0, 60): up to four 15-bit candidate codes (stripe index << 11 | i - r0), oldest first
 //   bits [60, 63): count 0..4; CW_WHOLE = re-evaluate the whole corridor exactly
 constexpr unsigned long long CW_WHOLE = 5ull;
-constexpr unsigned long long CW_FALLBACK = 6ull; // search3_box_kernel -> search2_filter_list_kernel
+constexpr unsigned long long CW_FALLBACK = 6ull; // search3_box_kernel -> search3_fallback_kernel
 constexpr int S3_OUT_PX = 53;                     // pixels per box-kernel wave (see search3_box_kernel)
 
 // Tile work lists between the kernels of one search pass (search version 3): the box kernel appends the tiles it
@@ -1038,28 +1038,6 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
     const TileId tid = xcd_tile();
     search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0, tid.x * 64u, 64u,
                                tid.y, WorkList{nullptr, nullptr});
-}
-
-// The box kernel's declined tiles: a persistent grid walks the list (search version 3).
-template <bool COUNT>
-__global__ __launch_bounds__(256, 3) void search2_filter_list_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                                      const uint8_t *__restrict__ img2,
-                                                                      const float2 *__restrict__ stats1,
-                                                                      const uint2 *__restrict__ istats1,
-                                                                      const uint2 *__restrict__ istats2,
-                                                                      const uint32_t *__restrict__ range,
-                                                                      unsigned long long *__restrict__ contenders,
-                                                                      uint2 *__restrict__ out,
-                                                                      unsigned long long *__restrict__ counters,
-                                                                      WorkList declined, WorkList whole_list)
-{
-    const uint32_t n = *declined.count;
-    for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
-        const uint32_t entry = declined.items[t];
-        search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 1,
-                                   entry & 0xFFFFu, (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, (entry >> 16) & 0x3FFFu, whole_list);
-        __syncthreads(); // the tile's LDS is reused by the next one
-    }
 }
 
 // ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
@@ -1697,26 +1675,40 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
     search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, blockIdx.x * 64u, 64u, blockIdx.y);
 }
 
-// The tiles that hold a CW_WHOLE pixel: a persistent grid walks the list (search version 3; no barriers inside).
-__global__ __launch_bounds__(256) void search2_exact_list_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                                  const uint8_t *__restrict__ img2,
-                                                                  const float2 *__restrict__ stats1,
-                                                                  const uint2 *__restrict__ istats2,
-                                                                  const uint32_t *__restrict__ range,
-                                                                  const unsigned long long *__restrict__ contenders,
-                                                                  uint2 *__restrict__ out,
-                                                                  unsigned long long *__restrict__ counters,
-                                                                  WorkList whole_list)
+// Search version 3, everything the box kernel left behind, in ONE persistent grid over its two work lists:
+// the tiles it declined go through the candidate filter and then, for their own > 4-contender pixels, straight
+// through the whole-corridor evaluation (each lane reads back only the contender word it wrote itself); the tiles
+// where the box kernel found such pixels only need the latter.
+template <bool COUNT>
+__global__ __launch_bounds__(256, 3) void search3_fallback_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+                                                                   const uint8_t *__restrict__ img2,
+                                                                   const float2 *__restrict__ stats1,
+                                                                   const uint2 *__restrict__ istats1,
+                                                                   const uint2 *__restrict__ istats2,
+                                                                   const uint32_t *__restrict__ range,
+                                                                   unsigned long long *__restrict__ contenders,
+                                                                   uint2 *__restrict__ out,
+                                                                   unsigned long long *__restrict__ counters,
+                                                                   WorkList declined, WorkList whole_list, int skip_exact)
 {
-    const uint32_t n = *whole_list.count;
-    for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
+    const uint32_t nd = *declined.count, nw = *whole_list.count;
+    for (uint32_t t = blockIdx.x; t < nd; t += gridDim.x) {
+        const uint32_t entry = declined.items[t];
+        const uint32_t x0 = entry & 0xFFFFu, width = (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, ytile = (entry >> 16) & 0x3FFFu;
+        search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 1, x0, width,
+                                   ytile, WorkList{nullptr, nullptr});
+        __syncthreads(); // the tile's LDS is reused by the next one
+        if (!skip_exact) search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, x0, width, ytile);
+    }
+    if (skip_exact) return;
+    for (uint32_t t = blockIdx.x; t < nw; t += gridDim.x) {
         const uint32_t entry = whole_list.items[t];
         search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, entry & 0xFFFFu,
                            (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, (entry >> 16) & 0x3FFFu);
     }
 }
 
-constexpr int LIST_GRID = 512; // persistent workgroups of the work-list kernels (an empty list costs their dispatch)
+constexpr int LIST_GRID = 768; // persistent workgroups of the work-list kernels (an empty list costs their dispatch)
 
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
@@ -1732,18 +1724,18 @@ void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8
                            range, contenders, out, counters);
 }
 
-void launch_search2_filter_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                                const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                                unsigned long long *contenders, uint2 *out, unsigned long long *counters,
-                                WorkList declined, WorkList whole_list, hipStream_t s)
+void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                             const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                             unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList declined,
+                             WorkList whole_list, bool skip_exact, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     if (counters)
-        hipLaunchKernelGGL(search2_filter_list_kernel<true>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1,
-                           istats1, istats2, range, contenders, out, counters, declined, whole_list);
+        hipLaunchKernelGGL(search3_fallback_kernel<true>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1, istats1,
+                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0);
     else
-        hipLaunchKernelGGL(search2_filter_list_kernel<false>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1,
-                           istats1, istats2, range, contenders, out, counters, declined, whole_list);
+        hipLaunchKernelGGL(search3_fallback_kernel<false>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1, istats1,
+                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0);
 }
 
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
@@ -1777,15 +1769,6 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
     hipLaunchKernelGGL(search2_exact_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats2, range, contenders,
                        out, counters);
-}
-
-void launch_search2_exact_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                               const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
-                               uint2 *out, unsigned long long *counters, WorkList whole_list, hipStream_t s)
-{
-    if (p.row1 <= p.row0) return;
-    hipLaunchKernelGGL(search2_exact_list_kernel, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1, istats2, range,
-                       contenders, out, counters, whole_list);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -133,7 +133,7 @@ static void shard_rows(const cvhip_ctx *c, uint32_t lh, uint32_t *row0, uint32_t
 // One search pass (mod.rs:247-319) given level images already staged in c->img[a] (searched)
 // and c->img[b] (target) with their window statistics in c->stats[a], c->stats[b].
 static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2,
-                       float scale, int k, int first_pass, int dir)
+                       float scale, int k, int first_pass, int dir, bool zero_counts = true)
 {
     DirState &ds = c->dir[dir];
     hipStream_t s = c->dev->d.stream;
@@ -204,9 +204,10 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
             if (v3) {
                 // box filter -> (declined tiles) candidate filter -> (tiles with CW_WHOLE pixels) whole-corridor
                 // kernel; the two followers are persistent grids over the work lists the producers fill
-                const WorkList declined{c->work, c->work + 2};
-                const WorkList whole{c->work + 1, c->work + 2 + c->work_cap};
-                CVHIP_TRY_HIP(hipMemsetAsync(c->work, 0, 2 * sizeof(uint32_t), s));
+                const WorkList declined{c->work + 2 * dir, c->work + 4};
+                const WorkList whole{c->work + 2 * dir + 1, c->work + 4 + c->work_cap};
+                // both directions' counts are zeroed once per level by cvhip_correlate_level; per-pass callers zero here
+                if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(c->work + 2 * dir, 0, 2 * sizeof(uint32_t), s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     // exactly axis-parallel lines never step: the leaner instantiation
                     launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
@@ -214,11 +215,8 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
                                        s);
                 }));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                    launch_search2_filter_list(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b],
-                                               c->range, c->contenders, ds.cells[next], cnt, declined, whole, s);
-                    if (!(p.debug & 1))
-                        launch_search2_exact_list(p, c->img[a], c->img[b], c->stats[a], c->istats[b], c->range,
-                                                  c->contenders, ds.cells[next], cnt, whole, s);
+                    launch_search3_fallback(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
+                                            c->contenders, ds.cells[next], cnt, declined, whole, (p.debug & 1) != 0, s);
                 }));
             } else {
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
@@ -415,7 +413,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->contenders, c->max_px * sizeof(unsigned long long));
     c->work_cap = 2 * search3_worklist_capacity(std::max(w1, w2), std::max(h1, h2));
-    if (e == hipSuccess) e = hipMalloc(&c->work, (2 + 2 * c->work_cap) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->work, (4 + 2 * c->work_cap) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
@@ -515,7 +513,8 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         ctx->shard_num = 0;
         ctx->shard_den = 1;
     }
-    int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0); // mod.rs:224-230
+    CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 4 * sizeof(uint32_t), s)); // work-list counts of both passes
+    int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, false); // mod.rs:224-230
     if (rc == CVHIP_OK && sharded) {
         const DirState &ds = ctx->dir[0];
         const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);
@@ -523,7 +522,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
             rc = fail(CVHIP_ERR_DEVICE, "all-gather hook failed (forward grid)");
     }
     report(progress, user, 0, 1.0f);
-    if (rc == CVHIP_OK) rc = search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1); // mod.rs:231-237
+    if (rc == CVHIP_OK) rc = search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, false); // mod.rs:231-237
     if (rc == CVHIP_OK && sharded) {
         const DirState &ds = ctx->dir[1];
         const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);

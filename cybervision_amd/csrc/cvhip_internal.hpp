@@ -77,10 +77,10 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                            unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s);
-void launch_search2_filter_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                                const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                                unsigned long long *contenders, uint2 *out, unsigned long long *counters,
-                                WorkList declined, WorkList whole_list, hipStream_t s);
+void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                             const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
+                             unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList declined,
+                             WorkList whole_list, bool skip_exact, hipStream_t s);
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                         unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
@@ -89,9 +89,6 @@ size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
                           uint2 *out, unsigned long long *counters, hipStream_t s);
-void launch_search2_exact_list(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                               const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
-                               uint2 *out, unsigned long long *counters, WorkList whole_list, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
 void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
@@ -145,7 +142,7 @@ struct cvhip_ctx {
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
     uint32_t *range = nullptr;
     unsigned long long *contenders = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
-    uint32_t *work = nullptr;                 // two tile work lists: [0], [1] counts, then the items (search version 3)
+    uint32_t *work = nullptr;                 // tile work lists: counts [2*dir], [2*dir+1], then two item arrays (search version 3)
     size_t work_cap = 0;                      // items per list
     size_t max_px = 0;
 
