@@ -612,7 +612,8 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
 // apart, so 64 lanes reading consecutive candidates hit 64 distinct bank pairs.
 // ---------------------------------------------------------------------------------------------
 constexpr int S2_K = 4;                 // contenders kept per pixel before falling back to the full corridor
-constexpr int S2_LDS_BYTES = 40448;     // 8 tile copies + candidate statistics; 3-4 workgroups per CU
+constexpr int S2_LDS_BYTES = 40448;     // 8 tile copies + candidate statistics; 3 workgroups per CU
+constexpr int S2_LDS_BYTES_STEEP = 65024; // steep / column-major / per-pixel lines: taller candidate boxes, 2 workgroups per CU
 constexpr float S2_DELTA = 2.5e-5f;     // >= 393 * 2^-24 (see above)
 
 // Contender word written by the filter kernel, one u64 per searched pixel:
@@ -687,9 +688,11 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
                                                     const uint32_t *__restrict__ range,
                                                     unsigned long long *__restrict__ contenders, uint2 *__restrict__ out,
                                                     unsigned long long *__restrict__ counters, int only_fallback,
-                                                    uint32_t x0, uint32_t width, uint32_t ytile, WorkList whole_list)
+                                                    uint32_t x0, uint32_t width, uint32_t ytile, WorkList whole_list,
+                                                    uint8_t *__restrict__ tile, uint32_t lds_bytes)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[S2_LDS_BYTES];
+    // `tile` is the launch's dynamic LDS (lds_bytes: S2_LDS_BYTES, or S2_LDS_BYTES_STEEP where the host expects
+    // tall candidate boxes)
     __shared__ int bb[4]; // min x, min y, max x, max y of in-bounds candidate centres
 
     const uint32_t lane = threadIdx.x & 63;
@@ -763,7 +766,7 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
     // per-candidate statistics (istats2) of every candidate centre in the box, staged next to the tile
     const uint32_t cw = any_active ? (uint32_t)(bb[2] - bb[0] + 1) : 0u, ch = any_active ? (uint32_t)(bb[3] - bb[1] + 1) : 0u;
     const uint32_t IS_OFF = 8u * CS;
-    const bool use_lds = any_active && IS_OFF + cw * ch * 8u <= (uint32_t)S2_LDS_BYTES;
+    const bool use_lds = any_active && IS_OFF + cw * ch * 8u <= lds_bytes;
     const uint2 *lds_is = reinterpret_cast<const uint2 *>(tile + IS_OFF);
 
     // ---- stage the target tile (8 byte-shifted copies) and the candidate statistics -----------------
@@ -905,10 +908,12 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
                         asm volatile("" : "+v"(s12a), "+v"(s12b));
                         const float sd0 = __uint_as_float(is0.y), sd1 = __uint_as_float(is1.y);
                         if (COUNT) evaluated += (sd0 < __builtin_inff() ? 1u : 0u) + (sd1 < __builtin_inff() ? 1u : 0u);
-                        const int n0 = (int)(KERNEL_POINT_COUNT * s12a) - s1 * (int)is0.x;
-                        const int n1 = (int)(KERNEL_POINT_COUNT * s12b) - s1 * (int)is1.x;
-                        // one rarely-taken branch for the pair
-                        if ((float)n0 >= limk * sd0 || (float)n1 >= limk * sd1) {
+                        // all factors are below 2^24: full-rate 24-bit multiplies instead of v_mul_lo_u32
+                        const int n0 = __mul24((int)s12a, KERNEL_POINT_COUNT) - __mul24(s1, (int)is0.x);
+                        const int n1 = __mul24((int)s12b, KERNEL_POINT_COUNT) - __mul24(s1, (int)is1.x);
+                        // one rarely-taken branch for the pair: the larger margin (float)N - limk*sd2 decides (the
+                        // fused multiply-add only pre-screens - limk is shaved by 2^-20 - and record() re-tests)
+                        if (fmaxf(__builtin_fmaf(-limk, sd0, (float)n0), __builtin_fmaf(-limk, sd1, (float)n1)) >= 0.0f) {
                             if (sd0 < __builtin_inff()) record(score(n0, sd0), ti);
                             if (sd1 < __builtin_inff()) record(score(n1, sd1), ti + 1);
                         }
@@ -940,7 +945,7 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
                         asm volatile("" : "+v"(s12), "+v"(s12x));
                         const float sd2 = __uint_as_float(is2.y);
                         if (COUNT) evaluated += sd2 < __builtin_inff() ? 1u : 0u;
-                        const int num = (int)(KERNEL_POINT_COUNT * (s12 + s12x)) - s1 * (int)is2.x;
+                        const int num = __mul24((int)(s12 + s12x), KERNEL_POINT_COUNT) - __mul24(s1, (int)is2.x);
                         if ((float)num >= limk * sd2 && sd2 < __builtin_inff()) record(score(num, sd2), tbase + (i - r0));
                     }
                 }
@@ -1033,11 +1038,13 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
                                                                  const uint32_t *__restrict__ range,
                                                                  unsigned long long *__restrict__ contenders,
                                                                  uint2 *__restrict__ out,
-                                                                 unsigned long long *__restrict__ counters)
+                                                                 unsigned long long *__restrict__ counters,
+                                                                 uint32_t lds_bytes)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     const TileId tid = xcd_tile();
     search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0, tid.x * 64u, 64u,
-                               tid.y, WorkList{nullptr, nullptr});
+                               tid.y, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
 }
 
 // ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
@@ -1689,14 +1696,16 @@ __global__ __launch_bounds__(256, 3) void search3_fallback_kernel(CorrParams p, 
                                                                    unsigned long long *__restrict__ contenders,
                                                                    uint2 *__restrict__ out,
                                                                    unsigned long long *__restrict__ counters,
-                                                                   WorkList declined, WorkList whole_list, int skip_exact)
+                                                                   WorkList declined, WorkList whole_list, int skip_exact,
+                                                                   uint32_t lds_bytes)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     const uint32_t nd = *declined.count, nw = *whole_list.count;
     for (uint32_t t = blockIdx.x; t < nd; t += gridDim.x) {
         const uint32_t entry = declined.items[t];
         const uint32_t x0 = entry & 0xFFFFu, width = (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, ytile = (entry >> 16) & 0x3FFFu;
         search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 1, x0, width,
-                                   ytile, WorkList{nullptr, nullptr});
+                                   ytile, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
         __syncthreads(); // the tile's LDS is reused by the next one
         if (!skip_exact) search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, x0, width, ytile);
     }
@@ -1708,6 +1717,18 @@ __global__ __launch_bounds__(256, 3) void search3_fallback_kernel(CorrParams p, 
     }
 }
 
+// LDS per workgroup of the candidate filter.  A 64x4 tile's candidate box is as tall as the lines are steep: for
+// an affine F with row-major lines of slope <= 0.25 the 40 KB budget (3 workgroups per CU) always fits; column-major
+// lines, steeper ones and perspective F (per-pixel lines) get 64 KB, without which most of their tiles would fall
+// through to the whole-corridor kernel.
+static uint32_t search2_lds_bytes(const CorrParams &p)
+{
+    const double *F = p.F;
+    const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
+    const bool shallow = affine_form && std::fabs(F[2]) <= 0.25 * std::fabs(F[5]);
+    return shallow ? (uint32_t)S2_LDS_BYTES : (uint32_t)S2_LDS_BYTES_STEEP;
+}
+
 constexpr int LIST_GRID = 768; // persistent workgroups of the work-list kernels (an empty list costs their dispatch)
 
 void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
@@ -1716,12 +1737,13 @@ void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
+    const uint32_t lds = search2_lds_bytes(p);
     if (counters)
-        hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters);
+        hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), lds, s, p, img1, img2, stats1, istats1, istats2,
+                           range, contenders, out, counters, lds);
     else
-        hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters);
+        hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), lds, s, p, img1, img2, stats1, istats1, istats2,
+                           range, contenders, out, counters, lds);
 }
 
 void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
@@ -1730,12 +1752,13 @@ void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uin
                              WorkList whole_list, bool skip_exact, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
+    const uint32_t lds = search2_lds_bytes(p);
     if (counters)
-        hipLaunchKernelGGL(search3_fallback_kernel<true>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1, istats1,
-                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0);
+        hipLaunchKernelGGL(search3_fallback_kernel<true>, dim3(LIST_GRID), dim3(256), lds, s, p, img1, img2, stats1, istats1,
+                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0, lds);
     else
-        hipLaunchKernelGGL(search3_fallback_kernel<false>, dim3(LIST_GRID), dim3(256), 0, s, p, img1, img2, stats1, istats1,
-                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0);
+        hipLaunchKernelGGL(search3_fallback_kernel<false>, dim3(LIST_GRID), dim3(256), lds, s, p, img1, img2, stats1, istats1,
+                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0, lds);
 }
 
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
