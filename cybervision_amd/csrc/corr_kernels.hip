@@ -761,10 +761,14 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
     const int bhei = bb[3] - bb[1] + 2 * KERNEL_SIZE + 1;
     // row pitch, multiple of 8; the common case (box <= 128 B wide) uses a compile-time pitch so that every
     // LDS row offset in the candidate loop is an immediate
-    const uint32_t P = !any_active ? 8u : (bwid <= (int)S2_FIXED_PITCH ? S2_FIXED_PITCH : (uint32_t)((bwid + 7) & ~7));
-    const uint32_t CS = any_active ? ((P * (uint32_t)bhei + 16u + 255u) & ~255u) + 32u : 0u; // copy stride
-    // per-candidate statistics (istats2) of every candidate centre in the box, staged next to the tile
+    // ... unless only the box's own width (tall narrow boxes: column-major lines) makes the eight copies fit
     const uint32_t cw = any_active ? (uint32_t)(bb[2] - bb[0] + 1) : 0u, ch = any_active ? (uint32_t)(bb[3] - bb[1] + 1) : 0u;
+    auto copy_stride = [&](uint32_t pitch) { return ((pitch * (uint32_t)bhei + 16u + 255u) & ~255u) + 32u; };
+    const uint32_t Ptight = (uint32_t)((bwid + 7) & ~7);
+    const bool fixed_fits = bwid <= (int)S2_FIXED_PITCH && 8u * copy_stride(S2_FIXED_PITCH) + cw * ch * 8u <= lds_bytes;
+    const uint32_t P = !any_active ? 8u : (fixed_fits ? S2_FIXED_PITCH : Ptight);
+    const uint32_t CS = any_active ? copy_stride(P) : 0u; // copy stride
+    // per-candidate statistics (istats2) of every candidate centre in the box, staged next to the tile
     const uint32_t IS_OFF = 8u * CS;
     const bool use_lds = any_active && IS_OFF + cw * ch * 8u <= lds_bytes;
     const uint2 *lds_is = reinterpret_cast<const uint2 *>(tile + IS_OFF);

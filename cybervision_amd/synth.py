@@ -77,14 +77,22 @@ def disparity(width: int, height: int):
     return (a * _tri(xs, p) * _tri(ys, q)) >> 16
 
 
-def make_pair(width: int, height: int | None = None, seed: int = 1234, sem_style: bool = False):
-    """Return (img1, img2, d): two uint8 (H, W) images and the int64 disparity field."""
+def make_pair(width: int, height: int | None = None, seed: int = 1234, sem_style: bool = False,
+              tilt_deg: float = 0.0):
+    """Return (img1, img2, d): two uint8 (H, W) images and the int64 disparity field.  The displacement is
+    d along the direction (cos, sin) of tilt_deg - the epipolar direction of f_tilt(tilt_deg) - rounded to
+    integer pixels (16.16 fixed point), so a tilted F sees a geometrically consistent pair."""
     height = width if height is None else height
     xs = np.arange(width, dtype=np.int64)[None, :]
     ys = np.arange(height, dtype=np.int64)[:, None]
     d = disparity(width, height)
     t1 = texture(xs, ys, seed)
-    t2 = texture(xs + d, ys + 0 * xs, seed)
+    if tilt_deg == 0.0:
+        t2 = texture(xs + d, ys + 0 * xs, seed)
+    else:
+        ci = int(round(math.cos(math.radians(tilt_deg)) * 65536.0))
+        si = int(round(math.sin(math.radians(tilt_deg)) * 65536.0))
+        t2 = texture(xs + ((d * ci + 32768) >> 16), ys + ((d * si + 32768) >> 16), seed)
     if sem_style:
         # linear shading ramp of +-16 grey levels and 0.2 % salt noise (independent per image), both integer
         ramp = ((xs * 32) // max(width, 1)) - 16

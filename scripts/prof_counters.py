@@ -11,7 +11,11 @@ import torch  # noqa: E402,F401
 from cybervision_amd import correlation, synth  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
-img1, img2, _ = synth.make_pair(W, W)
+TILT = 0.0
+for a in sys.argv:
+    if a.startswith("--tilt="):
+        TILT = float(a.split("=")[1])
+img1, img2, _ = synth.make_pair(W, W, tilt_deg=TILT)  # displacement along the epipolar direction of F
 steps = synth.optimal_scale_steps(W, W)
 p1, p2 = synth.box_pyramid(img1, steps), synth.box_pyramid(img2, steps)
 d1 = [torch.from_numpy(p).cuda() for p in p1]
