@@ -620,8 +620,8 @@ constexpr float S2_DELTA = 2.5e-5f;     // >= 393 * 2^-24 (see above)
 //   bits [0, 60): up to four 15-bit candidate codes (stripe index << 11 | i - r0), oldest first
 //   bits [60, 63): count 0..4; CW_WHOLE = re-evaluate the whole corridor exactly
 constexpr unsigned long long CW_WHOLE = 5ull;
+constexpr int S3_OUT_PX = 53; // pixels per box-kernel wave (see search3_box_kernel)
 constexpr unsigned long long CW_FALLBACK = 6ull; // search3_box_kernel -> search3_fallback_kernel
-constexpr int S3_OUT_PX = 53;                     // pixels per box-kernel wave (see search3_box_kernel)
 
 // Tile work lists between the kernels of one search pass (search version 3): the box kernel appends the tiles it
 // declined (for the candidate filter) and both filters append the tiles that hold a CW_WHOLE pixel (for the
@@ -631,6 +631,30 @@ constexpr int S3_OUT_PX = 53;                     // pixels per box-kernel wave 
 __device__ __forceinline__ void worklist_push(WorkList wl, uint32_t entry)
 {
     if (wl.count) wl.items[atomicAdd(wl.count, 1u)] = entry;
+}
+// A 256-thread tile of searched pixels for the per-candidate kernels: lanes along x and the four waves on four
+// rows (nl <= 64 pixels wide) - or, for the transposed box kernel's tiles, lanes along y and the waves on four
+// columns (nl pixels tall).  Work-list entry: x0 | tile index along y << 16 | transposed << 30 | 64-wide << 31.
+struct PixTile {
+    uint32_t x0, y0, nl;
+    bool tr;
+};
+__device__ __forceinline__ PixTile tile_of_entry(uint32_t entry, uint32_t row0)
+{
+    PixTile t;
+    t.tr = ((entry >> 30) & 1u) != 0u;
+    t.x0 = entry & 0xFFFFu;
+    const uint32_t idx = (entry >> 16) & 0x3FFFu;
+    t.y0 = row0 + idx * (t.tr ? (uint32_t)S3_OUT_PX : 4u);
+    t.nl = t.tr ? (uint32_t)S3_OUT_PX : ((entry >> 31) ? 64u : (uint32_t)S3_OUT_PX);
+    return t;
+}
+__device__ __forceinline__ bool tile_pixel(const PixTile &t, uint32_t &x, uint32_t &y)
+{
+    const uint32_t l = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    x = t.x0 + (t.tr ? wv : l);
+    y = t.y0 + (t.tr ? l : wv);
+    return l < t.nl;
 }
 constexpr uint32_t CW_MAX_LEN = 2048u;  // i - r0 must fit in 11 bits
 constexpr uint32_t S2_FIXED_PITCH = 128u;
@@ -688,17 +712,16 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
                                                     const uint32_t *__restrict__ range,
                                                     unsigned long long *__restrict__ contenders, uint2 *__restrict__ out,
                                                     unsigned long long *__restrict__ counters, int only_fallback,
-                                                    uint32_t x0, uint32_t width, uint32_t ytile, WorkList whole_list,
-                                                    uint8_t *__restrict__ tile, uint32_t lds_bytes)
+                                                    PixTile tl, WorkList whole_list, uint8_t *__restrict__ tile,
+                                                    uint32_t lds_bytes)
 {
     // `tile` is the launch's dynamic LDS (lds_bytes: S2_LDS_BYTES, or S2_LDS_BYTES_STEEP where the host expects
     // tall candidate boxes)
     __shared__ int bb[4]; // min x, min y, max x, max y of in-bounds candidate centres
 
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t x = x0 + lane;
-    const uint32_t y = p.row0 + ytile * 4 + (threadIdx.x >> 6);
-    const bool in_image = lane < width && x < p.w1 && y < p.row1;
+    uint32_t x, y;
+    const bool in_image = tile_pixel(tl, x, y) && x < p.w1 && y < p.row1;
     if (threadIdx.x == 0) {
         bb[0] = 0x7FFFFFFF;
         bb[1] = 0x7FFFFFFF;
@@ -1029,7 +1052,8 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
     }
     if (whole_list.count) { // uniform; every thread of the workgroup is still here
         const int any_whole = __syncthreads_or(whole ? 1 : 0);
-        if (threadIdx.x == 0 && any_whole) worklist_push(whole_list, x0 | (ytile << 16) | (width == 64u ? 0x80000000u : 0u));
+        if (threadIdx.x == 0 && any_whole)
+            worklist_push(whole_list, tl.x0 | (((tl.y0 - p.row0) / 4u) << 16) | (tl.nl == 64u ? 0x80000000u : 0u));
     }
 }
 
@@ -1047,8 +1071,9 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     const TileId tid = xcd_tile();
-    search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0, tid.x * 64u, 64u,
-                               tid.y, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
+    search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0,
+                               PixTile{tid.x * 64u, p.row0 + tid.y * 4u, 64u, false}, WorkList{nullptr, nullptr}, dyn_lds,
+                               lds_bytes);
 }
 
 // ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
@@ -1067,14 +1092,14 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
 // their minor coordinate over the pixel's interval (rectified pairs: always; tilted epipolar lines: only where
 // the line does not step inside the interval).  A workgroup where that fails, or whose box is much larger
 // than its pixels' own sets (disparity discontinuities, the first pass), taller than 9 rows or wider than 61
-// columns, marks its pixels CW_FALLBACK and search2_filter_kernel (only_fallback = 1) walks them candidate
-// by candidate.
+// columns, marks its pixels CW_FALLBACK and search3_fallback_kernel walks them candidate by candidate.
 //
-// Layout: lane l <-> image column X0 - 6 + l, and lanes 11..63 also own the searched pixel whose window ENDS
-// in that column (x = X0 - 11 + l), so S12 = P(l) - P(l - 11).  The target image is staged TRANSPOSED, once per
-// wave row: copy w holds, for every column, the 20 bytes of rows Y0 + w + dy0 - 5 ... as 5 dwords (one
-// ds_read_b128 + one ds_read_b32 per lane and dx serve all <= 9 dy planes); plane s = dy - dy0 multiplies them
-// with the searched column pre-shifted by s & 3 bytes (a[s & 3][k] against dword (s >> 2) + k).
+// Layout (TR = false; TR = true is the same with the image axes exchanged): lane l <-> image column U0 - 6 + l,
+// and lanes 11..63 also own the searched pixel whose window ENDS in that column (x = U0 - 11 + l), so
+// S12 = P(l) - P(l - 11).  The target image is staged TRANSPOSED, once per wave row: copy w holds, for every
+// column, the 20 bytes of rows V0 + w + dy0 - 5 ... as 5 dwords (one ds_read_b128 + one ds_read_b32 per lane and
+// dx serve all <= 9 dy planes); plane s = dy - dy0 multiplies them with the searched column pre-shifted by s & 3
+// bytes (a[s & 3][k] against dword (s >> 2) + k).
 constexpr int S3_LANE0 = 11;
 constexpr int S3_OUT = S3_OUT_PX;
 constexpr int S3_COLS = 128;  // staged columns per copy / per statistics row
@@ -1127,9 +1152,13 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 }
 
 // STEP = false: rectified pairs only (every candidate set a rectangle; anything else is declined);
-// STEP = true: additionally row-major lines that step inside a pixel's interval (per-dx row offset and plane window).
-template <bool COUNT, bool STEP>
-__global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+// STEP = true: additionally lines that step inside a pixel's interval (per-step offset and plane window).
+// TR = false: lanes run along x and the four waves of a workgroup along y (row-major epipolar lines: the long side
+// of the displacement box is dx);  TR = true: the same kernel with the two image axes exchanged - lanes along y,
+// waves along x, the packed 11-byte vectors are image ROWS - for column-major lines.  Below, u is the lane axis
+// and v the other one; S12 is the same integer either way.
+template <bool COUNT, bool STEP, bool TR>
+__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                            const uint8_t *__restrict__ img2,
                                                            const float2 *__restrict__ stats1,
                                                            const uint2 *__restrict__ istats1,
@@ -1146,13 +1175,14 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const TileId tid = xcd_tile();
-    const int X0 = (int)tid.x * S3_OUT;
-    const int xc = X0 - 6 + (int)lane;        // image column of this lane
-    const int xi = X0 - S3_LANE0 + (int)lane; // searched pixel of this lane (its window ends in column xc)
-    const uint32_t Y0 = p.row0 + tid.y * 4;
-    const uint32_t y = Y0 + w;
-    const bool is_out = lane >= (uint32_t)S3_LANE0 && xi < (int)p.w1 && y < p.row1;
-    const uint32_t x = (uint32_t)xi;
+    const int U0 = (TR ? (int)p.row0 : 0) + (int)tid.x * S3_OUT;
+    const int uc = U0 - 6 + (int)lane;        // u coordinate of this lane's image line (a column; a row when TR)
+    const int ui = U0 - S3_LANE0 + (int)lane; // u coordinate of this lane's searched pixel (its window ends at uc)
+    const uint32_t V0 = (TR ? 0u : p.row0) + tid.y * 4;
+    const uint32_t vv = V0 + w;
+    const uint32_t x = TR ? vv : (uint32_t)ui, y = TR ? (uint32_t)ui : vv;
+    const int xi = (int)x;
+    const bool is_out = lane >= (uint32_t)S3_LANE0 && x < p.w1 && y < p.row1;
     if (threadIdx.x == 0) {
         bb[0] = 0x7FFFFFFF;
         bb[1] = 0x7FFFFFFF;
@@ -1178,7 +1208,7 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
     // row-major lines that step inside the interval ("stepped"), the same rectangle with a row offset loy(dx)
     // that is re-evaluated per dx with the reference's own f64 expression (mod.rs:424-429).
     bool simple = true, stepped = false;
-    int lox = 0, loy = 0, loy_hi = 0;
+    int lox = 0, loy = 0, lox_hi = 0, loy_hi = 0;
     uint32_t wx = 0, wy = 0;
     if (active) {
         uint32_t m0 = 0, m0l = 0;
@@ -1198,25 +1228,30 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
         const uint32_t nmaj = ihi > ilo ? ihi - ilo : 0u;
         const bool sane = (r1 - r0) <= CW_MAX_LEN && m0 < 0x40000000u && m0l < 0x40000000u && ilo < 0x40000000u;
         simple = constant && consecutive && sane;
-        if (STEP && !simple && major_x && consecutive && sane && m0 >= (uint32_t)KERNEL_SIZE && m0l >= (uint32_t)KERNEL_SIZE &&
-            nmaj > 0u && nmaj <= 64u) {
+        // (m0, m0l >= 1: the casts of mod.rs:427-428 did not saturate a negative coordinate to 0)
+        if (STEP && !simple && major_x != TR && consecutive && sane && m0 >= 1u && m0l >= 1u && nmaj > 0u && nmaj <= 64u) {
             // the stripes must be consecutive rows at EVERY candidate, exactly as the reference rounds them:
             // floor((cy*i + ay) + off) == floor((cy*i + ay) - cs) + off + cs.  Where the fractional part is away
             // from 0 and 1 that is implied (the addition of a small integer is then exact enough); the few
             // positions where the line passes through an integer row are checked stripe by stripe.
             bool ok = true;
             for (uint32_t i = ilo; i < ihi; i++) {
-                const double v = e.cy * (double)i + e.ay;
+                const double v = TR ? e.cx * (double)i + e.ax : e.cy * (double)i + e.ay;
                 const double fr = v - floor(v);
                 if (!(fr >= 9.5367431640625e-7 && fr <= 1.0 - 9.5367431640625e-7)) {
-                    const uint32_t b0 = candidate_xy(e, i, -cs).y;
-                    for (int off = -cs + 1; off <= cs; off++) ok = ok && candidate_xy(e, i, off).y == b0 + (uint32_t)(off + cs);
+                    const CandXY c0 = candidate_xy(e, i, -cs);
+                    const uint32_t b0 = TR ? c0.x : c0.y;
+                    for (int off = -cs + 1; off <= cs; off++) {
+                        const CandXY co = candidate_xy(e, i, off);
+                        ok = ok && (TR ? co.x : co.y) == b0 + (uint32_t)(off + cs);
+                    }
                 }
             }
             stepped = ok;
         }
         if (major_x) {
             lox = (int)ilo - xi;
+            lox_hi = lox;
             wx = nmaj;
             loy = (int)min(m0, m0l) - (int)y;
             loy_hi = (int)max(m0, m0l) - (int)y;
@@ -1225,15 +1260,19 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
             loy = (int)ilo - (int)y;
             loy_hi = loy;
             wy = nmaj;
-            lox = (int)m0 - xi;
+            lox = (int)min(m0, m0l) - xi;
+            lox_hi = (int)max(m0, m0l) - xi;
             wx = (uint32_t)(2 * cs + 1);
         }
     }
     const bool has = active && (simple || stepped) && wx > 0u && wy > 0u;
+    // the same rectangle on the kernel's axes: [lou, lou+wu) along the lanes, [lov .. lov_hi, +wv) across the planes
+    const int lou = TR ? loy : lox, lov = TR ? lox : loy, lov_hi = TR ? lox_hi : loy_hi;
+    const uint32_t wu = TR ? wy : wx, wv = TR ? wx : wy;
     // wave-uniform bounds of the wave's displacement box
-    const int mnx = wave_min_i32(has ? lox : 0x7FFFFFFF), mny = wave_min_i32(has ? loy : 0x7FFFFFFF);
-    const int mxx = wave_max_i32(has ? lox + (int)wx - 1 : -0x7FFFFFFF), mxy = wave_max_i32(has ? loy_hi + (int)wy - 1 : -0x7FFFFFFF);
-    const int need = wave_max_i32(has ? (int)min(wx * wy, 0x3FFFFFFFu) : 0);
+    const int mnx = wave_min_i32(has ? lou : 0x7FFFFFFF), mny = wave_min_i32(has ? lov : 0x7FFFFFFF);
+    const int mxx = wave_max_i32(has ? lou + (int)wu - 1 : -0x7FFFFFFF), mxy = wave_max_i32(has ? lov_hi + (int)wv - 1 : -0x7FFFFFFF);
+    const int need = wave_max_i32(has ? (int)min(wu * wv, 0x3FFFFFFFu) : 0);
     const bool wave_has = mxx >= mnx;
     const bool wave_odd = __any(active && !(simple || stepped));
     const bool wave_step = STEP && __any(has && stepped);
@@ -1253,8 +1292,8 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
     const bool any_has = bb[2] >= bb[0];
     const int dx0 = bb[0], dy0 = bb[1];
     const int W = bb[2] - bb[0] + 1, H = bb[3] - bb[1] + 1;
-    const int C0 = X0 - 6 + dx0; // target column of lane 0 at dx0
-    const int C0a = C0 & ~3;
+    const int C0 = U0 - 6 + dx0; // target line (column; row when TR) of lane 0 at the box's first step
+    const int C0a = TR ? C0 : (C0 & ~3);
     const int colshift = C0 - C0a;
     const int ncol = colshift + 64 + W - 1;
     bool eligible = !bb[5] && !(p.debug & 4);
@@ -1266,45 +1305,71 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
             contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
             if (!fb) out[pix] = make_uint2(CELL_NONE, 0x7FC00000u);
         }
-        if (!eligible && threadIdx.x == 0) worklist_push(declined, (uint32_t)X0 | (tid.y << 16));
+        if (!eligible && threadIdx.x == 0) {
+            if (counters && (p.debug & 32)) { // diagnostics: declined workgroups, and why
+                atomicAdd(&counters[3], 1ull);
+                if (bb[5]) atomicAdd(&counters[0], 1ull << 32);
+                else if (!(ncol <= S3_COLS)) atomicAdd(&counters[0], 1ull << 40);
+                else if (!(H <= S3_MAXH)) atomicAdd(&counters[0], 1ull << 48);
+                else atomicAdd(&counters[0], 1ull << 56);
+            }
+            // a transposed tile is named by its first column and its index along y
+            worklist_push(declined, TR ? (V0 | (tid.x << 16) | 0x40000000u) : ((uint32_t)U0 | (tid.y << 16)));
+        }
         return;
     }
     const int NPL = H > 5 ? S3_MAXH : 5; // planes computed (group A: 0..4, group B: 5..8)
     if (p.debug & 256) return; // profiling: per-pixel setup and box reduction only
 
-    // ---- stage the transposed target copies and the candidate statistics -----------------------------------
+    // ---- stage the target copies (20 bytes along v per line and copy) and the candidate statistics -------------
     if (!(p.debug & 512)) {
-        const int R0 = (int)Y0 + dy0 - KERNEL_SIZE;
-        const int nb = (ncol + 3) >> 2;
-        const int units = 4 * 5 * nb;
-        for (int u = (int)threadIdx.x; u < units; u += 256) {
-            const int wk = u / nb, b = u - wk * nb; // wk = copy * 5 + k
-            const int cw = wk / 5, k = wk - cw * 5;
-            const int rr = R0 + cw + 4 * k, col = C0a + 4 * b;
-            const uint32_t d0 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 0, col);
-            const uint32_t d1 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 1, col);
-            const uint32_t d2 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 2, col);
-            const uint32_t d3 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 3, col);
-            uint4 t; // 4x4 byte transpose: t.c = rows rr..rr+3 of column col + c
-            t.x = (d0 & 0xFFu) | ((d1 & 0xFFu) << 8) | ((d2 & 0xFFu) << 16) | (d3 << 24);
-            t.y = ((d0 >> 8) & 0xFFu) | (d1 & 0xFF00u) | ((d2 & 0xFF00u) << 8) | ((d3 & 0xFF00u) << 16);
-            t.z = ((d0 >> 16) & 0xFFu) | ((d1 >> 8) & 0xFF00u) | (d2 & 0xFF0000u) | ((d3 & 0xFF0000u) << 8);
-            t.w = (d0 >> 24) | ((d1 >> 16) & 0xFF00u) | ((d2 >> 8) & 0xFF0000u) | (d3 & 0xFF000000u);
-            if (k < 4) {
-                uint32_t *dst = reinterpret_cast<uint32_t *>(lds + S3_B16_OFF + (size_t)(cw * S3_COLS + 4 * b) * 16u) + k;
-                dst[0] = t.x;
-                dst[4] = t.y;
-                dst[8] = t.z;
-                dst[12] = t.w;
-            } else {
-                *reinterpret_cast<uint4 *>(lds + S3_B4_OFF + (size_t)(cw * S3_COLS + 4 * b) * 4u) = t;
+        const int R0 = (int)V0 + dy0 - KERNEL_SIZE; // first v coordinate of copy 0
+        if (!TR) {
+            // lines are columns: the bytes along v are a column of the image, gathered by 4x4 byte transposes
+            const int nb = (ncol + 3) >> 2;
+            const int units = 4 * 5 * nb;
+            for (int u = (int)threadIdx.x; u < units; u += 256) {
+                const int wk = u / nb, b = u - wk * nb; // wk = copy * 5 + k
+                const int cw = wk / 5, k = wk - cw * 5;
+                const int rr = R0 + cw + 4 * k, col = C0a + 4 * b;
+                const uint32_t d0 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 0, col);
+                const uint32_t d1 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 1, col);
+                const uint32_t d2 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 2, col);
+                const uint32_t d3 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 3, col);
+                uint4 t; // 4x4 byte transpose: t.c = rows rr..rr+3 of column col + c
+                t.x = (d0 & 0xFFu) | ((d1 & 0xFFu) << 8) | ((d2 & 0xFFu) << 16) | (d3 << 24);
+                t.y = ((d0 >> 8) & 0xFFu) | (d1 & 0xFF00u) | ((d2 & 0xFF00u) << 8) | ((d3 & 0xFF00u) << 16);
+                t.z = ((d0 >> 16) & 0xFFu) | ((d1 >> 8) & 0xFF00u) | (d2 & 0xFF0000u) | ((d3 & 0xFF0000u) << 8);
+                t.w = (d0 >> 24) | ((d1 >> 16) & 0xFF00u) | ((d2 >> 8) & 0xFF0000u) | (d3 & 0xFF000000u);
+                if (k < 4) {
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(lds + S3_B16_OFF + (size_t)(cw * S3_COLS + 4 * b) * 16u) + k;
+                    dst[0] = t.x;
+                    dst[4] = t.y;
+                    dst[8] = t.z;
+                    dst[12] = t.w;
+                } else {
+                    *reinterpret_cast<uint4 *>(lds + S3_B4_OFF + (size_t)(cw * S3_COLS + 4 * b) * 4u) = t;
+                }
+            }
+        } else {
+            // lines are rows: the bytes along v are contiguous in the image
+            const int units = 4 * 5 * ncol;
+            for (int u = (int)threadIdx.x; u < units; u += 256) {
+                const int wk = u / ncol, c = u - wk * ncol; // wk = copy * 5 + k
+                const int cw = wk / 5, k = wk - cw * 5;
+                const uint32_t d = load_dword_checked(img2, (int)p.w2, (int)p.h2, C0a + c, R0 + cw + 4 * k);
+                if (k < 4)
+                    *(reinterpret_cast<uint32_t *>(lds + S3_B16_OFF + (size_t)(cw * S3_COLS + c) * 16u) + k) = d;
+                else
+                    *reinterpret_cast<uint32_t *>(lds + S3_B4_OFF + (size_t)(cw * S3_COLS + c) * 4u) = d;
             }
         }
         const int isp = 64 + W - 1, isrows = NPL + 3;
-        const int gx0 = X0 - S3_LANE0 + dx0; // target column of lane 0's pixel at dx0
+        const int gu0 = U0 - S3_LANE0 + dx0; // target u of lane 0's pixel at the box's first step
         for (int u = (int)threadIdx.x; u < isp * isrows; u += 256) {
             const int r = u / isp, c = u - r * isp;
-            const int gy = (int)Y0 + dy0 + r, gx = gx0 + c;
+            const int gv = (int)V0 + dy0 + r, gu = gu0 + c;
+            const int gx = TR ? gv : gu, gy = TR ? gu : gv;
             // {-window sum, f32 stdev}; centres outside the image or skipped by the reference (stdev non-finite or
             // < min_stdev, mod.rs:430-441) get stdev = +inf: their acceptance threshold can never be reached
             uint2 v = make_uint2(0u, 0x7F800000u);
@@ -1315,18 +1380,24 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
             *reinterpret_cast<uint2 *>(lds + S3_IS_OFF + (size_t)(r * S3_COLS + c) * 8u) = v;
         }
     }
-    // this lane's searched column, rows y-5 .. y+5, packed and pre-shifted by 0..3 bytes
+    // this lane's searched line (column uc, or row uc when TR), v-5 .. v+5, packed and pre-shifted by 0..3 bytes
     uint32_t a[4][4];
     {
         uint32_t a0 = 0, a1 = 0, a2 = 0;
-        if (xc >= 0 && xc < (int)p.w1 && y >= (uint32_t)KERNEL_SIZE && y + KERNEL_SIZE < p.h1) {
-            const uint8_t *pc = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (size_t)xc;
+        if (!TR && uc >= 0 && uc < (int)p.w1 && vv >= (uint32_t)KERNEL_SIZE && vv + KERNEL_SIZE < p.h1) {
+            const uint8_t *pc = img1 + (size_t)(vv - KERNEL_SIZE) * p.w1 + (size_t)uc;
             uint32_t b[KERNEL_WIDTH];
 #pragma unroll
             for (int r = 0; r < KERNEL_WIDTH; r++) b[r] = pc[(size_t)r * p.w1];
             a0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
             a1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
             a2 = b[8] | (b[9] << 8) | (b[10] << 16);
+        }
+        if (TR && uc >= 0 && uc < (int)p.h1 && vv >= (uint32_t)KERNEL_SIZE && vv + KERNEL_SIZE < p.w1) {
+            const Row12 rr = load_row12(img1 + (size_t)uc * p.w1 + (vv - KERNEL_SIZE));
+            a0 = rr.a;
+            a1 = rr.b;
+            a2 = rr.c & 0x00FFFFFFu;
         }
         a[0][0] = a0;
         a[0][1] = a1;
@@ -1378,14 +1449,17 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
         const int nsteps = mxx - mnx + 1;
         const int ws0 = mny - dy0, wn = mxy - mny + 1; // the wave's plane window while no line steps
         for (int step = 0; step < nsteps; step++, pB16 += 16, pB4 += 4, pIS += 8) {
-            const int dx = mnx + step;
-            const bool mx = has && (uint32_t)(dx - lox) < wx;
-            // first row offset of this lane's candidates at this dx, and the planes the wave needs for it
-            int bl = loy, s0 = ws0, n = wn;
+            const int dx = mnx + step; // displacement along the lanes (x; y when TR)
+            const bool mx = has && (uint32_t)(dx - lou) < wu;
+            // first plane offset of this lane's candidates at this step, and the planes the wave needs for it
+            int bl = lov, s0 = ws0, n = wn;
             if (wave_step) {
-                if (stepped && mx) bl = (int)candidate_xy(e, (uint32_t)(xi + dx), -cs).y - (int)y; // mod.rs:424-429
-                const int lo = wave_min_i32(mx ? bl : 0x7FFFFFFF), hi = wave_max_i32(mx ? bl + (int)wy - 1 : -0x7FFFFFFF);
-                if (hi < lo) continue; // nobody searches this dx
+                if (stepped && mx) { // mod.rs:424-429
+                    const CandXY cb = candidate_xy(e, (uint32_t)((TR ? (int)y : xi) + dx), -cs);
+                    bl = TR ? (int)cb.x - xi : (int)cb.y - (int)y;
+                }
+                const int lo = wave_min_i32(mx ? bl : 0x7FFFFFFF), hi = wave_max_i32(mx ? bl + (int)wv - 1 : -0x7FFFFFFF);
+                if (hi < lo) continue; // nobody searches this step
                 s0 = lo - dy0;
                 n = hi - lo + 1;
             }
@@ -1417,15 +1491,17 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
                 if (COUNT) {
 #pragma unroll
                     for (int q = 0; q < N; q++)
-                        if (mx && (uint32_t)(dy0 + S0 + q - bl) < wy && sd[q] < __builtin_inff()) evaluated++;
+                        if (mx && (uint32_t)(dy0 + S0 + q - bl) < wv && sd[q] < __builtin_inff()) evaluated++;
                 }
                 if (margin >= 0.0f) {
 #pragma unroll
                     for (int q = 0; q < N; q++) {
-                        const int dy = dy0 + S0 + q;
-                        if (mx && (uint32_t)(dy - bl) < wy && sd[q] < __builtin_inff() && (float)num[q] >= limk * sd[q]) {
-                            const uint32_t code = major_x ? ((uint32_t)(dy - bl) << 11) | (uint32_t)(xi + dx - (int)r0)
-                                                          : ((uint32_t)(dx - lox) << 11) | (uint32_t)((int)y + dy - (int)r0);
+                        const int dy = dy0 + S0 + q; // displacement across the planes (y; x when TR)
+                        if (mx && (uint32_t)(dy - bl) < wv && sd[q] < __builtin_inff() && (float)num[q] >= limk * sd[q]) {
+                            // back to image axes: candidate (x + ddx, y + ddy), stripe origin (ox, oy)
+                            const int ddx = TR ? dy : dx, ddy = TR ? dx : dy, ox = TR ? bl : lox, oy = TR ? loy : bl;
+                            const uint32_t code = major_x ? ((uint32_t)(ddy - oy) << 11) | (uint32_t)(xi + ddx - (int)r0)
+                                                          : ((uint32_t)(ddx - ox) << 11) | (uint32_t)((int)y + ddy - (int)r0);
                             record(score(num[q], sd[q]), code);
                         }
                     }
@@ -1549,7 +1625,8 @@ __global__ __launch_bounds__(256, 5) void search3_box_kernel(CorrParams p, const
     }
     {
         const int any_whole = __syncthreads_or(whole ? 1 : 0);
-        if (threadIdx.x == 0 && any_whole) worklist_push(whole_list, (uint32_t)X0 | (tid.y << 16));
+        if (threadIdx.x == 0 && any_whole)
+            worklist_push(whole_list, TR ? (V0 | (tid.x << 16) | 0x40000000u) : ((uint32_t)U0 | (tid.y << 16)));
     }
 }
 
@@ -1559,12 +1636,11 @@ __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const ui
                                                    const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
                                                    const unsigned long long *__restrict__ contenders,
                                                    uint2 *__restrict__ out, unsigned long long *__restrict__ counters,
-                                                   uint32_t x0, uint32_t width, uint32_t ytile)
+                                                   PixTile tl)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t x = x0 + lane;
-    const uint32_t y = p.row0 + ytile * 4 + (threadIdx.x >> 6);
-    const bool in_image = lane < width && x < p.w1 && y < p.row1;
+    uint32_t x, y;
+    const bool in_image = tile_pixel(tl, x, y) && x < p.w1 && y < p.row1;
     // Only pixels the filter kernel marked CW_WHOLE are handled here (the filter kernel settles everything
     // else itself); a wave without such a pixel leaves after reading its contender words.
     const bool interior =
@@ -1683,7 +1759,8 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
                                                              uint2 *__restrict__ out,
                                                              unsigned long long *__restrict__ counters)
 {
-    search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, blockIdx.x * 64u, 64u, blockIdx.y);
+    search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters,
+                       PixTile{blockIdx.x * 64u, p.row0 + blockIdx.y * 4u, 64u, false});
 }
 
 // Search version 3, everything the box kernel left behind, in ONE persistent grid over its two work lists:
@@ -1691,7 +1768,7 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
 // through the whole-corridor evaluation (each lane reads back only the contender word it wrote itself); the tiles
 // where the box kernel found such pixels only need the latter.
 template <bool COUNT>
-__global__ __launch_bounds__(256, 3) void search3_fallback_kernel(CorrParams p, const uint8_t *__restrict__ img1,
+__global__ __launch_bounds__(256, 2) void search3_fallback_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                                    const uint8_t *__restrict__ img2,
                                                                    const float2 *__restrict__ stats1,
                                                                    const uint2 *__restrict__ istats1,
@@ -1706,19 +1783,16 @@ __global__ __launch_bounds__(256, 3) void search3_fallback_kernel(CorrParams p, 
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     const uint32_t nd = *declined.count, nw = *whole_list.count;
     for (uint32_t t = blockIdx.x; t < nd; t += gridDim.x) {
-        const uint32_t entry = declined.items[t];
-        const uint32_t x0 = entry & 0xFFFFu, width = (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, ytile = (entry >> 16) & 0x3FFFu;
-        search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 1, x0, width,
-                                   ytile, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
+        const PixTile tl = tile_of_entry(declined.items[t], p.row0);
+        search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 1, tl,
+                                   WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
         __syncthreads(); // the tile's LDS is reused by the next one
-        if (!skip_exact) search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, x0, width, ytile);
+        if (!skip_exact) search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, tl);
     }
     if (skip_exact) return;
-    for (uint32_t t = blockIdx.x; t < nw; t += gridDim.x) {
-        const uint32_t entry = whole_list.items[t];
-        search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, entry & 0xFFFFu,
-                           (entry >> 31) ? 64u : (uint32_t)S3_OUT_PX, (entry >> 16) & 0x3FFFu);
-    }
+    for (uint32_t t = blockIdx.x; t < nw; t += gridDim.x)
+        search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters,
+                           tile_of_entry(whole_list.items[t], p.row0));
 }
 
 // LDS per workgroup of the candidate filter.  A 64x4 tile's candidate box is as tall as the lines are steep: for
@@ -1768,24 +1842,35 @@ void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uin
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                         unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
-                        WorkList declined, WorkList whole_list, hipStream_t s)
+                        bool transposed, WorkList declined, WorkList whole_list, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
-    dim3 grid((p.w1 + S3_OUT - 1) / S3_OUT, (p.row1 - p.row0 + 3) / 4);
+    // lanes along x, 4 rows per workgroup - or, transposed, lanes along y and 4 columns per workgroup
+    const dim3 grid = transposed ? dim3((p.row1 - p.row0 + S3_OUT - 1) / S3_OUT, (p.w1 + 3) / 4)
+                                 : dim3((p.w1 + S3_OUT - 1) / S3_OUT, (p.row1 - p.row0 + 3) / 4);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2, range, contenders, out,
                            counters, declined, whole_list);
     };
-    if (stepped_lines)
-        counters ? launch(search3_box_kernel<true, true>) : launch(search3_box_kernel<false, true>);
-    else
-        counters ? launch(search3_box_kernel<true, false>) : launch(search3_box_kernel<false, false>);
+    const int variant = (counters ? 4 : 0) | (stepped_lines ? 2 : 0) | (transposed ? 1 : 0);
+    switch (variant) {
+    case 0: launch(search3_box_kernel<false, false, false>); break;
+    case 1: launch(search3_box_kernel<false, false, true>); break;
+    case 2: launch(search3_box_kernel<false, true, false>); break;
+    case 3: launch(search3_box_kernel<false, true, true>); break;
+    case 4: launch(search3_box_kernel<true, false, false>); break;
+    case 5: launch(search3_box_kernel<true, false, true>); break;
+    case 6: launch(search3_box_kernel<true, true, false>); break;
+    default: launch(search3_box_kernel<true, true, true>); break;
+    }
 }
 
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h)
 {
     // every box tile can be declined once and report CW_WHOLE once; every 64-wide tile can report CW_WHOLE once
-    return (size_t)((max_w + S3_OUT - 1) / S3_OUT) * ((max_h + 3) / 4 + 1);
+    const size_t along_x = (size_t)((max_w + S3_OUT - 1) / S3_OUT) * ((max_h + 3) / 4 + 1);
+    const size_t along_y = (size_t)((max_h + S3_OUT - 1) / S3_OUT) * ((max_w + 3) / 4 + 1); // transposed tiles
+    return along_x > along_y ? along_x : along_y;
 }
 
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,

@@ -187,32 +187,36 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         }));
     } else {
         if (!(p.debug & 2)) {
-            // version 3: the box filter is the search; the candidate filter only walks the workgroups it declined
-            // and is timed with the other fallback kernel (class K_EXACT)
-            // The box walk pays where the candidate sets of neighbouring pixels are (nearly) the same few image
-            // rows: row-major epipolar lines of small slope.  For an affine F (F*p = (a, b, .) for every pixel)
-            // that is known up front: lines within ~4.5 degrees of the x axis (each extra row a line crosses inside
-            // a workgroup's displacement box is one more plane per dx; beyond 9 rows the workgroups decline anyway).
-            // Column-major lines and perspective F (lines differ per pixel) go to the candidate filter directly.
-            // Purely a performance choice - both paths are exact.
+            // Version 3: the box filter is the search; the candidate filter only walks the workgroups it declines
+            // (timed with the other fallback work, class K_EXACT).  The box walk pays where the candidate sets of
+            // neighbouring pixels are (nearly) the same few image rows (columns): axis-near epipolar lines.  For an
+            // affine F (F*p = (a, b, .) for every pixel) that is known up front: lines within ~4.5 degrees of the x
+            // or y axis (each extra line crossed inside a workgroup's displacement box is one more plane per step;
+            // beyond 9 the workgroups decline anyway).  Steeper lines and perspective F (lines differ per pixel) go
+            // to the candidate filter directly.  Purely a performance choice - both paths are exact.
             bool v3 = c->search_version >= 3;
+            // column-major lines (|F*p|_x > |F*p|_y, mod.rs:397): the transposed instantiation of the box kernel
+            const bool transposed = std::fabs(p.F[2]) > std::fabs(p.F[5]);
+            const double f_major = transposed ? std::fabs(p.F[2]) : std::fabs(p.F[5]);
+            const double f_minor = transposed ? std::fabs(p.F[5]) : std::fabs(p.F[2]);
             if (v3 && !c->force_box) {
                 const double *F = p.F;
                 const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
-                v3 = affine_form && std::fabs(F[5]) > 0.0 && std::fabs(F[2]) <= 0.08 * std::fabs(F[5]);
+                v3 = affine_form && f_major > 0.0 && f_minor <= 0.08 * f_major;
             }
             if (v3) {
-                // box filter -> (declined tiles) candidate filter -> (tiles with CW_WHOLE pixels) whole-corridor
-                // kernel; the two followers are persistent grids over the work lists the producers fill
-                const WorkList declined{c->work + 2 * dir, c->work + 4};
-                const WorkList whole{c->work + 2 * dir + 1, c->work + 4 + c->work_cap};
+                // box filter -> one persistent fallback kernel over the tiles it declined and the tiles with
+                // whole-corridor pixels (work lists filled by the producers)
+                uint32_t *wc = c->work + 4 * dir;
+                const WorkList declined{wc, c->work + 8};
+                const WorkList whole{wc + 1, c->work + 8 + c->work_cap};
                 // both directions' counts are zeroed once per level by cvhip_correlate_level; per-pass callers zero here
-                if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(c->work + 2 * dir, 0, 2 * sizeof(uint32_t), s));
+                if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(wc, 0, 4 * sizeof(uint32_t), s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     // exactly axis-parallel lines never step: the leaner instantiation
                     launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                       c->contenders, ds.cells[next], cnt, p.F[2] != 0.0 || c->force_box, declined, whole,
-                                       s);
+                                       c->contenders, ds.cells[next], cnt, f_minor != 0.0 || c->force_box, transposed,
+                                       declined, whole, s);
                 }));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
                     launch_search3_fallback(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
@@ -413,7 +417,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->contenders, c->max_px * sizeof(unsigned long long));
     c->work_cap = 2 * search3_worklist_capacity(std::max(w1, w2), std::max(h1, h2));
-    if (e == hipSuccess) e = hipMalloc(&c->work, (4 + 2 * c->work_cap) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->work, (8 + 2 * c->work_cap) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
@@ -513,7 +517,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         ctx->shard_num = 0;
         ctx->shard_den = 1;
     }
-    CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 4 * sizeof(uint32_t), s)); // work-list counts of both passes
+    CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 8 * sizeof(uint32_t), s)); // work-list counts and flags of both passes
     int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, false); // mod.rs:224-230
     if (rc == CVHIP_OK && sharded) {
         const DirState &ds = ctx->dir[0];

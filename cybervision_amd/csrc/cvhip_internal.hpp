@@ -84,7 +84,7 @@ void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uin
 void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                         unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
-                        WorkList declined, WorkList whole_list, hipStream_t s);
+                        bool transposed, WorkList declined, WorkList whole_list, hipStream_t s);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
@@ -142,7 +142,7 @@ struct cvhip_ctx {
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
     uint32_t *range = nullptr;
     unsigned long long *contenders = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
-    uint32_t *work = nullptr;                 // tile work lists: counts [2*dir], [2*dir+1], then two item arrays (search version 3)
+    uint32_t *work = nullptr;                 // tile work lists: per direction {declined n, whole n, declined scan, whole scan}, then two item arrays
     size_t work_cap = 0;                      // items per list
     size_t max_px = 0;
 
