@@ -1214,7 +1214,9 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
         uint32_t m0 = 0, m0l = 0;
         bool constant = true, consecutive = true;
         for (int off = -cs; off <= cs; off++) {
-            const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
+            // The lean instantiation is only launched for exactly axis-parallel lines (minor coefficient +-0): the
+            // minor coordinate (+-0 * i + add) + off then does not depend on i, so the far end need not be evaluated.
+            const CandXY cf = candidate_xy(e, r0, off), cl = STEP ? candidate_xy(e, r1 - 1, off) : cf;
             const uint32_t mf = major_x ? cf.y : cf.x, ml = major_x ? cl.y : cl.x;
             if (off == -cs) {
                 m0 = mf;
@@ -1227,7 +1229,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
         const uint32_t ilo = max(r0, (uint32_t)KERNEL_SIZE), ihi = min(r1, sat_sub_u32(lim2, KERNEL_SIZE));
         const uint32_t nmaj = ihi > ilo ? ihi - ilo : 0u;
         const bool sane = (r1 - r0) <= CW_MAX_LEN && m0 < 0x40000000u && m0l < 0x40000000u && ilo < 0x40000000u;
-        simple = constant && consecutive && sane;
+        simple = constant && consecutive && sane && (STEP || (major_x ? e.cy == 0.0 : e.cx == 0.0));
         // (m0, m0l >= 1: the casts of mod.rs:427-428 did not saturate a negative coordinate to 0)
         if (STEP && !simple && major_x != TR && consecutive && sane && m0 >= 1u && m0l >= 1u && nmaj > 0u && nmaj <= 64u) {
             // the stripes must be consecutive rows at EVERY candidate, exactly as the reference rounds them:
