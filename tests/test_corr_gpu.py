@@ -395,6 +395,23 @@ def test_two_rank_sharded_level_calls(case, mode):
         assert p.returncode == 0 and f"rank {rank} ok" in out, out
 
 
+@pytest.mark.parametrize("tilt", [3.0, -2.0, 87.0, 90.0])
+def test_box_filter_variants_equal_exact_kernel_1024(gpu_device, tilt):
+    """The stepped-line and transposed instantiations of the box filter (slightly tilted and near-vertical
+    epipolar lines, pairs displaced along those lines) against the plain exact kernel at a size the oracle
+    would need minutes for: same match coordinates and score bits, both directions."""
+    a, b, _ = synth.make_pair(1024, 1024, seed=31, tilt_deg=tilt)
+    steps = synth.optimal_scale_steps(1024, 1024)
+    c = dict(img1=a, img2=b, F=synth.f_tilt(tilt), projection=0, steps=steps)
+    cnt = {}
+    (fxy, fc), (rxy, rc) = run_gpu(gpu_device, c, both=True, counters=cnt)
+    (fxy1, fc1), (rxy1, rc1) = run_gpu(gpu_device, c, both=True, version=1)
+    assert (fxy == fxy1).all() and (rxy == rxy1).all()
+    vf, vr = fxy1[..., 0] >= 0, rxy1[..., 0] >= 0
+    assert (bits(fc)[vf] == bits(fc1)[vf]).all() and (bits(rc)[vr] == bits(rc1)[vr]).all()
+    assert vf.mean() > 0.7 and cnt["candidates"] > 100_000_000
+
+
 def test_full_size_4096_filters_equal_exact_kernel():
     """BASELINE's 4096^2 pair: the filter + exact-re-evaluation searches (v3 box filter, v2) must reproduce, bit for bit,
     the plain kernel that sends every one of the 3.2e9 candidates through the reference's serial f32
