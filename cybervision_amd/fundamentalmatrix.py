@@ -39,3 +39,180 @@ def find_ransac_affine(device, matches, seed: int = 0):
                                               C.c_void_p(F.ctypes.data), C.byref(cnt), C.c_void_p(mask.ctypes.data)),
                "cvhip_ransac_affine")
     return F.reshape(3, 3), mask[:N].astype(bool)
+
+
+# ---------------------------------------------------------------------------------------------
+# Perspective model: host-side hypothesis generation (numpy), device-side scoring.
+# Mirrors FundamentalMatrix::find_ransac for ProjectionMode::Perspective
+# (src/fundamentalmatrix.rs:103-147, 155-229, 289-449); the reference's RNG is OS-seeded, so
+# parity is statistical - the hypothesis scoring itself is the bit-exact kernel.
+# ---------------------------------------------------------------------------------------------
+TOP_INLIERS = 5000                   # fundamentalmatrix.rs:16
+MIN_INLIER_DISTANCE = 10             # :17
+RANSAC_K_PERSPECTIVE = 1_000_000     # :19
+RANSAC_N_PERSPECTIVE = 7             # :21
+RANSAC_D_PERSPECTIVE = 200           # :25
+RANSAC_D_EARLY_EXIT_PERSPECTIVE = 50_000  # :27
+RANSAC_CHECK_INTERVAL = 50_000       # :28
+RANSAC_RANK_EPSILON_PERSPECTIVE = 0.001   # :30
+
+
+def reprojection_error(F, matches):
+    """fundamentalmatrix.rs:461-471, vectorised over matches [N, 4] (and over F [H, 3, 3] when given)."""
+    F = np.asarray(F, dtype=np.float64)
+    m = np.asarray(matches, dtype=np.float64).reshape(-1, 4)
+    p1 = np.stack([m[:, 0], m[:, 1], np.ones(len(m))], axis=-1)
+    p2 = np.stack([m[:, 2], m[:, 3], np.ones(len(m))], axis=-1)
+    f_p1 = p1 @ np.swapaxes(F, -1, -2)          # (F p1)
+    ft_p2 = p2 @ F                              # (F^T p2)
+    num = np.sum(p2 * f_p1, axis=-1) ** 2
+    den = f_p1[..., 0] ** 2 + f_p1[..., 1] ** 2 + ft_p2[..., 0] ** 2 + ft_p2[..., 1] ** 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return num / den
+
+
+def choose_inliers(matches, count: int, rng):
+    """choose_inliers (:155-175) for `count` samples at once: 7 matches from the top min(N, 5000), pairwise at
+    least 10 px apart in all four coordinates (rejection sampling, vectorised: a sample with a conflict is
+    redrawn whole - same distribution over accepted samples as drawing conflicting members again)."""
+    m = np.asarray(matches, dtype=np.int64).reshape(-1, 4)
+    limit = min(len(m), TOP_INLIERS)
+    out = np.empty((count, RANSAC_N_PERSPECTIVE), dtype=np.int64)
+    todo = np.arange(count)
+    for _ in range(64):
+        if len(todo) == 0:
+            break
+        idx = rng.integers(0, limit, size=(len(todo), RANSAC_N_PERSPECTIVE))
+        pts = m[idx]                                              # [T, 7, 4]
+        d = np.abs(pts[:, :, None, :] - pts[:, None, :, :])       # [T, 7, 7, 4]
+        close = (d < MIN_INLIER_DISTANCE).any(axis=-1)
+        close[:, np.arange(7), np.arange(7)] = False
+        ok = ~close.any(axis=(1, 2))
+        out[todo[ok]] = idx[ok]
+        todo = todo[~ok]
+    return out[np.setdiff1d(np.arange(count), todo)]
+
+
+def calculate_model_perspective(samples):
+    """calculate_model_perspective (:289-389) for a batch of 7-match samples [B, 7, 4] -> (F [K, 3, 3],
+    sample index [K]): null space of the 7x9 system, det(a F1 + (1-a) F2) = 0 cubic, rank and
+    sign-consistency checks, normalised by F[2][2]."""
+    s = np.asarray(samples, dtype=np.float64)
+    B = len(s)
+    x1, y1, x2, y2 = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
+    one = np.ones_like(x1)
+    A = np.stack([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, one], axis=-1)   # [B, 7, 9]
+    _, _, vt = np.linalg.svd(A, full_matrices=True)
+    F1 = vt[:, 7, :].reshape(B, 3, 3)
+    F2 = vt[:, 8, :].reshape(B, 3, 3)
+    FF = np.stack([F1, F2], axis=1)                                                    # [B, 2, 3, 3]
+    # d[i][j][k] = det([F_i col 0, F_j col 1, F_k col 2])  (vgg_singF_from_FF)
+    d = np.empty((B, 2, 2, 2))
+    for i in range(2):
+        for j in range(2):
+            for k in range(2):
+                M = np.stack([FF[:, i, :, 0], FF[:, j, :, 1], FF[:, k, :, 2]], axis=-1)
+                d[:, i, j, k] = np.linalg.det(M)
+    c0 = (-d[:, 1, 0, 0] + d[:, 0, 1, 1] + d[:, 0, 0, 0] + d[:, 1, 1, 0] + d[:, 1, 0, 1] - d[:, 0, 1, 0]
+          - d[:, 0, 0, 1] - d[:, 1, 1, 1])
+    c1 = (d[:, 0, 0, 1] - 2.0 * d[:, 0, 1, 1] - 2.0 * d[:, 1, 0, 1] + d[:, 1, 0, 0] - 2.0 * d[:, 1, 1, 0]
+          + d[:, 0, 1, 0] + 3.0 * d[:, 1, 1, 1])
+    c2 = d[:, 1, 1, 0] + d[:, 0, 1, 1] + d[:, 1, 0, 1] - 3.0 * d[:, 1, 1, 1]
+    c3 = d[:, 1, 1, 1]
+    # real roots of c0 a^3 + c1 a^2 + c2 a + c3 via the companion matrix (find_roots_cubic, :351)
+    good = np.abs(c0) > 1e-300
+    comp = np.zeros((B, 3, 3))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        comp[:, 0, 0] = -c1 / c0
+        comp[:, 0, 1] = -c2 / c0
+        comp[:, 0, 2] = -c3 / c0
+    comp[:, 1, 0] = 1.0
+    comp[:, 2, 1] = 1.0
+    comp[~good] = 0.0
+    ev = np.linalg.eigvals(comp)                                                       # [B, 3] complex
+    real = good[:, None] & (np.abs(ev.imag) <= 1e-9 * np.maximum(1.0, np.abs(ev.real)))
+    bi, ri = np.nonzero(real)
+    a = ev.real[bi, ri]
+    F = a[:, None, None] * F1[bi] + (1.0 - a)[:, None, None] * F2[bi]
+    u, sv, vt2 = np.linalg.svd(np.swapaxes(F, 1, 2))
+    rank_ok = (np.abs(sv[:, 1]) >= RANSAC_RANK_EPSILON_PERSPECTIVE) & (np.abs(sv[:, 2]) <= RANSAC_RANK_EPSILON_PERSPECTIVE)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        F = F / F[:, 2:3, 2:3]
+    # sign consistency (:372-383): e1 = last right singular vector of F^T, l1 = [e1]x x1, s = sum((F x2) * l1)
+    e1 = vt2[:, 2, :]
+    X1 = np.stack([x1[bi], y1[bi], one[bi]], axis=1)                                   # [K, 3, 7]
+    X2 = np.stack([x2[bi], y2[bi], one[bi]], axis=1)
+    l1 = np.cross(e1[:, :, None], X1, axisa=1, axisb=1, axisc=1)
+    # nalgebra's column_sum() adds the COLUMNS (the seven points) - one total per component
+    sgn = np.sum((F @ X2) * l1, axis=2)                                                # [K, 3]
+    sign_ok = (sgn > 0.0).all(axis=1) | (sgn < 0.0).all(axis=1)
+    keep = rank_ok & sign_ok & np.isfinite(F).all(axis=(1, 2))
+    return F[keep], bi[keep]
+
+
+def f_from_perspective_params(p):
+    """:442-449 - det(F) = 0 by construction, 7 degrees of freedom."""
+    x = -(-p[0] * p[4] + p[6] * p[2] * p[4] + p[3] * p[1] - p[6] * p[1] * p[5]) / (-p[3] * p[2] + p[0] * p[5])
+    return np.array([[p[0], p[1], p[2]], [p[3], p[4], p[5]], [p[6], x, 1.0]])
+
+
+def optimize_perspective_f(F, inliers):
+    """optimize_perspective_f (:391-426): Levenberg-Marquardt on the 7 free parameters minimising the
+    reprojection error over `inliers`; None when the result is not rank 2."""
+    from scipy.optimize import least_squares
+
+    p0 = np.array([F[0, 0], F[0, 1], F[0, 2], F[1, 0], F[1, 1], F[1, 2], F[2, 0]])
+    try:
+        res = least_squares(lambda p: reprojection_error(f_from_perspective_params(p), inliers), p0, method="lm", max_nfev=1000)
+    except Exception:
+        return None
+    Fo = f_from_perspective_params(res.x)
+    if not np.isfinite(Fo).all():
+        return None
+    sv = np.linalg.svd(Fo.T, compute_uv=False)
+    if abs(sv[1]) < RANSAC_RANK_EPSILON_PERSPECTIVE or abs(sv[2]) > RANSAC_RANK_EPSILON_PERSPECTIVE:
+        return None
+    return Fo
+
+
+def find_ransac_perspective(device, matches, max_dimension: float, seed: int = 0, k: int = RANSAC_K_PERSPECTIVE,
+                            check_interval: int = RANSAC_CHECK_INTERVAL):
+    """FundamentalMatrix::new(Perspective, max_dimension).find_ransac(matches): rounds of `check_interval`
+    7-point hypotheses generated on the host, every surviving root scored against ALL matches on the device
+    (cvhip_ransac_score - the fold of validate_f :210-216), best = most inliers then smallest mean error
+    (:623-663), early exit above 50 000 inliers, final LM refit on the inliers (optimize_result :231-257).
+    The per-hypothesis LM of validate_f (:205) is skipped: a 7-point solution has zero reprojection error on
+    its own sample, which is that optimisation's fixed point.
+    -> (F [3, 3], inlier_mask [N] bool).  Raises ValueError with the reference's messages."""
+    m = np.ascontiguousarray(np.asarray(matches, dtype=np.uint32).reshape(-1, 4))
+    t = RANSAC_T_PERSPECTIVE * float(max_dimension)
+    if len(m) < RANSAC_D_PERSPECTIVE + RANSAC_N_PERSPECTIVE:
+        raise ValueError("Not enough matches")
+    rng = np.random.default_rng(seed)
+    best = None  # (count, mean error, F)
+    for _ in range(max(k // check_interval, 1)):
+        idx = choose_inliers(m, check_interval, rng)
+        F, _ = calculate_model_perspective(m[idx].astype(np.float64))
+        if len(F):
+            cnt, err = ransac_score(device, F, m, t)
+            ok = cnt >= RANSAC_D_PERSPECTIVE + RANSAC_N_PERSPECTIVE
+            if ok.any():
+                mean = np.where(ok, err / np.maximum(cnt, 1), np.inf)
+                order = np.lexsort((mean, -cnt.astype(np.int64)))
+                j = order[0]
+                cand = (int(cnt[j]), float(mean[j]), F[j])
+                if best is None or (cand[0], -cand[1]) > (best[0], -best[1]):
+                    best = cand
+        if best is not None and best[0] > RANSAC_D_EARLY_EXIT_PERSPECTIVE:
+            break
+    if best is None:
+        raise ValueError("No reliable matches found")
+    Fb = best[2]
+    err = reprojection_error(Fb, m)
+    mask = np.isfinite(err) & (np.abs(err) <= t)
+    Fo = optimize_perspective_f(Fb, m[mask])
+    if Fo is not None:
+        Fb = Fo
+        err = reprojection_error(Fb, m)
+        mask = np.isfinite(err) & (np.abs(err) <= t)
+    return Fb, mask

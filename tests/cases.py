@@ -75,3 +75,30 @@ GOLDEN_CASES = ["tilt3_200x150", "persp_240x180", "ragged_dims"]
 
 def pyramids(case):
     return synth.box_pyramid(case["img1"], case["steps"]), synth.box_pyramid(case["img2"], case["steps"])
+
+
+def perspective_matches(n=4000, outlier_frac=0.3, seed=5, size=2048):
+    """Two pinhole views of random 3-D points (mostly sideways translation, so that the reference's rank test
+    fundamentalmatrix.rs:356-362 accepts the true F), rounded to integer pixels, plus uniform outliers.
+    -> (matches [n, 4] uint32, inlier truth [n] bool, exact coordinates [n, 4] float64, F_true [3, 3])."""
+    rng = np.random.default_rng(seed)
+    f = 0.88 * size
+    K = np.array([[f, 0, size / 2.0], [0, f, size / 2.0], [0, 0, 1.0]])
+    ax, ay = 0.0005, -0.001
+    Ry = np.array([[math.cos(ay), 0, math.sin(ay)], [0, 1, 0], [-math.sin(ay), 0, math.cos(ay)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
+    R = Ry @ Rx
+    t = np.array([1.0, 0.03, 0.02])
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)], axis=1)
+    x1 = (K @ X.T).T
+    x1 = x1[:, :2] / x1[:, 2:]
+    x2 = (K @ ((R @ X.T).T + t).T).T
+    x2 = x2[:, :2] / x2[:, 2:]
+    exact = np.concatenate([x1, x2], axis=1)
+    out = rng.random(n) < outlier_frac
+    m = np.round(exact)
+    m[out, 2:] = rng.integers(0, size, size=(int(out.sum()), 2))
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(K)
+    F = Ki.T @ tx @ R @ Ki
+    return m.clip(0, size - 1).astype(np.uint32), ~out, exact, F / F[2, 2]

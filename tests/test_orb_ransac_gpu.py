@@ -162,6 +162,27 @@ def test_device_affine_ransac_recovers_known_model(gpu_device, oracle):
     assert abs(int(mask3.sum()) - int(mask.sum())) < 0.05 * mask.sum()
 
 
+def test_perspective_ransac_host_generation_device_scoring(gpu_device, oracle):
+    """find_ransac for the perspective model: 7-point hypotheses on the host, every root scored against all
+    matches on the device.  Statistical parity (the reference's RNG is OS-seeded): the planted geometry is
+    recovered, and the returned mask is exactly fits_model of the returned F."""
+    import cases
+
+    m, truth, _, F_true = cases.perspective_matches(n=4000, outlier_frac=0.3)
+    F, mask = fundamentalmatrix.find_ransac_perspective(gpu_device, m, 2048.0, seed=3, k=60_000, check_interval=20_000)
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+    assert F[2, 2] == 1.0 and abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-9
+    assert (mask & truth).sum() > 0.97 * truth.sum() and (mask & ~truth).sum() < 0.1 * (~truth).sum()
+    err_true = np.abs(fundamentalmatrix.reprojection_error(F, m[truth]))
+    assert np.median(err_true) < 1.0  # squared pixels (t = 20.5): integer rounding, plus the few outliers the refit absorbs
+    cnt, _ = oracle.ransac_score(F, m, t)
+    assert cnt[0] == mask.sum()
+    cnt_dev, _ = fundamentalmatrix.ransac_score(gpu_device, F, m, t)
+    assert cnt_dev[0] == mask.sum()
+    with pytest.raises(ValueError, match="Not enough matches"):
+        fundamentalmatrix.find_ransac_perspective(gpu_device, m[:100], 2048.0)
+
+
 def test_device_affine_ransac_error_reporting(gpu_device):
     from cybervision_amd._lib import CvhipError
 
