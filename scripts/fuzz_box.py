@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the box filter (stepped / transposed / lean instantiations, forced and
+host-selected) against the CPU oracle on small pairs: random sizes (incl. differing image dims), tilts around
+both axes, consistent and inconsistent displacement directions, SEM-style noise.  Prints every mismatch."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import torch  # noqa: E402,F401
+
+from cybervision_amd import correlation, synth  # noqa: E402
+from oracle import cvref  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+MAXDIM = int(sys.argv[3]) if len(sys.argv) > 3 else 420
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = correlation.create_gpu_context()
+bad = 0
+for it in range(N):
+    w, h = int(rng.integers(90, MAXDIM)), int(rng.integers(90, MAXDIM))
+    tilt = float(rng.choice([0.0, 0.3, -0.7, 1.5, 3.0, -4.0, 86.0, 89.2, 90.0, 91.0, -88.0, 12.0, 45.0]))
+    consistent = bool(rng.integers(0, 2))
+    seed = int(rng.integers(1, 1000))
+    a, b, _ = synth.make_pair(w, h, seed=seed, sem_style=bool(rng.integers(0, 2)), tilt_deg=tilt if consistent else 0.0)
+    if rng.integers(0, 3) == 0:  # second image larger (the reverse grid has its own dims)
+        b = np.ascontiguousarray(np.pad(b, ((0, int(rng.integers(1, 20))), (0, int(rng.integers(1, 20)))), mode="edge"))
+    proj = int(rng.integers(0, 2)) if abs(tilt) < 5 else 0
+    F = synth.f_tilt(tilt) if tilt != 0.0 else synth.F_HORIZONTAL
+    steps = synth.optimal_scale_steps(a.shape[1], a.shape[0])
+    p1, p2 = synth.box_pyramid(a, steps), synth.box_pyramid(b, steps)
+    want = cvref.correlate_dense(p1, p2, F, proj)
+    for version in (3, 4):
+        pc = correlation.PointCorrelations(dev, (a.shape[1], a.shape[0]), (b.shape[1], b.shape[0]), F,
+                                           correlation.ProjectionMode(proj))
+        pc.set_search_version(version)
+        for i in range(steps + 1):
+            k = steps - i
+            pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+        got = pc.complete()
+        pc.close()
+        ok = (got[0] == want[0]).all()
+        v = want[0][..., 0] >= 0
+        ok = ok and (got[1].view(np.uint32)[v] == want[1].view(np.uint32)[v]).all()
+        if not ok:
+            bad += 1
+            print(f"MISMATCH it={it} version={version} {w}x{h} b={b.shape} tilt={tilt} consistent={consistent} seed={seed} "
+                  f"proj={proj} diff_cells={(got[0] != want[0]).any(axis=-1).sum()}")
+    if it % 10 == 9:
+        print(f"{it + 1} cases, {bad} mismatches", flush=True)
+print(f"done: {N} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
