@@ -58,6 +58,8 @@ SIGNATURES = {
     "cvhip_orb_extract": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cvhip_match_points": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cvhip_ransac_affine": (C.c_int, [_vp, _vp, _u32, C.c_uint64, _vp, C.POINTER(_u32), _vp]),
+    "cvhip_ransac_perspective": (C.c_int, [_vp, _vp, _u32, C.c_double, C.c_uint64, _u32, _vp, C.POINTER(_u32), _vp]),
+    "cvhip_ransac_perspective_models": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp]),
     "cvhip_ransac_score": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp, _vp]),
 }
 

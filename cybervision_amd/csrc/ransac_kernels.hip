@@ -239,6 +239,283 @@ __global__ __launch_bounds__(64) void ransac_generate_affine_kernel(const uint4 
     for (int i = 0; i < 9; i++) F[(size_t)h * 9 + i] = ok ? f[i] : nan; // NaN hypotheses score 0 inliers
 }
 
+// ---------------------------------------------------------------------------------------------
+// Perspective model: hypothesis generation on the device.  Per sample (one thread):
+// calculate_model_perspective (fundamentalmatrix.rs:289-389) - the two-dimensional null space of the
+// 7x9 epipolar system, the cubic det(a F1 + (1 - a) F2) = 0, and per real root the reference's rank test
+// (second singular value >= 1e-3, third <= 1e-3), normalisation by F[2][2] and sign-consistency test -
+// then validate_f's finiteness and sample-fit checks (:197-209).  The null space comes from a Householder
+// QR of A^T (its last two Q columns) instead of an SVD: any basis of the null space gives the same pencil,
+// hence the same F's.  validate_f's per-hypothesis LM (:205) is skipped: a 7-point solution has zero
+// reprojection error on its own sample, that optimisation's fixed point.  Statistical parity, as for the
+// affine model; tests compare this generator with the numpy restatement on identical samples.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double det3(const double (&m)[9])
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// singular values of a 3x3 matrix, descending (eigenvalues of F^T F by cyclic Jacobi)
+__device__ void singular_values3(const double (&f)[9], double (&sv)[3])
+{
+    double m[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) m[i][j] = f[0 * 3 + i] * f[0 * 3 + j] + f[1 * 3 + i] * f[1 * 3 + j] + f[2 * 3 + i] * f[2 * 3 + j];
+    for (int sweep = 0; sweep < 12; sweep++) {
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                if (fabs(m[p][q]) < 1e-300) continue;
+                const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double mkp = m[k][p], mkq = m[k][q];
+                    m[k][p] = c * mkp - sn * mkq;
+                    m[k][q] = sn * mkp + c * mkq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double mpk = m[p][k], mqk = m[q][k];
+                    m[p][k] = c * mpk - sn * mqk;
+                    m[q][k] = sn * mpk + c * mqk;
+                }
+            }
+    }
+    double a = sqrt(fmax(m[0][0], 0.0)), b = sqrt(fmax(m[1][1], 0.0)), c = sqrt(fmax(m[2][2], 0.0));
+    if (a < b) { const double t = a; a = b; b = t; }
+    if (b < c) { const double t = b; b = c; c = t; }
+    if (a < b) { const double t = a; a = b; b = t; }
+    sv[0] = a;
+    sv[1] = b;
+    sv[2] = c;
+}
+
+// real roots of c0 x^3 + c1 x^2 + c2 x + c3 (c0 != 0), polished by Newton steps; returns their number
+__device__ int cubic_real_roots(double c0, double c1, double c2, double c3, double (&r)[3])
+{
+    const double b = c1 / c0, c = c2 / c0, d = c3 / c0;
+    const double p = c - b * b / 3.0, q = 2.0 * b * b * b / 27.0 - b * c / 3.0 + d;
+    const double disc = q * q / 4.0 + p * p * p / 27.0;
+    int n;
+    if (disc > 0.0) {
+        const double sq = sqrt(disc);
+        r[0] = cbrt(-q / 2.0 + sq) + cbrt(-q / 2.0 - sq) - b / 3.0;
+        n = 1;
+    } else if (p == 0.0) {
+        r[0] = -b / 3.0;
+        n = 1;
+    } else {
+        const double rr = 2.0 * sqrt(-p / 3.0);
+        double arg = 3.0 * q / (p * rr);
+        arg = fmin(1.0, fmax(-1.0, arg));
+        const double phi = acos(arg) / 3.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) r[k] = rr * cos(phi - 2.0943951023931953 * (double)k) - b / 3.0;
+        n = 3;
+    }
+    for (int k = 0; k < n; k++) {
+        double x = r[k];
+        for (int it = 0; it < 3; it++) {
+            const double fx = ((c0 * x + c1) * x + c2) * x + c3, dfx = (3.0 * c0 * x + 2.0 * c1) * x + c2;
+            if (dfx != 0.0 && fabs(fx) < __builtin_inf()) x -= fx / dfx;
+        }
+        r[k] = x;
+    }
+    return n;
+}
+
+// -> number of candidate F's written (each normalised by F[2][2]); ok[k] tells which survived the checks
+__device__ int perspective_models_from_sample(const uint4 (&sm)[7], double t, double (&fout)[3][9], bool (&ok)[3])
+{
+    // M = A^T (9 x 7), fundamentalmatrix.rs:293-309; Householder QR, reflectors kept in place
+    double M[9][7], beta[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const double x1 = (double)sm[i].x, y1 = (double)sm[i].y, x2 = (double)sm[i].z, y2 = (double)sm[i].w;
+        M[0][i] = x2 * x1;
+        M[1][i] = x2 * y1;
+        M[2][i] = x2;
+        M[3][i] = y2 * x1;
+        M[4][i] = y2 * y1;
+        M[5][i] = y2;
+        M[6][i] = x1;
+        M[7][i] = y1;
+        M[8][i] = 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        double nrm = 0.0;
+#pragma unroll
+        for (int r = k; r < 9; r++) nrm += M[r][k] * M[r][k];
+        nrm = sqrt(nrm);
+        const double alpha = M[k][k] >= 0.0 ? -nrm : nrm;
+        M[k][k] -= alpha; // v = x - alpha e_k, stored in rows k..8 of column k
+        double vv = 0.0;
+#pragma unroll
+        for (int r = k; r < 9; r++) vv += M[r][k] * M[r][k];
+        beta[k] = vv > 0.0 ? 2.0 / vv : 0.0;
+#pragma unroll
+        for (int c = k + 1; c < 7; c++) {
+            double dot = 0.0;
+#pragma unroll
+            for (int r = k; r < 9; r++) dot += M[r][k] * M[r][c];
+            dot *= beta[k];
+#pragma unroll
+            for (int r = k; r < 9; r++) M[r][c] -= dot * M[r][k];
+        }
+    }
+    // null space of A = last two columns of Q = H0 H1 ... H6 applied to e7, e8
+    double n1[9], n2[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        n1[r] = r == 7 ? 1.0 : 0.0;
+        n2[r] = r == 8 ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int r = k; r < 9; r++) {
+            d1 += M[r][k] * n1[r];
+            d2 += M[r][k] * n2[r];
+        }
+        d1 *= beta[k];
+        d2 *= beta[k];
+#pragma unroll
+        for (int r = k; r < 9; r++) {
+            n1[r] -= d1 * M[r][k];
+            n2[r] -= d2 * M[r][k];
+        }
+    }
+    // d[i][j][k] = det([F_i col 0, F_j col 1, F_k col 2]) (vgg_singF_from_FF, :326-337)
+    double d[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                double m[9];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    m[r * 3 + 0] = i ? n2[r * 3 + 0] : n1[r * 3 + 0];
+                    m[r * 3 + 1] = j ? n2[r * 3 + 1] : n1[r * 3 + 1];
+                    m[r * 3 + 2] = k ? n2[r * 3 + 2] : n1[r * 3 + 2];
+                }
+                d[i][j][k] = det3(m);
+            }
+    const double c0 = -d[1][0][0] + d[0][1][1] + d[0][0][0] + d[1][1][0] + d[1][0][1] - d[0][1][0] - d[0][0][1] - d[1][1][1];
+    const double c1 = d[0][0][1] - 2.0 * d[0][1][1] - 2.0 * d[1][0][1] + d[1][0][0] - 2.0 * d[1][1][0] + d[0][1][0] + 3.0 * d[1][1][1];
+    const double c2 = d[1][1][0] + d[0][1][1] + d[1][0][1] - 3.0 * d[1][1][1];
+    const double c3 = d[1][1][1];
+    ok[0] = ok[1] = ok[2] = false;
+    if (!(fabs(c0) > 1e-300) || !(fabs(c0) < __builtin_inf())) return 0;
+    double roots[3];
+    const int nr = cubic_real_roots(c0, c1, c2, c3, roots);
+    for (int k = 0; k < nr; k++) {
+        const double a = roots[k];
+        double f[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) f[i] = a * n1[i] + (1.0 - a) * n2[i]; // :359
+        double sv[3];
+        singular_values3(f, sv);
+        bool good = !(sv[1] < 0.001) && !(sv[2] > 0.001); // :362-366
+        // e1: null vector of F^T (last right singular vector of svd(F^T), :372-373) = normal of F's columns
+        double e1[3], best = -1.0;
+#pragma unroll
+        for (int pr = 0; pr < 3; pr++) {
+            const int ca = pr == 2 ? 1 : 0, cb = pr == 0 ? 1 : 2;
+            const double ax = f[0 + ca], ay = f[3 + ca], az = f[6 + ca], bx = f[0 + cb], by = f[3 + cb], bz = f[6 + cb];
+            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            const double nn = cx * cx + cy * cy + cz * cz;
+            if (nn > best) {
+                best = nn;
+                e1[0] = cx;
+                e1[1] = cy;
+                e1[2] = cz;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) fout[k][i] = f[i] / f[8]; // :369
+        // sign consistency (:374-383): s = sum over the seven points of (F x2) .* (e1 x x1), per component
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const double x1 = (double)sm[i].x, y1 = (double)sm[i].y, x2 = (double)sm[i].z, y2 = (double)sm[i].w;
+            const double l0 = e1[1] * 1.0 - e1[2] * y1, l1 = e1[2] * x1 - e1[0] * 1.0, l2 = e1[0] * y1 - e1[1] * x1;
+            const double g0 = fout[k][0] * x2 + fout[k][1] * y2 + fout[k][2], g1 = fout[k][3] * x2 + fout[k][4] * y2 + fout[k][5],
+                         g2 = fout[k][6] * x2 + fout[k][7] * y2 + fout[k][8];
+            s0 += g0 * l0;
+            s1 += g1 * l1;
+            s2 += g2 * l2;
+        }
+        good = good && ((s0 > 0.0 && s1 > 0.0 && s2 > 0.0) || (s0 < 0.0 && s1 < 0.0 && s2 < 0.0));
+#pragma unroll
+        for (int i = 0; i < 9; i++) good = good && fabs(fout[k][i]) < __builtin_inf(); // validate_f, :197-199
+        if (good) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) { // all sample points must fit, :206-209
+                const double err = reprojection_error(fout[k], (double)sm[i].x, (double)sm[i].y, (double)sm[i].z, (double)sm[i].w);
+                good = good && fabs(err) < __builtin_inf() && !(fabs(err) > t);
+            }
+        }
+        ok[k] = good;
+    }
+    return nr;
+}
+
+// three hypothesis slots per sample; slots without a surviving root hold NaN (they score 0 inliers).
+// sample_idx != nullptr: the caller's samples (7 match indices each) instead of choose_inliers (test hook).
+__global__ __launch_bounds__(64) void ransac_generate_perspective_kernel(const uint4 *__restrict__ matches, uint32_t limit,
+                                                                          double t, unsigned long long seed,
+                                                                          uint32_t round, uint32_t H,
+                                                                          const uint32_t *__restrict__ sample_idx,
+                                                                          double *__restrict__ F)
+{
+    const uint32_t h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    uint4 sm[7];
+    int have = 0;
+    if (sample_idx) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) sm[i] = matches[sample_idx[(size_t)h * 7 + i]];
+        have = 7;
+    } else {
+        unsigned long long state = mix64(seed ^ mix64(((unsigned long long)round << 32) | h));
+        for (int tries = 0; tries < 512 && have < 7; tries++) { // choose_inliers, :155-175 (bounded here)
+            state = mix64(state + 0x9E3779B97F4A7C15ull);
+            const uint32_t idx = (uint32_t)(((state >> 32) * (unsigned long long)limit) >> 32);
+            const uint4 nm = matches[idx];
+            bool close = false;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const uint4 c = sm[i];
+                auto dist = [](uint32_t a, uint32_t b) { return a > b ? a - b : b - a; };
+                close = close || (i < have && (dist(nm.x, c.x) < 10u || dist(nm.y, c.y) < 10u || dist(nm.z, c.z) < 10u || dist(nm.w, c.w) < 10u));
+            }
+            if (!close) {
+#pragma unroll
+                for (int i = 0; i < 7; i++)
+                    if (i == have) sm[i] = nm;
+                have++;
+            }
+        }
+    }
+    double f[3][9];
+    bool ok[3] = {false, false, false};
+    if (have == 7) perspective_models_from_sample(sm, t, f, ok);
+    const double nan = __builtin_nan("");
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 9; i++) F[((size_t)h * 3 + k) * 9 + i] = ok[k] ? f[k][i] : nan;
+}
+
 struct RansacBest {
     double f[9];
     double best_error;
@@ -438,4 +715,118 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     (void)hipFree(d_mask);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("ransac_affine: ") + hipGetErrorString(e));
     return rc;
+}
+
+// Shared driver of the two RANSAC models: rounds of `per_round` samples x `slots` hypotheses each.
+namespace {
+template <typename Generate>
+int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
+                  double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
+                  uint8_t *out_inlier_mask, const char *what, Generate generate)
+{
+    hipStream_t s = dev->d.stream;
+    const uint32_t H = per_round * slots;
+    uint32_t *d_m = nullptr, *d_cnt = nullptr;
+    double *d_F = nullptr, *d_err = nullptr;
+    RansacBest *d_best = nullptr;
+    uint8_t *d_mask = nullptr;
+    hipError_t e = hipMalloc(&d_m, (size_t)N * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_F, (size_t)H * 9 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)H * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_err, (size_t)H * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_best, sizeof(RansacBest));
+    if (e == hipSuccess) e = hipMalloc(&d_mask, N);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
+    RansacBest h_best;
+    std::memset(&h_best, 0, sizeof(h_best));
+    const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
+    for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
+        generate(m4, round, d_F, s);
+        launch_ransac_score(d_F, H, d_m, N, t, d_cnt, d_err, s);
+        hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, H, min_count, d_best);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (h_best.valid && h_best.matches_count > early_exit) break; // :135-141
+    }
+    int rc = CVHIP_OK;
+    if (e == hipSuccess && !h_best.valid) rc = fail(CVHIP_ERR_NO_MODEL, "No reliable matches found"); // :145
+    if (e == hipSuccess && rc == CVHIP_OK) {
+        std::memcpy(out_F, h_best.f, sizeof(h_best.f));
+        hipLaunchKernelGGL(ransac_inlier_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_best, m4, N, t, d_mask);
+        e = hipGetLastError();
+        std::vector<uint8_t> h_mask(N);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_mask.data(), d_mask, N, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < N; i++) cnt += h_mask[i];
+            if (out_inlier_count) *out_inlier_count = cnt;
+            if (out_inlier_mask) std::memcpy(out_inlier_mask, h_mask.data(), N);
+        }
+    }
+    (void)hipFree(d_m);
+    (void)hipFree(d_F);
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_err);
+    (void)hipFree(d_best);
+    (void)hipFree(d_mask);
+    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    return rc;
+}
+} // namespace
+
+extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension,
+                                        uint64_t seed, uint32_t rounds, double *out_F, uint32_t *out_inlier_count,
+                                        uint8_t *out_inlier_mask)
+{
+    // constants of the perspective model, fundamentalmatrix.rs:16-30
+    constexpr uint32_t RANSAC_K = 1000000, CHECK_INTERVAL = 50000, RANSAC_N = 7, RANSAC_D = 200, EARLY_EXIT = 50000,
+                       TOP_INLIERS = 5000;
+    if (!dev || !matches || !out_F) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (!(max_dimension > 0.0)) return fail(CVHIP_ERR_INVALID, "max_dimension must be positive");
+    if (N < RANSAC_D + RANSAC_N) return fail(CVHIP_ERR_NO_MODEL, "Not enough matches"); // :107-109
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    const double t = 10.0 / 1000.0 * max_dimension; // :23, :85
+    const uint32_t limit = std::min(N, TOP_INLIERS);
+    if (rounds == 0 || rounds > RANSAC_K / CHECK_INTERVAL) rounds = RANSAC_K / CHECK_INTERVAL;
+    return ransac_rounds(dev, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
+                         out_inlier_count, out_inlier_mask, "ransac_perspective",
+                         [&](const uint4 *m4, uint32_t round, double *d_F, hipStream_t s) {
+                             hipLaunchKernelGGL(ransac_generate_perspective_kernel, dim3((CHECK_INTERVAL + 63) / 64), dim3(64),
+                                                0, s, m4, limit, t, (unsigned long long)seed, round, CHECK_INTERVAL,
+                                                (const uint32_t *)nullptr, d_F);
+                         });
+}
+
+extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t *matches, uint32_t N,
+                                               const uint32_t *sample_idx, uint32_t B, double t, double *out_F)
+{
+    if (!dev || !matches || !sample_idx || !out_F) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (B == 0) return CVHIP_OK;
+    for (size_t i = 0; i < (size_t)B * 7; i++)
+        if (sample_idx[i] >= N) return fail(CVHIP_ERR_INVALID, "sample index out of range");
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    uint32_t *d_m = nullptr, *d_idx = nullptr;
+    double *d_F = nullptr;
+    hipError_t e = hipMalloc(&d_m, (size_t)N * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_idx, (size_t)B * 7 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_F, (size_t)B * 27 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, sample_idx, (size_t)B * 7 * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ransac_generate_perspective_kernel, dim3((B + 63) / 64), dim3(64), 0, s,
+                           reinterpret_cast<const uint4 *>(d_m), N, t, 0ull, 0u, B, (const uint32_t *)d_idx, d_F);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_F, d_F, (size_t)B * 27 * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_m);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_F);
+    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("ransac_perspective_models: ") + hipGetErrorString(e));
+    return CVHIP_OK;
 }

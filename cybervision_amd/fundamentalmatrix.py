@@ -216,3 +216,38 @@ def find_ransac_perspective(device, matches, max_dimension: float, seed: int = 0
         err = reprojection_error(Fb, m)
         mask = np.isfinite(err) & (np.abs(err) <= t)
     return Fb, mask
+
+
+def perspective_models_device(device, matches, sample_idx, t: float):
+    """cvhip_ransac_perspective_models: the device generator on caller-chosen samples [B, 7] -> F [B, 3, 3, 3]
+    (NaN where a root does not exist or fails a check)."""
+    m = np.ascontiguousarray(np.asarray(matches, dtype=np.uint32).reshape(-1, 4))
+    idx = np.ascontiguousarray(np.asarray(sample_idx, dtype=np.uint32).reshape(-1, 7))
+    out = np.zeros((len(idx), 3, 3, 3), dtype=np.float64)
+    p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    _lib.check(_lib.lib().cvhip_ransac_perspective_models(device.handle, p(m), len(m), p(idx), len(idx), float(t), p(out)),
+               "cvhip_ransac_perspective_models")
+    return out
+
+
+def find_ransac_perspective_device(device, matches, max_dimension: float, seed: int = 0, rounds: int = 0, refit: bool = True):
+    """find_ransac for the perspective model with hypothesis generation, scoring and best-pick all on the device
+    (cvhip_ransac_perspective); the final LM refit of optimize_result (:246-256) runs here on the host.
+    -> (F [3, 3], inlier_mask [N] bool).  Raises CvhipError (code -5) with the reference's messages."""
+    m = np.ascontiguousarray(np.asarray(matches, dtype=np.uint32).reshape(-1, 4))
+    N = len(m)
+    F = np.zeros(9, dtype=np.float64)
+    mask = np.zeros(max(N, 1), dtype=np.uint8)
+    cnt = C.c_uint32(0)
+    _lib.check(_lib.lib().cvhip_ransac_perspective(device.handle, C.c_void_p(m.ctypes.data), N, float(max_dimension), seed,
+                                                   rounds, C.c_void_p(F.ctypes.data), C.byref(cnt), C.c_void_p(mask.ctypes.data)),
+               "cvhip_ransac_perspective")
+    F = F.reshape(3, 3)
+    mask = mask[:N].astype(bool)
+    if refit:
+        Fo = optimize_perspective_f(F, m[mask])
+        if Fo is not None:
+            t = RANSAC_T_PERSPECTIVE * float(max_dimension)
+            err = reprojection_error(Fo, m)
+            F, mask = Fo, np.isfinite(err) & (np.abs(err) <= t)
+    return F, mask

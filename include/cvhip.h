@@ -236,6 +236,24 @@ int cvhip_ransac_score(cvhip_device *dev, const double *F, uint32_t H, const uin
 int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint64_t seed, double *out_F,
                         uint32_t *out_inlier_count, uint8_t *out_inlier_mask);
 
+/* Perspective RANSAC on the device — FundamentalMatrix::new(Perspective, max_dimension).find_ransac
+ * (fundamentalmatrix.rs:72-147, 155-229, 289-389): per sample the 7-point model (null space of the 7x9
+ * system, the determinant cubic, the reference's rank and sign-consistency checks, up to three roots),
+ * every surviving root scored against ALL matches, best = most inliers then smallest mean error, early
+ * exit above 50 000 inliers; t = 0.01 * max_dimension.  `rounds` = number of 50 000-sample rounds (0 or
+ * more than 20 = the reference's 20).  Not done here: validate_f's per-hypothesis LM (:205; a 7-point
+ * solution has zero reprojection error on its own sample, that optimisation's fixed point) and the final
+ * LM refit of optimize_result (:246-256), which stays with the caller.  out_F: the best hypothesis
+ * (normalised by F[2][2]); mask/count: its inliers.  Statistical parity, as above. */
+int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension,
+                             uint64_t seed, uint32_t rounds, double *out_F, uint32_t *out_inlier_count,
+                             uint8_t *out_inlier_mask);
+/* Test hook of the generator above: the models of B caller-chosen samples (sample_idx: 7 match indices
+ * each, host memory) -> out_F: B x 3 x 9 doubles, NaN where a root does not exist or fails a check;
+ * t as in fits_model.  Compared against the numpy restatement on identical samples. */
+int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t *matches, uint32_t N, const uint32_t *sample_idx,
+                                    uint32_t B, double t, double *out_F);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,6 +183,52 @@ def test_perspective_ransac_host_generation_device_scoring(gpu_device, oracle):
         fundamentalmatrix.find_ransac_perspective(gpu_device, m[:100], 2048.0)
 
 
+def test_device_perspective_generator_matches_numpy_on_identical_samples(gpu_device):
+    """The device's 7-point generator (Householder null space, closed-form cubic, Jacobi singular values)
+    against the numpy restatement of calculate_model_perspective (SVD, companion eigenvalues) on the same
+    samples: the same surviving roots, the same F up to 1e-7 relative."""
+    import cases
+
+    m, _, _, _ = cases.perspective_matches(n=3000, outlier_frac=0.2, seed=11)
+    rng = np.random.default_rng(4)
+    idx = fundamentalmatrix.choose_inliers(m, 4000, rng)
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+    got = fundamentalmatrix.perspective_models_device(gpu_device, m, idx, t)          # [B, 3, 3, 3]
+    F_np, which = fundamentalmatrix.calculate_model_perspective(m[idx].astype(np.float64))
+    n_dev = np.isfinite(got[:, :, 0, 0]).sum()
+    assert abs(int(n_dev) - len(F_np)) <= 0.02 * len(F_np) and len(F_np) > 500  # borderline rank/sign cases may differ
+    matched = 0
+    for Fi, b in zip(F_np, which):
+        cand = got[b][np.isfinite(got[b][:, 0, 0])]
+        if len(cand) == 0:
+            continue
+        rel = np.abs(cand - Fi).reshape(len(cand), -1).max(axis=1) / np.abs(Fi).max()
+        if rel.min() < 1e-7:
+            matched += 1
+    assert matched > 0.97 * len(F_np)
+
+
+def test_device_perspective_ransac_recovers_planted_geometry(gpu_device, oracle):
+    import cases
+
+    m, truth, _, _ = cases.perspective_matches(n=4000, outlier_frac=0.3)
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+    F0, mask0 = fundamentalmatrix.find_ransac_perspective_device(gpu_device, m, 2048.0, seed=5, rounds=2, refit=False)
+    assert F0[2, 2] == 1.0
+    cnt, _ = oracle.ransac_score(F0, m, t)
+    assert cnt[0] == mask0.sum()  # the mask is exactly fits_model of the returned F
+    assert (mask0 & truth).sum() > 0.95 * truth.sum()
+    F, mask = fundamentalmatrix.find_ransac_perspective_device(gpu_device, m, 2048.0, seed=5, rounds=2)
+    assert (mask & truth).sum() > 0.97 * truth.sum() and (mask & ~truth).sum() < 0.1 * (~truth).sum()
+    assert np.median(np.abs(fundamentalmatrix.reprojection_error(F, m[truth]))) < 1.0
+    F2, mask2 = fundamentalmatrix.find_ransac_perspective_device(gpu_device, m, 2048.0, seed=5, rounds=2, refit=False)
+    assert (F2 == F0).all() and (mask2 == mask0).all()  # reproducible for a fixed seed
+    from cybervision_amd._lib import CvhipError
+    with pytest.raises(CvhipError) as ei:
+        fundamentalmatrix.find_ransac_perspective_device(gpu_device, m[:100], 2048.0)
+    assert ei.value.code == -5 and "Not enough matches" in str(ei.value)
+
+
 def test_device_affine_ransac_error_reporting(gpu_device):
     from cybervision_amd._lib import CvhipError
 
