@@ -231,12 +231,11 @@ struct FundamentalMatrixResult { // fundamentalmatrix.rs:57-61
 // FundamentalMatrix (fundamentalmatrix.rs:63-257) for the affine model.  Sampling and the 4-point fit
 // run on the host exactly as in the reference (rejection sampling from the top 5000 matches, >= 10 px
 // apart; mean-centred 4x4 smallest right-singular vector); all hypotheses of one check interval are
-// scored on the GPU in one call.  The perspective model (7-point + LM refinement,
-// fundamentalmatrix.rs:289-449, 515-621) stays with the caller for now: find_ransac throws
-// RansacError for it (SURVEY.md §8f rank 3 moves hypothesis generation to the device).
+// scored on the GPU in one call.  The perspective model (7-point, fundamentalmatrix.rs:289-389) runs
+// entirely on the device (cvhip_ransac_perspective); its final LM refit (:391-426, 515-621) is not done.
 class FundamentalMatrix {
   public:
-    FundamentalMatrix(ProjectionMode projection, double max_dimension) : projection_(projection)
+    FundamentalMatrix(ProjectionMode projection, double max_dimension) : projection_(projection), max_dimension_(max_dimension)
     {
         // fundamentalmatrix.rs:16-30, 72-101
         ransac_k_ = 1000000;
@@ -257,14 +256,27 @@ class FundamentalMatrix {
                                         uint64_t seed = std::random_device{}()) const
     {
         if (point_matches.size() < ransac_d_ + ransac_n_) throw RansacError("Not enough matches");
-        if (projection_ != ProjectionMode::Affine)
-            throw RansacError("perspective hypothesis generation is not part of this library yet");
         std::vector<uint32_t> flat(4 * point_matches.size());
         for (size_t i = 0; i < point_matches.size(); i++) {
             flat[4 * i] = (uint32_t)point_matches[i].first.x;
             flat[4 * i + 1] = (uint32_t)point_matches[i].first.y;
             flat[4 * i + 2] = (uint32_t)point_matches[i].second.x;
             flat[4 * i + 3] = (uint32_t)point_matches[i].second.y;
+        }
+        if (projection_ != ProjectionMode::Affine) {
+            // Perspective: sampling, the 7-point model and its checks, scoring and best-pick all run on the device
+            // (cvhip_ransac_perspective).  The final LM refit of optimize_result (:246-256) is not part of it:
+            // the result is the best RANSAC hypothesis and its inliers.
+            FundamentalMatrixResult res;
+            std::vector<uint8_t> mask(point_matches.size());
+            uint32_t cnt = 0;
+            const int rc = cvhip_ransac_perspective(dev.handle(), flat.data(), (uint32_t)point_matches.size(), max_dimension_,
+                                                    seed, 0, res.f.data(), &cnt, mask.data());
+            if (rc == CVHIP_ERR_NO_MODEL) throw RansacError(cvhip_last_error());
+            check(rc, "cvhip_ransac_perspective");
+            for (size_t i = 0; i < point_matches.size(); i++)
+                if (mask[i]) res.inliers.push_back(point_matches[i]);
+            return res;
         }
         std::mt19937_64 rng(seed); // the reference seeds SmallRng from the OS: runs are not reproducible there
         const size_t check_interval = 50000, outer = ransac_k_ / check_interval;
@@ -433,6 +445,7 @@ class FundamentalMatrix {
     }
 
     ProjectionMode projection_;
+    double max_dimension_;
     size_t ransac_k_, ransac_n_, ransac_d_, ransac_d_early_exit_;
     double ransac_t_;
 };

@@ -95,14 +95,16 @@ int main(int argc, char **argv)
                     "\"dense_valid\": %zu, \"levels\": %zu}\n",
                     dev.name().c_str(), kp1.size(), kp2.size(), matching.matches.size(), fr.inliers.size(), valid,
                     steps + 1);
-        // error behaviour: a perspective request surfaces as RansacError, a bad image as GpuError
+        // error behaviour: too few matches for the perspective model (207) surface as RansacError with the
+        // reference's text, a bad image as GpuError
         bool threw = false;
         try {
-            FundamentalMatrix(ProjectionMode::Perspective, 1000.0).find_ransac(dev, matching.matches, 1);
-        } catch (const RansacError &) {
-            threw = true;
+            std::vector<PointMatch> few(matching.matches.begin(), matching.matches.begin() + 50);
+            FundamentalMatrix(ProjectionMode::Perspective, 1000.0).find_ransac(dev, few, 1);
+        } catch (const RansacError &e) {
+            threw = std::string(e.what()).find("Not enough matches") != std::string::npos;
         }
-        if (!threw) throw std::runtime_error("perspective find_ransac did not report an error");
+        if (!threw) throw std::runtime_error("perspective find_ransac did not report 'Not enough matches'");
         threw = false;
         try {
             PointCorrelations bad(dev, {4, 4}, {4, 4}, f_h, ProjectionMode::Affine);
