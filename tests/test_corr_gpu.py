@@ -299,15 +299,17 @@ def test_full_size_properties_1024(gpu_device):
         assert ((np.abs(win[:, 0] - x) <= 4) & (np.abs(win[:, 1] - y) <= 4)).any()
 
 
-def test_row_sharded_equals_unsharded(gpu_device, oracle):
+@pytest.mark.parametrize("name", ["tilt3_200x150", "vert_200x260", "h256", "tilt60_150x200"])
+def test_row_sharded_equals_unsharded(gpu_device, oracle, name):
     """Two row-sharded contexts (shard 0/2 and 1/2) on one GPU, bands exchanged between their
     level grids after every search pass exactly as the RCCL all-gather would: the result must be
-    bit-identical to the unsharded run (and so to the oracle)."""
+    bit-identical to the unsharded run (and so to the oracle).  The cases cover the stepped, transposed and
+    lean box-filter instantiations and the candidate filter, each on a row range that does not start at 0."""
     import torch
 
     from cybervision_amd import sharding
 
-    c = cases.make_case("tilt3_200x150")
+    c = cases.make_case(name)
     p1, p2 = cases.pyramids(c)
     h1, w1 = c["img1"].shape
     h2, w2 = c["img2"].shape
