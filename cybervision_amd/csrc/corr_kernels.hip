@@ -1891,7 +1891,7 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
 // match (x2, y2) is the full-res match (x2, y2) << k, so the window test reduces to +-4 level
 // cells.  Each thread owns one cell of `own` and only reads `other`.
 // ---------------------------------------------------------------------------------------------
-constexpr int CC_ROWS = 2; // rows per thread: independent load chains in flight (the kernel is latency-bound)
+constexpr int CC_ROWS = 1; // rows per thread (more than one only lengthens the chain of dependent round trips)
 
 __global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ own, const uint2 *__restrict__ other,
                                                            uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
