@@ -414,6 +414,20 @@ def test_box_filter_variants_equal_exact_kernel_1024(gpu_device, tilt):
     assert vf.mean() > 0.7 and cnt["candidates"] > 100_000_000
 
 
+def test_box_filter_perspective_parameter_set_equals_exact_kernel_1024(gpu_device):
+    """Nine stripes, threshold 0.5 (the perspective parameter set, mod.rs:127-133) on a rectified pair: the box
+    filter then runs its second plane group (planes 5..8); against the plain exact kernel, both directions."""
+    a, b, _ = synth.make_pair(1024, 1024, seed=41, sem_style=True)
+    steps = synth.optimal_scale_steps(1024, 1024)
+    c = dict(img1=a, img2=b, F=synth.F_HORIZONTAL, projection=1, steps=steps)
+    (fxy, fc), (rxy, rc) = run_gpu(gpu_device, c, both=True)
+    (fxy1, fc1), (rxy1, rc1) = run_gpu(gpu_device, c, both=True, version=1)
+    assert (fxy == fxy1).all() and (rxy == rxy1).all()
+    vf, vr = fxy1[..., 0] >= 0, rxy1[..., 0] >= 0
+    assert (bits(fc)[vf] == bits(fc1)[vf]).all() and (bits(rc)[vr] == bits(rc1)[vr]).all()
+    assert vf.mean() > 0.7
+
+
 def test_full_size_4096_filters_equal_exact_kernel():
     """BASELINE's 4096^2 pair: the filter + exact-re-evaluation searches (v3 box filter, v2) must reproduce, bit for bit,
     the plain kernel that sends every one of the 3.2e9 candidates through the reference's serial f32
