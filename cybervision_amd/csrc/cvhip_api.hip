@@ -72,8 +72,19 @@ static void free_ctx_buffers(cvhip_ctx *c)
         c->stats[d] = nullptr;
     }
     if (c->range) (void)hipFree(c->range);
+    if (c->range_rev) (void)hipFree(c->range_rev);
     if (c->contenders) (void)hipFree(c->contenders);
-    c->contenders = nullptr;
+    if (c->contenders_rev) (void)hipFree(c->contenders_rev);
+    c->contenders = c->contenders_rev = nullptr;
+    c->range_rev = nullptr;
+    if (c->aux_stream) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        (void)hipStreamDestroy(c->aux_stream);
+        c->aux_stream = nullptr;
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    c->ev_fork = c->ev_join = nullptr;
     if (c->work) (void)hipFree(c->work);
     c->work = nullptr;
     if (c->d_cand) (void)hipFree(c->d_cand);
@@ -87,9 +98,9 @@ static void free_ctx_buffers(cvhip_ctx *c)
 }
 
 // Bracket a launch with HIP events on the context's stream when kernel timing is on.
-template <typename F> static int timed(cvhip_ctx *c, int cls, F &&launch)
+template <typename F> static int timed(cvhip_ctx *c, int cls, F &&launch, hipStream_t s = nullptr)
 {
-    hipStream_t s = c->dev->d.stream;
+    if (!s) s = c->dev->d.stream;
     if (!c->time_kernels) {
         launch();
         return CVHIP_OK;
@@ -133,10 +144,12 @@ static void shard_rows(const cvhip_ctx *c, uint32_t lh, uint32_t *row0, uint32_t
 // One search pass (mod.rs:247-319) given level images already staged in c->img[a] (searched)
 // and c->img[b] (target) with their window statistics in c->stats[a], c->stats[b].
 static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2,
-                       float scale, int k, int first_pass, int dir, bool zero_counts = true)
+                       float scale, int k, int first_pass, int dir, bool zero_counts = true, hipStream_t s = nullptr)
 {
     DirState &ds = c->dir[dir];
-    hipStream_t s = c->dev->d.stream;
+    if (!s) s = c->dev->d.stream;
+    uint32_t *range = dir == 0 ? c->range : c->range_rev;
+    unsigned long long *contenders = dir == 0 ? c->contenders : c->contenders_rev;
     if (lw1 != (ds.gw >> k) || lh1 != (ds.gh >> k))
         return fail(CVHIP_ERR_UNSUPPORTED, "level dims must be floor(full * scale) (reconstruction.rs:146-152)");
     if (!first_pass) {
@@ -180,11 +193,11 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
     unsigned long long *cnt = c->count_candidates ? c->d_cand : nullptr;
     if (!first_pass)
-        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->stats[a], ds.cells[prev], c->range, s); }));
+        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->stats[a], ds.cells[prev], range, s); }, s));
     if (c->search_version == 1) {
         CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-            launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], c->range, ds.cells[next], cnt, s);
-        }));
+            launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], range, ds.cells[next], cnt, s);
+        }, s));
     } else {
         if (!(p.debug & 2)) {
             // Version 3: the box filter is the search; the candidate filter only walks the workgroups it declines
@@ -208,30 +221,31 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
                 // box filter -> one persistent fallback kernel over the tiles it declined and the tiles with
                 // whole-corridor pixels (work lists filled by the producers)
                 uint32_t *wc = c->work + 4 * dir;
-                const WorkList declined{wc, c->work + 8};
-                const WorkList whole{wc + 1, c->work + 8 + c->work_cap};
+                uint32_t *items = c->work + 8 + (size_t)dir * 2 * c->work_cap; // per-direction item arrays
+                const WorkList declined{wc, items};
+                const WorkList whole{wc + 1, items + c->work_cap};
                 // both directions' counts are zeroed once per level by cvhip_correlate_level; per-pass callers zero here
                 if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(wc, 0, 4 * sizeof(uint32_t), s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     // exactly axis-parallel lines never step: the leaner instantiation
-                    launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                       c->contenders, ds.cells[next], cnt, f_minor != 0.0 || c->force_box, transposed,
+                    launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                                       contenders, ds.cells[next], cnt, f_minor != 0.0 || c->force_box, transposed,
                                        declined, whole, s);
-                }));
+                }, s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                    launch_search3_fallback(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                            c->contenders, ds.cells[next], cnt, declined, whole, (p.debug & 1) != 0, s);
-                }));
+                    launch_search3_fallback(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                                            contenders, ds.cells[next], cnt, declined, whole, (p.debug & 1) != 0, s);
+                }, s));
             } else {
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                    launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], c->range,
-                                          c->contenders, ds.cells[next], cnt, s);
-                }));
+                    launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                                          contenders, ds.cells[next], cnt, s);
+                }, s));
                 if (!(p.debug & 1))
                     CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                        launch_search2_exact(p, c->img[a], c->img[b], c->stats[a], c->istats[b], c->range, c->contenders,
+                        launch_search2_exact(p, c->img[a], c->img[b], c->stats[a], c->istats[b], range, contenders,
                                              ds.cells[next], cnt, s);
-                    }));
+                    }, s));
             }
         }
     }
@@ -415,9 +429,14 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         if (e == hipSuccess) e = hipMalloc(&c->istats[d], c->max_px * sizeof(uint2));
     }
     if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->range_rev, c->max_px * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->contenders, c->max_px * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->contenders_rev, c->max_px * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     c->work_cap = 2 * search3_worklist_capacity(std::max(w1, w2), std::max(h1, h2));
-    if (e == hipSuccess) e = hipMalloc(&c->work, (8 + 2 * c->work_cap) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->work, (8 + 4 * c->work_cap) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
@@ -518,7 +537,20 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         ctx->shard_den = 1;
     }
     CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 8 * sizeof(uint32_t), s)); // work-list counts and flags of both passes
-    int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, false); // mod.rs:224-230
+    // The two search passes of a level are independent (each reads only its own direction's previous grid and
+    // writes only its own), so unless a gather has to run between them the reverse pass goes to a second
+    // stream: on the small levels - and on the short bands of a many-GPU run - neither fills the GPU alone.
+    // Only where one pass leaves the GPU partly idle (<= 1 M searched pixels: ~5 k workgroups for 1.5 k resident
+    // ones); the big levels keep their launches back to back, which also keeps their per-kernel timings clean.
+    hipStream_t s_rev = s;
+    uint64_t pass_px = (uint64_t)w1 * h1;
+    if (ctx->band_mode) pass_px = (uint64_t)w1 * (ctx->band[k].sf[1] - ctx->band[k].sf[0]);
+    if (!sharded && ctx->aux_stream && pass_px <= (1u << 20)) {
+        CVHIP_TRY_HIP(hipEventRecord(ctx->ev_fork, s));
+        CVHIP_TRY_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        s_rev = ctx->aux_stream;
+    }
+    int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, false, s); // mod.rs:224-230
     if (rc == CVHIP_OK && sharded) {
         const DirState &ds = ctx->dir[0];
         const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);
@@ -526,7 +558,12 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
             rc = fail(CVHIP_ERR_DEVICE, "all-gather hook failed (forward grid)");
     }
     report(progress, user, 0, 1.0f);
-    if (rc == CVHIP_OK) rc = search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, false); // mod.rs:231-237
+    if (rc == CVHIP_OK) rc = search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, false, s_rev); // mod.rs:231-237
+    if (s_rev != s) { // join, also on the error path, before anything else touches the shared inputs
+        const hipError_t ej = hipEventRecord(ctx->ev_join, s_rev);
+        const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_join, 0) : ej;
+        if (ew != hipSuccess && rc == CVHIP_OK) rc = fail(CVHIP_ERR_DEVICE, std::string("joining the reverse pass: ") + hipGetErrorString(ew));
+    }
     if (rc == CVHIP_OK && sharded) {
         const DirState &ds = ctx->dir[1];
         const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);

@@ -140,8 +140,11 @@ struct cvhip_ctx {
     // 3 = displacement-plane box filter (falls back to 2 per workgroup) + exact re-evaluation
     int search_version = 3;
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
-    uint32_t *range = nullptr;
-    unsigned long long *contenders = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
+    // per-direction scratch of a search pass (the two passes of a level are independent and run on two streams)
+    uint32_t *range = nullptr, *range_rev = nullptr;
+    unsigned long long *contenders = nullptr, *contenders_rev = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
+    hipStream_t aux_stream = nullptr; // the reverse pass of cvhip_correlate_level, forked from / joined to the device's stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *work = nullptr;                 // tile work lists: per direction {declined n, whole n, declined scan, whole scan}, then two item arrays
     size_t work_cap = 0;                      // items per list
     size_t max_px = 0;
