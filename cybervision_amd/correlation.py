@@ -166,7 +166,8 @@ class PointCorrelations:
         return pts[:n.value].copy(), p2[:n.value].copy()
 
     # -- measurement / sharding hooks -----------------------------------------------------------
-    def set_profiling(self, time_kernels: bool, count_candidates: bool):
+    def set_profiling(self, time_kernels, count_candidates: bool):
+        """time_kernels: 0/False off, 1/True every kernel class, 2 the search class only (include/cvhip.h)."""
         _lib.check(_lib.lib().cvhip_ctx_set_profiling(self._h, int(time_kernels), int(count_candidates)),
                    "cvhip_ctx_set_profiling")
 

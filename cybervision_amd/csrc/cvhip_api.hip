@@ -101,7 +101,8 @@ static void free_ctx_buffers(cvhip_ctx *c)
 template <typename F> static int timed(cvhip_ctx *c, int cls, F &&launch, hipStream_t s = nullptr)
 {
     if (!s) s = c->dev->d.stream;
-    if (!c->time_kernels) {
+    // time_kernels: 0 = off, 1 = every class, 2 = the search class only
+    if (!c->time_kernels || (c->time_kernels == 2 && cls != cvhip_ctx::K_SEARCH)) {
         launch();
         return CVHIP_OK;
     }
