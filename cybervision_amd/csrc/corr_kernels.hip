@@ -166,16 +166,32 @@ __device__ __forceinline__ uint32_t corridor_end_of(const CorrParams &p, const L
 // evaluated on the reference's own f32 stdev.
 constexpr int WS_PITCH = 88; // bytes per staged row: 64 + 2*5 window columns, dword aligned start, padded
 
-__global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
-                                                            uint32_t row0, uint32_t row1, float min_stdev,
-                                                            float2 *__restrict__ stats, uint2 *__restrict__ istats)
+struct StatsJob { // one image's statistics pass
+    const uint8_t *img;
+    uint32_t w, h, row0, row1;
+    float2 *stats;
+    uint2 *istats;
+};
+
+// Both images of a level in one launch (blockIdx.z picks the image; the grid covers the larger one).  zero_words:
+// eight u32 cleared by the first thread - the work-list counts of the level's two search passes, which start
+// after this kernel on the same stream.
+__global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob jb, float min_stdev,
+                                                            uint32_t *__restrict__ zero_words)
 {
     // The 64x4 tile's 74x14 source bytes are staged once in LDS (one dword load per thread instead of 33
     // unaligned loads per pixel, which made the kernel address-unit-bound); each lane then reads its 12
     // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.
     __shared__ uint32_t tile[14 * (WS_PITCH / 4)];
+    if (zero_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) zero_words[threadIdx.x] = 0u;
+    const StatsJob &job = blockIdx.z == 0 ? ja : jb;
+    const uint8_t *__restrict__ img = job.img;
+    const uint32_t w = job.w, h = job.h, row0 = job.row0, row1 = job.row1;
+    float2 *__restrict__ stats = job.stats;
+    uint2 *__restrict__ istats = job.istats;
     const TileId tid = xcd_tile();
     const uint32_t x0 = tid.x * 64, y0 = row0 + tid.y * 4;
+    if (x0 >= w || y0 >= row1) return; // the grid covers the larger image
     const int sx = (int)x0 - 8, sy = (int)y0 - KERNEL_SIZE; // staged origin; sx is 0 mod 4 relative to x0
     for (uint32_t u = threadIdx.x; u < 14u * (WS_PITCH / 4); u += 256) {
         const uint32_t r = u / (WS_PITCH / 4), c4 = (u - r * (WS_PITCH / 4)) * 4;
@@ -220,13 +236,20 @@ __global__ __launch_bounds__(256) void window_stats_kernel(const uint8_t *__rest
     istats[(size_t)y * w + x] = iout;
 }
 
-void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, uint32_t row0, uint32_t row1, float min_stdev,
-                         float2 *stats, uint2 *istats, hipStream_t s)
+void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, float2 *stats_a, uint2 *istats_a,
+                              const uint8_t *img_b, uint32_t wb, uint32_t hb, float2 *stats_b, uint2 *istats_b,
+                              uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s)
 {
-    row1 = min(row1, h);
-    if (row1 <= row0) return;
-    dim3 grid((w + 63) / 64, (row1 - row0 + 3) / 4);
-    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, img, w, h, row0, row1, min_stdev, stats, istats);
+    const StatsJob ja{img_a, wa, ha, row0, row1 < ha ? row1 : ha, stats_a, istats_a};
+    const StatsJob jb{img_b, wb, hb, row0, row1 < hb ? row1 : hb, stats_b, istats_b};
+    const uint32_t rows_a = ja.row1 > row0 ? ja.row1 - row0 : 0u, rows_b = jb.row1 > row0 ? jb.row1 - row0 : 0u;
+    const uint32_t rows = rows_a > rows_b ? rows_a : rows_b;
+    if (rows == 0) {
+        if (zero_words) (void)hipMemsetAsync(zero_words, 0, 8 * sizeof(uint32_t), s);
+        return;
+    }
+    dim3 grid(((wa > wb ? wa : wb) + 63) / 64, (rows + 3) / 4, 2);
+    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, ja, jb, min_stdev, zero_words);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1893,10 +1916,21 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
 // ---------------------------------------------------------------------------------------------
 constexpr int CC_ROWS = 1; // rows per thread (more than one only lengthens the chain of dependent round trips)
 
-__global__ __launch_bounds__(256) void cross_check_kernel(uint2 *__restrict__ own, const uint2 *__restrict__ other,
-                                                           uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
-                                                           uint32_t row0)
+struct CrossJob { // one direction's cross-check: `own` is filtered against `other`
+    uint2 *own;
+    const uint2 *other;
+    uint32_t ow, oh, rw, rh, row0; // oh = end of the row range handled, row0 its start
+};
+
+// One or both directions of a level in one launch (blockIdx.z).  The two filters may run side by side: a
+// match's supporters are exactly the matches it supports, so neither ever removes a cell the other one needs and
+// each decision depends on the UNFILTERED other grid only.
+__global__ __launch_bounds__(256) void cross_check_kernel(CrossJob ja, CrossJob jb)
 {
+    const CrossJob &job = blockIdx.z == 0 ? ja : jb;
+    uint2 *__restrict__ own = job.own;
+    const uint2 *__restrict__ other = job.other;
+    const uint32_t ow = job.ow, oh = job.oh, rw = job.rw, rh = job.rh, row0 = job.row0;
     // oh = end of the row range handled by this launch, row0 its start
     const TileId tid = xcd_tile();
     const uint32_t x = tid.x * 64 + (threadIdx.x & 63);
@@ -1954,8 +1988,25 @@ void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh
 {
     row1 = min(row1, oh);
     if (row1 <= row0) return;
-    dim3 grid((ow + 63) / 64, (row1 - row0 + 4 * CC_ROWS - 1) / (4 * CC_ROWS));
-    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, own, other, ow, row1, rw, rh, row0);
+    dim3 grid((ow + 63) / 64, (row1 - row0 + 4 * CC_ROWS - 1) / (4 * CC_ROWS), 1);
+    const CrossJob j{own, other, ow, row1, rw, rh, row0};
+    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, j, j);
+}
+
+// forward and reverse cross-check of a level in one launch
+void launch_cross_check_pair(uint2 *fwd, uint2 *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
+                             uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s)
+{
+    f_row1 = f_row1 < fh ? f_row1 : fh;
+    r_row1 = r_row1 < rh ? r_row1 : rh;
+    const uint32_t rows_f = f_row1 > f_row0 ? f_row1 - f_row0 : 0u, rows_r = r_row1 > r_row0 ? r_row1 - r_row0 : 0u;
+    const uint32_t rows_max = rows_f > rows_r ? rows_f : rows_r;
+    if (rows_max == 0) return;
+    // an empty range is expressed as oh = row0 (every thread of that slice exits)
+    const CrossJob jf{fwd, rev, fw, rows_f ? f_row1 : f_row0, rw, rh, f_row0};
+    const CrossJob jr{rev, fwd, rw, rows_r ? r_row1 : r_row0, fw, fh, r_row0};
+    dim3 grid(((fw > rw ? fw : rw) + 63) / 64, (rows_max + 4 * CC_ROWS - 1) / (4 * CC_ROWS), 2);
+    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, jf, jr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -480,8 +480,8 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
             sr1 = ctx->band[k].st[1];
         }
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats(ctx->img[0], w1, h1, sr0, sr1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
-            launch_window_stats(ctx->img[1], w2, h2, sr0, sr1, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+            launch_window_stats_pair(ctx->img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->img[1], w2, h2, ctx->stats[1],
+                                     ctx->istats[1], sr0, sr1, ctx->min_stdev, nullptr, s);
         }));
     }
     report(progress, user, dir, 0.20f);
@@ -525,9 +525,10 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
             sr0 = ctx->band[k].st[0];
             sr1 = ctx->band[k].st[1];
         }
+        // both images in one launch, which also clears the work-list counts of the level's two search passes
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats(ctx->img[0], w1, h1, sr0, sr1, ctx->min_stdev, ctx->stats[0], ctx->istats[0], s);
-            launch_window_stats(ctx->img[1], w2, h2, sr0, sr1, ctx->min_stdev, ctx->stats[1], ctx->istats[1], s);
+            launch_window_stats_pair(ctx->img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->img[1], w2, h2, ctx->stats[1],
+                                     ctx->istats[1], sr0, sr1, ctx->min_stdev, ctx->work, s);
         }));
     }
     report(progress, user, 0, 0.20f);
@@ -537,7 +538,6 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         ctx->shard_num = 0;
         ctx->shard_den = 1;
     }
-    CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 8 * sizeof(uint32_t), s)); // work-list counts and flags of both passes
     // The two search passes of a level are independent (each reads only its own direction's previous grid and
     // writes only its own), so unless a gather has to run between them the reverse pass goes to a second
     // stream: on the small levels - and on the short bands of a many-GPU run - neither fills the GPU alone.
@@ -575,8 +575,24 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     ctx->shard_den = den;
     CVHIP_TRY(rc);
     report(progress, user, 1, 1.0f);
-    CVHIP_TRY(cross_check_pass(ctx, k, 0)); // mod.rs:239
-    CVHIP_TRY(cross_check_pass(ctx, k, 1)); // mod.rs:240
+    // mod.rs:239-240: forward then reverse cross-check.  They commute and each depends only on the unfiltered
+    // other grid, so one launch runs both.
+    {
+        DirState &df = ctx->dir[0], &dr = ctx->dir[1];
+        if (!df.valid || !dr.valid || (int)df.k != k || (int)dr.k != k)
+            return fail(CVHIP_ERR_INVALID, "cross-check before both passes of the level ran");
+        uint32_t f0 = 0, f1 = df.lh, r0 = 0, r1 = dr.lh;
+        if (ctx->band_mode) {
+            f0 = std::min(ctx->band[k].cf[0], df.lh);
+            f1 = std::min(ctx->band[k].cf[1], df.lh);
+            r0 = std::min(ctx->band[k].cr[0], dr.lh);
+            r1 = std::min(ctx->band[k].cr[1], dr.lh);
+        }
+        CVHIP_TRY(timed(ctx, cvhip_ctx::K_CROSS, [&] {
+            launch_cross_check_pair(df.cells[df.cur], dr.cells[dr.cur], df.lw, df.lh, dr.lw, dr.lh, f0, f1, r0, r1, s);
+        }));
+        CVHIP_TRY_HIP(hipGetLastError());
+    }
     if (!is_device_ptr(img1) || !is_device_ptr(img2)) CVHIP_TRY_HIP(hipStreamSynchronize(s));
     return CVHIP_OK;
 }

@@ -67,8 +67,9 @@ struct WorkList {
     uint32_t *count;
     uint32_t *items;
 };
-void launch_window_stats(const uint8_t *img, uint32_t w, uint32_t h, uint32_t row0, uint32_t row1, float min_stdev,
-                         float2 *stats, uint2 *istats, hipStream_t s);
+void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, float2 *stats_a, uint2 *istats_a,
+                              const uint8_t *img_b, uint32_t wb, uint32_t hb, float2 *stats_b, uint2 *istats_b,
+                              uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s);
 void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
                          hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
@@ -91,6 +92,8 @@ void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_
                           uint2 *out, unsigned long long *counters, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
+void launch_cross_check_pair(uint2 *fwd, uint2 *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
+                             uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s);
 void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                         int32_t *out_xy, float *out_corr, hipStream_t s);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
