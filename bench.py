@@ -97,13 +97,21 @@ def main():
     steps = synth.optimal_scale_steps(W, H)
     pyr1 = synth.box_pyramid(img1, steps)
     pyr2 = synth.box_pyramid(img2, steps)
-    d1 = [torch.from_numpy(p).cuda() for p in pyr1]
-    d2 = [torch.from_numpy(p).cuda() for p in pyr2]
+    def resident(p):
+        # u8 level image in HBM with 64 readable bytes behind it, so that the library can use it in place
+        # (cvhip_ctx_set_borrow_inputs) instead of copying it into its own padded buffer on every call
+        buf = torch.zeros(p.size + 64, dtype=torch.uint8, device="cuda")
+        buf[:p.size].copy_(torch.from_numpy(p).reshape(-1))
+        return buf[:p.size].view(p.shape[0], p.shape[1])
+
+    d1 = [resident(p) for p in pyr1]
+    d2 = [resident(p) for p in pyr2]
     level_dims = [(p.shape[1], p.shape[0], q.shape[1], q.shape[0]) for p, q in zip(pyr1, pyr2)]
 
     stream = torch.cuda.current_stream()
     dev = correlation.create_gpu_context(ordinal=local_rank, stream=stream.cuda_stream)
     pc = correlation.PointCorrelations(dev, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
+    pc.set_borrow_inputs(True)
     band_mode = False
     final_gather = None
     sim = None

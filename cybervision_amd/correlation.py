@@ -191,6 +191,11 @@ class PointCorrelations:
         return {"candidates": arr[0], "exact_evals": arr[1], "multi_contender_pixels": arr[2],
                 "whole_corridor_pixels": arr[3]}
 
+    def set_borrow_inputs(self, borrow: bool):
+        """Device-resident level images are used in place (no copy): the caller guarantees 64 readable bytes after
+        the last pixel of each and keeps them unchanged until the call's work has completed (include/cvhip.h)."""
+        _lib.check(_lib.lib().cvhip_ctx_set_borrow_inputs(self._h, int(borrow)), "cvhip_ctx_set_borrow_inputs")
+
     def set_search_version(self, version: int):
         _lib.check(_lib.lib().cvhip_ctx_set_search_version(self._h, version), "cvhip_ctx_set_search_version")
 

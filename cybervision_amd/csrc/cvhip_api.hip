@@ -142,6 +142,23 @@ static void shard_rows(const cvhip_ctx *c, uint32_t lh, uint32_t *row0, uint32_t
     *row1 = std::min(lh, r0 + rpr);
 }
 
+// Level images of a call: copied into the context's padded buffers - or, when the caller has vouched for the
+// padding of its device buffers (cvhip_ctx_set_borrow_inputs), used where they are.
+static int stage_images(cvhip_ctx *c, const uint8_t *img1, size_t n1, const uint8_t *img2, size_t n2, hipStream_t s)
+{
+    const uint8_t *src[2] = {img1, img2};
+    const size_t n[2] = {n1, n2};
+    for (int d = 0; d < 2; d++) {
+        if (c->borrow_inputs && is_device_ptr(src[d])) {
+            c->cur_img[d] = src[d];
+        } else {
+            CVHIP_TRY(copy_in(c->img[d], src[d], n[d], s));
+            c->cur_img[d] = c->img[d];
+        }
+    }
+    return CVHIP_OK;
+}
+
 // One search pass (mod.rs:247-319) given level images already staged in c->img[a] (searched)
 // and c->img[b] (target) with their window statistics in c->stats[a], c->stats[b].
 static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2,
@@ -197,7 +214,7 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->stats[a], ds.cells[prev], range, s); }, s));
     if (c->search_version == 1) {
         CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-            launch_search(p, c->img[a], c->img[b], c->stats[a], c->stats[b], range, ds.cells[next], cnt, s);
+            launch_search(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->stats[b], range, ds.cells[next], cnt, s);
         }, s));
     } else {
         if (!(p.debug & 2)) {
@@ -229,22 +246,22 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
                 if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(wc, 0, 4 * sizeof(uint32_t), s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     // exactly axis-parallel lines never step: the leaner instantiation
-                    launch_search3_box(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                    launch_search3_box(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[a], c->istats[b], range,
                                        contenders, ds.cells[next], cnt, f_minor != 0.0 || c->force_box, transposed,
                                        declined, whole, s);
                 }, s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                    launch_search3_fallback(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                    launch_search3_fallback(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[a], c->istats[b], range,
                                             contenders, ds.cells[next], cnt, declined, whole, (p.debug & 1) != 0, s);
                 }, s));
             } else {
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                    launch_search2_filter(p, c->img[a], c->img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                    launch_search2_filter(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[a], c->istats[b], range,
                                           contenders, ds.cells[next], cnt, s);
                 }, s));
                 if (!(p.debug & 1))
                     CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                        launch_search2_exact(p, c->img[a], c->img[b], c->stats[a], c->istats[b], range, contenders,
+                        launch_search2_exact(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[b], range, contenders,
                                              ds.cells[next], cnt, s);
                     }, s));
             }
@@ -470,8 +487,7 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
-    CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s)); // transfer_in_images, gpu/mod.rs:274
-    CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
+    CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s)); // transfer_in_images, gpu/mod.rs:274
     report(progress, user, dir, 0.02f);
     {
         uint32_t sr0 = 0, sr1 = std::max(h1, h2);
@@ -480,7 +496,7 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
             sr1 = ctx->band[k].st[1];
         }
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats_pair(ctx->img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->img[1], w2, h2, ctx->stats[1],
+            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->cur_img[1], w2, h2, ctx->stats[1],
                                      ctx->istats[1], sr0, sr1, ctx->min_stdev, nullptr, s);
         }));
     }
@@ -517,8 +533,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         return fail(CVHIP_ERR_INVALID, "row-sharded context without an all-gather hook (cvhip_ctx_set_row_shard)");
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
-    CVHIP_TRY(copy_in(ctx->img[0], img1, (size_t)w1 * h1, s));
-    CVHIP_TRY(copy_in(ctx->img[1], img2, (size_t)w2 * h2, s));
+    CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s));
     {
         uint32_t sr0 = 0, sr1 = std::max(h1, h2);
         if (ctx->band_mode) {
@@ -527,7 +542,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         }
         // both images in one launch, which also clears the work-list counts of the level's two search passes
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats_pair(ctx->img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->img[1], w2, h2, ctx->stats[1],
+            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->cur_img[1], w2, h2, ctx->stats[1],
                                      ctx->istats[1], sr0, sr1, ctx->min_stdev, ctx->work, s);
         }));
     }
@@ -877,6 +892,13 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset)
     CVHIP_TRY_HIP(hipMemcpy(v, ctx->d_cand, sizeof(v), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) out[i] = (uint64_t)v[i];
     if (reset) CVHIP_TRY_HIP(hipMemset(ctx->d_cand, 0, sizeof(v)));
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    ctx->borrow_inputs = borrow != 0;
     return CVHIP_OK;
 }
 

@@ -137,6 +137,8 @@ struct cvhip_ctx {
 
     cvhip::DirState dir[2];
     uint8_t *img[2] = {nullptr, nullptr}; // level image staging (padded), [0]=searched [1]=target of the call
+    const uint8_t *cur_img[2] = {nullptr, nullptr}; // the images the current call works on: img[] or the caller's own
+    bool borrow_inputs = false;                     // cvhip_ctx_set_borrow_inputs
     float2 *stats[2] = {nullptr, nullptr};
     uint2 *istats[2] = {nullptr, nullptr};
     // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,

@@ -159,6 +159,13 @@ int cvhip_ctx_set_row_band(cvhip_ctx *ctx, uint32_t num, uint32_t den);
 int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, uint32_t *lh, uint32_t *row0,
                          uint32_t *row1, uint32_t *rows_per_shard);
 
+/* Use device-resident level images where they are instead of copying them into the context's own padded
+ * buffers first.  By enabling this the caller guarantees, for every DEVICE pointer it passes as a level image:
+ * at least 64 readable bytes after the last pixel (the kernels read whole dwords at row ends), and that the
+ * image stays unchanged until the work of the call has completed on the device's stream.  Host images are
+ * still copied.  Off by default. */
+int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow);
+
 /* Measurement hooks (bench.py).  time_kernels: 1 = every kernel launch is bracketed by HIP events on the
  * stream it is launched on, 2 = only the launches of the search class ([2] below), 0 = off.  Timing is
  * not free: with any timing event in flight the runtime profiles every dispatch of the step (~4 us per
