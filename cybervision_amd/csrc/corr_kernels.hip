@@ -116,7 +116,8 @@ struct Line {
 __device__ __forceinline__ Line epipolar_line(const CorrParams &p, uint32_t px, uint32_t py)
 {
     const double scale = (double)p.scale;
-    const double p0 = (double)px / scale, p1 = (double)py / scale;
+    // p / scale (mod.rs:389-391) with scale = 2^-k: the quotient is exact, and so is this product
+    const double up = (double)(1u << p.k), p0 = (double)px * up, p1 = (double)py * up;
     double f[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -267,17 +268,23 @@ void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, fl
 // ---------------------------------------------------------------------------------------------
 constexpr int SR_TILE_W = 80, SR_TILE_H = 24; // LDS window of previous-level cells per workgroup
 constexpr int SR_WIN = 11;                    // cells per axis of one pixel's window, consecutive levels
+// sum path: block m's window is the SRF_TAPS x SRF_TAPS cells m-5 .. m+4 (see search_range_kernel); zero-padded
+// cell window of a 64 x 4 block tile: columns bx0-5 .. bx0+67, rows by0-5 .. by0+7
+constexpr int SRF_TAPS = 10, SRF_LEFT = 5;
+constexpr int SRF_W = 64 + SRF_TAPS - 1, SRF_H = 4 + SRF_TAPS - 1, SRF_PITCH = SRF_W;
+static_assert(SRF_PITCH == SRF_W, "the staging loop writes cell u at word u");
 
 __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x, uint32_t y, uint32_t &xs0,
                                                 uint32_t &xs1, uint32_t &ys0, uint32_t &ys1)
 {
     // mod.rs:481-491, window in FULL-RES cells, then the occupied (previous-level) cells inside it:
     // full-res X = x' << pk with x' < pw
-    const float scale = p.scale;
-    uint32_t x_min = f32_to_u32_sat(floorf((float)sat_sub_u32(x, NEIGHBOR_DISTANCE) / scale));
-    uint32_t x_max = f32_to_u32_sat(ceilf((float)(x + NEIGHBOR_DISTANCE) / scale));
-    uint32_t y_min = f32_to_u32_sat(floorf((float)sat_sub_u32(y, NEIGHBOR_DISTANCE) / scale));
-    uint32_t y_max = f32_to_u32_sat(ceilf((float)(y + NEIGHBOR_DISTANCE) / scale));
+    // v / scale in f32 with scale = 2^-k and v < 2^24: exact, equal to v * 2^k
+    const float up = (float)(1u << p.k);
+    uint32_t x_min = f32_to_u32_sat(floorf((float)sat_sub_u32(x, NEIGHBOR_DISTANCE) * up));
+    uint32_t x_max = f32_to_u32_sat(ceilf((float)(x + NEIGHBOR_DISTANCE) * up));
+    uint32_t y_min = f32_to_u32_sat(floorf((float)sat_sub_u32(y, NEIGHBOR_DISTANCE) * up));
+    uint32_t y_max = f32_to_u32_sat(ceilf((float)(y + NEIGHBOR_DISTANCE) * up));
     x_min = min(x_min, p.gw);
     x_max = min(x_max, p.gw);
     y_min = min(y_min, p.gh);
@@ -297,27 +304,20 @@ __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x,
 // only for perspective geometry, each get their own axis' statistics.)
 __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const float2 *__restrict__ stats1,
                                                             const uint2 *__restrict__ prev,
-                                                            uint32_t *__restrict__ range)
+                                                            uint32_t *__restrict__ range, int mode)
 {
-    __shared__ uint32_t cells[SR_TILE_W * SR_TILE_H + SR_WIN]; // + slack for the predicated row reads
+    // chain path: raw cells of the tile's window (+ slack for the predicated row reads);
+    // sum path: the same words hold FA | FB | HA | HB (see below)
+    __shared__ uint32_t lds[2 * SRF_H * SRF_PITCH + 2 * SRF_H * 64];
+    __shared__ uint32_t axis_vote;
+    static_assert(2 * SRF_H * SRF_PITCH + 2 * SRF_H * 64 >= SR_TILE_W * SR_TILE_H + SR_WIN, "LDS plan");
+    uint32_t *const cells = lds;
     // tile of 64 x 4 blocks = pixels [128*bx0 - 1, 128*bx0 + 127] x [by_first*2 - 1, ...]
     const TileId tid = xcd_tile();
     const uint32_t bxi = tid.x * 64 + (threadIdx.x & 63);
     const uint32_t byi = (p.row0 >> 1) + tid.y * 4 + (threadIdx.x >> 6);
     const uint32_t tile_x0 = tid.x * 128, tile_y0 = ((p.row0 >> 1) + tid.y * 4) * 2;
-    // window of the whole tile = union of its corner pixels' windows (the bounds are monotone in x, y)
-    uint32_t tx0, tx1, ty0, ty1, ux0, ux1, uy0, uy1;
-    neighbor_window(p, sat_sub_u32(tile_x0, 1), sat_sub_u32(tile_y0, 1), tx0, ux1, ty0, uy1);
-    neighbor_window(p, min(tile_x0 + 126, p.w1 - 1), min(tile_y0 + 6, p.h1 - 1), ux0, tx1, uy0, ty1);
-    const uint32_t tw = tx1 > tx0 ? tx1 - tx0 : 0u, th = ty1 > ty0 ? ty1 - ty0 : 0u;
-    const bool staged = tw <= (uint32_t)SR_TILE_W && th <= (uint32_t)SR_TILE_H;
-    if (staged) {
-        for (uint32_t u = threadIdx.x; u < tw * th; u += 256) {
-            const uint32_t r = u / tw, c = u - r * tw;
-            cells[r * SR_TILE_W + c] = prev[(size_t)(ty0 + r) * p.pw + (tx0 + c)].x;
-        }
-    }
-    __syncthreads();
+    if (threadIdx.x == 0) axis_vote = 0u;
 
     // the (up to) four pixels of this block and their per-pixel tests (mod.rs:334-345)
     uint32_t px[4], py[4];
@@ -334,6 +334,24 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
     const Line e0 = epipolar_line(p, 0u, 0u);
     const double fdom = fabs(p.F[2]) > fabs(p.F[5]) ? fabs(p.F[2]) : fabs(p.F[5]);
     const bool quick = affine_f && fdom > 1e-150 && fdom < 1e150 && finite_f64(e0.cx) && finite_f64(e0.cy);
+    // sum path (below) of an affine F: its cell loads do not depend on the per-pixel tests, so they are issued first
+    // and the two round trips to memory overlap
+    const bool params_ok = p.min_range >= 0.0 && p.min_range < 1e9 && p.extend_range >= 0.0 && p.extend_range < 1e9;
+    // positions of the previous level are < max(w2, h2) / 2 + 1 <= 4097: 100 squares fit 32 bits, 100 values 22 bits
+    const bool sums_ok = mode != 1 && shared && params_ok && p.w2 <= 8192u && p.h2 <= 8192u;
+    const int tile_bx0 = (int)(tid.x * 64), tile_by0 = (int)((p.row0 >> 1) + tid.y * 4);
+    constexpr int SRF_PER_THREAD = (SRF_H * SRF_W + 255) / 256;
+    auto load_cell = [&](uint32_t u) -> uint32_t {
+        const uint32_t r = u / SRF_W, c = u - r * SRF_W;
+        const int gx = tile_bx0 - SRF_LEFT + (int)c, gy = tile_by0 - SRF_LEFT + (int)r;
+        const bool in = u < (uint32_t)(SRF_H * SRF_W) && gx >= 0 && gy >= 0 && (uint32_t)gx < p.pw && (uint32_t)gy < p.ph;
+        return in ? prev[(size_t)gy * p.pw + (uint32_t)gx].x : CELL_NONE;
+    };
+    uint32_t early[SRF_PER_THREAD] = {};
+    if (quick && sums_ok) {
+#pragma unroll
+        for (int i = 0; i < SRF_PER_THREAD; i++) early[i] = load_cell(threadIdx.x + 256u * i);
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         px[q] = 2 * bxi + (q & 1) - 1; // wraps to 0xFFFFFFFF for bxi == 0, q even: rejected below
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
         Line e = e0;
         bool line_ok = false;
         if (quick) {
-            const double sc = (double)p.scale, p0 = (double)x / sc, p1 = (double)y / sc; // exact: scale = 2^-k
+            const double up = (double)(1u << p.k), p0 = (double)x * up, p1 = (double)y * up; // = x / scale, exact
             double f2 = p.F[6] * p0;
             f2 = p.F[7] * p1 + f2;
             f2 = p.F[8] * 1.0 + f2;
@@ -364,6 +382,79 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
         cend[q] = corridor_end_of(p, e);
         axis[q] = e.ox == 1 ? 1 : 0;
         any_valid = true;
+    }
+
+    // Which corridor axes do the valid pixels of this workgroup use?  None: nothing to scan.  Exactly one (always,
+    // for affine F) and consecutive levels: the windows of neighbouring blocks overlap in all but one column / row, and
+    // count, sum and sum of squares of the corridor positions are integers, so they are taken as separable 10-tap box
+    // sums over the tile (2 x 10 LDS reads per block instead of 2 x 100) and the f64 chain of mod.rs:515-529 is only
+    // run where the integer result leaves the rounding of mod.rs:532 open (sum_stats below).
+    // (Affine F: F*p has the same first two components for every pixel, so the axis is e0's and no vote is needed;
+    // a tile without valid pixels then stages cells for nothing.)
+    uint32_t vote = e0.ox == 1 ? 2u : 1u;
+    if (!quick) {
+        uint32_t my = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) my |= valid[q] ? 1u << axis[q] : 0u;
+        const uint32_t wave_axes = (__ballot(my & 1u) ? 1u : 0u) | (__ballot(my & 2u) ? 2u : 0u);
+        __syncthreads(); // axis_vote = 0 is visible
+        if ((threadIdx.x & 63) == 0 && wave_axes) atomicOr(&axis_vote, wave_axes);
+        __syncthreads();
+        vote = axis_vote;
+    }
+    const bool sums = sums_ok && (vote == 1u || vote == 2u);
+    uint32_t *const FA = lds, *const FB = lds + SRF_H * SRF_PITCH, *const HA = lds + 2 * SRF_H * SRF_PITCH,
+                    *const HB = HA + SRF_H * 64;
+    bool staged = false;
+    uint32_t tx0 = 0, ty0 = 0;
+    uint32_t win_a = 0, win_b = 0; // this block's window: count << 22 | sum of positions, sum of squared positions
+    if (vote == 0u) {
+        // no valid pixel in the tile
+    } else if (sums) {
+        const uint32_t ash = vote == 2u ? 16u : 0u;
+#pragma unroll
+        for (int i = 0; i < SRF_PER_THREAD; i++) {
+            const uint32_t u = threadIdx.x + 256u * i;
+            const uint32_t cell = quick ? early[i] : load_cell(u);
+            const uint32_t v = (cell >> ash) & 0xFFFFu;
+            if (u < (uint32_t)(SRF_H * SRF_W)) {
+                FA[u] = cell != CELL_NONE ? (1u << 22) | v : 0u; // SRF_PITCH == SRF_W
+                FB[u] = cell != CELL_NONE ? v * v : 0u;
+            }
+        }
+        __syncthreads();
+        for (uint32_t u = threadIdx.x; u < (uint32_t)(SRF_H * 64); u += 256) {
+            const uint32_t r = u >> 6, c = u & 63u;
+            uint32_t sa = 0u, sb = 0u;
+#pragma unroll
+            for (int j = 0; j < SRF_TAPS; j++) {
+                sa += FA[r * SRF_PITCH + c + j];
+                sb += FB[r * SRF_PITCH + c + j];
+            }
+            HA[u] = sa;
+            HB[u] = sb;
+        }
+        __syncthreads();
+        const uint32_t r0 = threadIdx.x >> 6, c = threadIdx.x & 63u;
+#pragma unroll
+        for (int j = 0; j < SRF_TAPS; j++) {
+            win_a += HA[(r0 + j) * 64 + c];
+            win_b += HB[(r0 + j) * 64 + c];
+        }
+    } else {
+        // window of the whole tile = union of its corner pixels' windows (the bounds are monotone in x, y)
+        uint32_t tx1, ty1, ux0, ux1, uy0, uy1;
+        neighbor_window(p, sat_sub_u32(tile_x0, 1), sat_sub_u32(tile_y0, 1), tx0, ux1, ty0, uy1);
+        neighbor_window(p, min(tile_x0 + 126, p.w1 - 1), min(tile_y0 + 6, p.h1 - 1), ux0, tx1, uy0, ty1);
+        const uint32_t tw = tx1 > tx0 ? tx1 - tx0 : 0u, th = ty1 > ty0 ? ty1 - ty0 : 0u;
+        staged = tw <= (uint32_t)SR_TILE_W && th <= (uint32_t)SR_TILE_H;
+        if (staged) {
+            for (uint32_t u = threadIdx.x; u < tw * th; u += 256) {
+                const uint32_t r = u / tw, c = u - r * tw;
+                cells[r * SR_TILE_W + c] = prev[(size_t)(ty0 + r) * p.pw + (tx0 + c)].x;
+            }
+        }
+        __syncthreads();
     }
 
     // neighbour statistics per corridor axis; res[a] = {center, length} or invalid
@@ -434,6 +525,65 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
             length[a] = f64_to_u32_sat(round(p.min_range + range_stdev * p.extend_range));
         }
     };
+    // The same statistics from the integer box sums.  With n cells at positions c_i = v_i << up:
+    //   mean = fl(sum c_i / n) as in the chain;   T = n * sum v_i^2 - (sum v_i)^2 = n * sum (v_i - mean_v)^2, exact.
+    // The chain's sum S of rounded squared deviations from the rounded mean satisfies S = (4^up T / n)(1 + e),
+    // |e| <= (n + 2) 2^-53 (sum of non-negative terms; the rounded mean adds n (mean 2^-53)^2, far below that because
+    // T >= n - 1 when T != 0), so sqrt(S / n), times extend_range, plus min_range is within 67 * 2^-53 relative of
+    // L = min_range + extend_range * 2^up sqrt(T) / n, and L as evaluated here within 5 * 2^-53.  round() of the two
+    // agrees unless L is within 2^-45 (L + 1) of a half-integer (exactly on it, in practice: 2 sqrt(T) / n is an
+    // integer for ~0.2 % of the windows): those blocks run the chain over the staged tile; any whose window is not
+    // the 10 x 10 cells m-5 .. m+4 runs it over global memory.  T == 0 (all positions equal): the chain's deviations are exact zeros.
+    auto sum_stats = [&](uint32_t x, uint32_t y, int a) -> bool {
+        uint32_t xs0, xs1, ys0, ys1;
+        neighbor_window(p, x, y, xs0, xs1, ys0, ys1);
+        if (xs0 != sat_sub_u32(bxi, SRF_LEFT) || xs1 != min(bxi + SRF_TAPS - SRF_LEFT, p.pw) ||
+            ys0 != sat_sub_u32(byi, SRF_LEFT) || ys1 != min(byi + SRF_TAPS - SRF_LEFT, p.ph))
+            return false;
+        // test hooks: mode 2 sends every third block of a sum tile through the chain over the staged tile,
+        // mode 3 through the chain over global memory
+        if (mode == 3 && ((bxi + byi) % 3u) == 0u) return false;
+        const bool force_chain = mode == 2 && ((bxi + byi) % 3u) == 0u;
+        const uint32_t n = win_a >> 22, sv = win_a & 0x3FFFFFu, up = p.pk - p.k;
+        if (n == 0u) {
+            have[a] = false;
+            return true;
+        }
+        const double mid_corridor = (double)((unsigned long long)sv << up) / (double)n;
+        const unsigned long long T = (unsigned long long)n * win_b - (unsigned long long)sv * sv;
+        uint32_t len;
+        if (T == 0ull) {
+            len = f64_to_u32_sat(round(p.min_range + 0.0 * p.extend_range));
+        } else {
+            const double v = sqrt((double)T) * (double)(1u << up) / (double)n;
+            const double L = p.min_range + v * p.extend_range;
+            const double fl = floor(L), fr = L - fl;
+            if (force_chain || !(L < 4.0e9) || fabs(fr - 0.5) <= (L + 1.0) * 0x1p-45) {
+                // open: the reference's chain (mod.rs:523-529) over this block's window in its row-major order, from
+                // the staged tile (FA is 0 for None)
+                const uint32_t r0 = threadIdx.x >> 6, c0 = threadIdx.x & 63u;
+                double range_stdev = 0.0;
+                for (uint32_t r = 0; r < (uint32_t)SRF_TAPS; r++) {
+                    const uint32_t *row = &FA[(r0 + r) * SRF_PITCH + c0];
+#pragma unroll
+                    for (int j = 0; j < SRF_TAPS; j++) {
+                        const uint32_t w = row[j];
+                        const double delta = (double)((w & 0x3FFFFFu) << up) - mid_corridor;
+                        const double next = range_stdev + delta * delta;
+                        range_stdev = w != 0u ? next : range_stdev;
+                    }
+                }
+                range_stdev = sqrt(range_stdev / (double)n);
+                len = f64_to_u32_sat(round(p.min_range + range_stdev * p.extend_range));
+            } else {
+                len = (uint32_t)fl + (fr > 0.5 ? 1u : 0u);
+            }
+        }
+        have[a] = true;
+        center[a] = f64_to_u32_sat(round(mid_corridor));
+        length[a] = len;
+        return true;
+    };
     auto finish = [&](int q, int a) -> uint32_t { // mod.rs:530-539 for pixel q with axis a's statistics
         if (!have[a]) return RANGE_NONE;
         const uint32_t corridor_start = KERNEL_SIZE, corridor_end = cend[q];
@@ -458,7 +608,7 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
                 if (rep >= 0) {
                     const uint32_t rx = rep == 0 ? px[0] : (rep == 1 ? px[1] : (rep == 2 ? px[2] : px[3]));
                     const uint32_t ry = rep == 0 ? py[0] : (rep == 1 ? py[1] : (rep == 2 ? py[2] : py[3]));
-                    block_stats(rx, ry, a);
+                    if (!(sums && sum_stats(rx, ry, a))) block_stats(rx, ry, a);
                 }
             }
 #pragma unroll
@@ -481,14 +631,14 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
     }
 }
 
-void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
+void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range, int mode,
                          hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     // blocks by = row0/2 .. row1/2 cover pixel rows 2by-1, 2by; bx = 0 .. w1/2 cover columns 2bx-1, 2bx
     const uint32_t nby = (p.row1 >> 1) - (p.row0 >> 1) + 1, nbx = (p.w1 >> 1) + 1;
     dim3 grid((nbx + 63) / 64, (nby + 3) / 4);
-    hipLaunchKernelGGL(search_range_kernel, grid, dim3(256), 0, s, p, stats1, prev, range);
+    hipLaunchKernelGGL(search_range_kernel, grid, dim3(256), 0, s, p, stats1, prev, range, mode);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -211,7 +211,7 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
     unsigned long long *cnt = c->count_candidates ? c->d_cand : nullptr;
     if (!first_pass)
-        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->stats[a], ds.cells[prev], range, s); }, s));
+        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->stats[a], ds.cells[prev], range, c->range_mode, s); }, s));
     if (c->search_version == 1) {
         CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
             launch_search(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->stats[b], range, ds.cells[next], cnt, s);
@@ -433,6 +433,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     c->dir[1].gh = h2;
     if (const char *v = std::getenv("CVHIP_SEARCH")) c->search_version = (v[0] >= '1' && v[0] <= '3') ? v[0] - '0' : 3;
     if (const char *v = std::getenv("CVHIP_FORCE_BOX")) c->force_box = v[0] == '1';
+    if (const char *v = std::getenv("CVHIP_RANGE")) c->range_mode = (v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 0;
     const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
     c->max_px = std::max(n1, n2);
     // Level grids are gathered in equal row chunks when sharded, so leave room for one padded

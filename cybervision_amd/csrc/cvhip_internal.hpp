@@ -70,7 +70,7 @@ struct WorkList {
 void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, float2 *stats_a, uint2 *istats_a,
                               const uint8_t *img_b, uint32_t wb, uint32_t hb, float2 *stats_b, uint2 *istats_b,
                               uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s);
-void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range,
+void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range, int mode,
                          hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
                    const float2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
@@ -144,6 +144,7 @@ struct cvhip_ctx {
     // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,
     // 3 = displacement-plane box filter (falls back to 2 per workgroup) + exact re-evaluation
     int search_version = 3;
+    int range_mode = 0; // search_range_kernel: 0 = integer box sums + chain where needed, 1 = chain only, 2 / 3 = test hooks
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
     // per-direction scratch of a search pass (the two passes of a level are independent and run on two streams)
     uint32_t *range = nullptr, *range_rev = nullptr;
