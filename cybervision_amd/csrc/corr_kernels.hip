@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
             word = CW_WHOLE << 60;
             whole = 1;
             evaluated = 0; // the exact kernel walks (and counts) the whole corridor
-        } else if (count > 0u && !(p.debug & 16)) {
+        } else if (count > 0u && !(p.debug & (16 | 512))) { // (512: the contenders come from unstaged LDS)
             // ---- exact re-evaluation of the contenders: mod.rs:442-464, the reference's serial f32 chain and
             // acceptance rule; the list is unordered here, so "first maximum" is the smallest code among equals
             multi = count > 1 ? 1u : 0u;
