@@ -174,16 +174,36 @@ struct StatsJob { // one image's statistics pass
     uint2 *istats;
 };
 
+// sd += (f_k - avg)^2, k = 0..10, on an already converted row (same operations as row_sq_acc)
+__device__ __forceinline__ float row_sq_acc_f(float sd, const float (&f)[KERNEL_WIDTH], float avg)
+{
+    const v2f a1 = {avg, avg};
+#pragma unroll
+    for (int c = 0; c < KERNEL_WIDTH - 1; c += 2) {
+        const v2f fa = {f[c], f[c + 1]};
+        const v2f d = fa - a1;
+        const v2f pr = d * d;
+        sd += pr.x;
+        sd += pr.y;
+    }
+    const float d1 = f[KERNEL_WIDTH - 1] - avg;
+    return sd + d1 * d1;
+}
+
 // Both images of a level in one launch (blockIdx.z picks the image; the grid covers the larger one).  zero_words:
 // eight u32 cleared by the first thread - the work-list counts of the level's two search passes, which start
 // after this kernel on the same stream.
+constexpr int WS_ROWS = 8; // pixel rows per workgroup: every lane owns two vertically adjacent pixels
 __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob jb, float min_stdev,
                                                             uint32_t *__restrict__ zero_words)
 {
-    // The 64x4 tile's 74x14 source bytes are staged once in LDS (one dword load per thread instead of 33
+    // The 64x8 tile's 74x18 source bytes are staged once in LDS (one dword load per thread instead of 33
     // unaligned loads per pixel, which made the kernel address-unit-bound); each lane then reads its 12
-    // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.
-    __shared__ uint32_t tile[14 * (WS_PITCH / 4)];
+    // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.  A lane's two pixels
+    // (x, y) and (x, y + 1) share 10 of their 11 window rows: the 12 rows are extracted, summed and converted to
+    // f32 once, and each pixel runs its own serial chain over its 11 of them - the per-pixel operation order of
+    // mod.rs:727-733 is untouched.
+    __shared__ uint32_t tile[(WS_ROWS + KERNEL_WIDTH - 1) * (WS_PITCH / 4)];
     if (zero_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) zero_words[threadIdx.x] = 0u;
     const StatsJob &job = blockIdx.z == 0 ? ja : jb;
     const uint8_t *__restrict__ img = job.img;
@@ -191,10 +211,10 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
     float2 *__restrict__ stats = job.stats;
     uint2 *__restrict__ istats = job.istats;
     const TileId tid = xcd_tile();
-    const uint32_t x0 = tid.x * 64, y0 = row0 + tid.y * 4;
+    const uint32_t x0 = tid.x * 64, y0 = row0 + tid.y * WS_ROWS;
     if (x0 >= w || y0 >= row1) return; // the grid covers the larger image
     const int sx = (int)x0 - 8, sy = (int)y0 - KERNEL_SIZE; // staged origin; sx is 0 mod 4 relative to x0
-    for (uint32_t u = threadIdx.x; u < 14u * (WS_PITCH / 4); u += 256) {
+    for (uint32_t u = threadIdx.x; u < (uint32_t)(WS_ROWS + KERNEL_WIDTH - 1) * (WS_PITCH / 4); u += 256) {
         const uint32_t r = u / (WS_PITCH / 4), c4 = (u - r * (WS_PITCH / 4)) * 4;
         const int gy = sy + (int)r, gx = sx + (int)c4;
         uint32_t v = 0;
@@ -204,37 +224,63 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t x = x0 + lane, y = y0 + wv;
-    if (x >= w || y >= row1) return;
+    const uint32_t x = x0 + lane, ya = y0 + 2 * wv, yb = ya + 1;
+    if (x >= w || ya >= row1) return;
     const float nan = __builtin_nanf("");
-    float2 out = make_float2(nan, nan);
-    uint2 iout = make_uint2(0u, 0u);
-    if (x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < w && y + KERNEL_SIZE < h) {
+    float2 out_a = make_float2(nan, nan), out_b = out_a;
+    uint2 iout_a = make_uint2(0u, 0u), iout_b = iout_a;
+    const bool col_in = x >= KERNEL_SIZE && x + KERNEL_SIZE < w;
+    const bool in_a = col_in && ya >= KERNEL_SIZE && ya + KERNEL_SIZE < h;
+    const bool in_b = col_in && yb >= KERNEL_SIZE && yb + KERNEL_SIZE < h && yb < row1;
+    if (in_a || in_b) {
         const uint32_t off = lane + 3u; // window starts at byte (x - 5) - (x0 - 8) of the staged row
         const uint32_t d0 = off >> 2, sh = off & 3u;
-        uint32_t isum = 0;
-        Row12 rows[KERNEL_WIDTH];
+        Row12 rows[KERNEL_WIDTH + 1];
+        uint32_t rs[KERNEL_WIDTH + 1];
 #pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH; r++) {
-            const uint32_t *src = &tile[(wv + r) * (WS_PITCH / 4) + d0];
+        for (int r = 0; r < KERNEL_WIDTH + 1; r++) {
+            const uint32_t *src = &tile[(2 * wv + r) * (WS_PITCH / 4) + d0];
             const uint32_t q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
             rows[r].a = __builtin_amdgcn_alignbyte(q1, q0, sh);
             rows[r].b = __builtin_amdgcn_alignbyte(q2, q1, sh);
             rows[r].c = __builtin_amdgcn_alignbyte(q3, q2, sh);
-            isum += __builtin_amdgcn_udot4(rows[r].a, 0x01010101u, 0u, false);
-            isum += __builtin_amdgcn_udot4(rows[r].b, 0x01010101u, 0u, false);
-            isum += __builtin_amdgcn_udot4(rows[r].c, 0x00010101u, 0u, false);
+            uint32_t t = __builtin_amdgcn_udot4(rows[r].a, 0x01010101u, 0u, false);
+            t = __builtin_amdgcn_udot4(rows[r].b, 0x01010101u, t, false);
+            rs[r] = __builtin_amdgcn_udot4(rows[r].c, 0x00010101u, t, false);
         }
-        const float avg = (float)isum / (float)KERNEL_POINT_COUNT;
-        float sd = 0.0f;
+        uint32_t isum_a = 0;
 #pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH; r++) sd = row_sq_acc(sd, rows[r], avg);
-        out = make_float2(avg, sqrtf(sd / (float)KERNEL_POINT_COUNT));
-        const bool valid = finite_f32(out.y) && !(fabsf(out.y) < min_stdev);
-        iout = make_uint2(isum | (valid ? 0x80000000u : 0u), __float_as_uint(out.y));
+        for (int r = 0; r < KERNEL_WIDTH; r++) isum_a += rs[r];
+        const uint32_t isum_b = isum_a - rs[0] + rs[KERNEL_WIDTH];
+        const float avg_a = (float)isum_a / (float)KERNEL_POINT_COUNT, avg_b = (float)isum_b / (float)KERNEL_POINT_COUNT;
+        float sd_a = 0.0f, sd_b = 0.0f;
+#pragma unroll
+        for (int r = 0; r < KERNEL_WIDTH + 1; r++) {
+            // one row at a time: without this the compiler converts all 12 rows up front (132 live floats)
+            asm volatile("" : "+v"(rows[r].a), "+v"(rows[r].b), "+v"(rows[r].c), "+v"(sd_a), "+v"(sd_b));
+            float f[KERNEL_WIDTH];
+#pragma unroll
+            for (int c = 0; c < KERNEL_WIDTH; c++) f[c] = byte_f32(row12_word(rows[r], c), c & 3);
+            if (r < KERNEL_WIDTH) sd_a = row_sq_acc_f(sd_a, f, avg_a);
+            if (r >= 1) sd_b = row_sq_acc_f(sd_b, f, avg_b);
+        }
+        if (in_a) {
+            out_a = make_float2(avg_a, sqrtf(sd_a / (float)KERNEL_POINT_COUNT));
+            const bool valid = finite_f32(out_a.y) && !(fabsf(out_a.y) < min_stdev);
+            iout_a = make_uint2(isum_a | (valid ? 0x80000000u : 0u), __float_as_uint(out_a.y));
+        }
+        if (in_b) {
+            out_b = make_float2(avg_b, sqrtf(sd_b / (float)KERNEL_POINT_COUNT));
+            const bool valid = finite_f32(out_b.y) && !(fabsf(out_b.y) < min_stdev);
+            iout_b = make_uint2(isum_b | (valid ? 0x80000000u : 0u), __float_as_uint(out_b.y));
+        }
     }
-    stats[(size_t)y * w + x] = out;
-    istats[(size_t)y * w + x] = iout;
+    stats[(size_t)ya * w + x] = out_a;
+    istats[(size_t)ya * w + x] = iout_a;
+    if (yb < row1) {
+        stats[(size_t)yb * w + x] = out_b;
+        istats[(size_t)yb * w + x] = iout_b;
+    }
 }
 
 void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, float2 *stats_a, uint2 *istats_a,
@@ -249,7 +295,7 @@ void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, fl
         if (zero_words) (void)hipMemsetAsync(zero_words, 0, 8 * sizeof(uint32_t), s);
         return;
     }
-    dim3 grid(((wa > wb ? wa : wb) + 63) / 64, (rows + 3) / 4, 2);
+    dim3 grid(((wa > wb ? wa : wb) + 63) / 64, (rows + WS_ROWS - 1) / WS_ROWS, 2);
     hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, ja, jb, min_stdev, zero_words);
 }
 
