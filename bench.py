@@ -85,10 +85,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # CVHIP_BENCH_BACKEND=gloo: rehearsal of the N-rank code path on a box with ONE GPU - every rank uses cuda:0 and
+    # the gather is staged through the host (sharding.make_allgather); the numbers it prints are not a benchmark
+    backend = os.environ.get("CVHIP_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from cybervision_amd import correlation, sharding, synth
 
@@ -186,7 +195,23 @@ def main():
     ktimes = pc.get_kernel_times()
     pc.set_profiling(0, False)
 
-    t = torch.tensor([dt, float(cand_local), search_ms_local], dtype=torch.float64, device="cuda")
+    if rehearsal and world > 1:
+        # the sharded result of the last step against an unsharded run of the same pair in this process
+        pc1 = correlation.PointCorrelations(dev, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
+        pc1.set_borrow_inputs(True)
+        for i in range(steps + 1):
+            k = steps - i
+            pc1.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+        ref_xy, ref_corr = torch.empty_like(out_xy), torch.empty_like(out_corr)
+        pc1.complete(out_xy=ref_xy, out_corr=ref_corr)
+        fence()
+        same = bool(torch.equal(out_xy, ref_xy)) and bool(torch.equal(out_corr.view(torch.int32), ref_corr.view(torch.int32)))
+        pc1.close()
+        print(f"[rehearsal] rank {rank}/{world}: sharded result {'==' if same else '!='} unsharded result", flush=True)
+        if not same:
+            raise SystemExit(f"rank {rank}: sharded result differs from the unsharded one")
+
+    t = torch.tensor([dt, float(cand_local), search_ms_local], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -281,6 +306,8 @@ def main():
                 "sample": (f"top-left {S}x{S} crop of the same pair" if S < W else f"the whole {S}x{S} pair")
                           + f", full {csteps + 1}-level pyramid, C restatement of --mode=cpu (oracle/), {tc:.2f} s",
             }
+        if rehearsal:
+            result["rehearsal"] = f"{backend}: all {world} ranks on one GPU, gather staged through the host - not a measurement"
         print(json.dumps(result), flush=True)
 
     pc.close()
