@@ -232,7 +232,8 @@ struct FundamentalMatrixResult { // fundamentalmatrix.rs:57-61
 // run on the host exactly as in the reference (rejection sampling from the top 5000 matches, >= 10 px
 // apart; mean-centred 4x4 smallest right-singular vector); all hypotheses of one check interval are
 // scored on the GPU in one call.  The perspective model (7-point, fundamentalmatrix.rs:289-389) runs
-// entirely on the device (cvhip_ransac_perspective); its final LM refit (:391-426, 515-621) is not done.
+// entirely on the device (cvhip_ransac_perspective); its final LM refit (:391-426, 515-621) is
+// cvhip_optimize_perspective_f.
 class FundamentalMatrix {
   public:
     FundamentalMatrix(ProjectionMode projection, double max_dimension) : projection_(projection), max_dimension_(max_dimension)
@@ -265,8 +266,8 @@ class FundamentalMatrix {
         }
         if (projection_ != ProjectionMode::Affine) {
             // Perspective: sampling, the 7-point model and its checks, scoring and best-pick all run on the device
-            // (cvhip_ransac_perspective).  The final LM refit of optimize_result (:246-256) is not part of it:
-            // the result is the best RANSAC hypothesis and its inliers.
+            // (cvhip_ransac_perspective); optimize_result (:231-257) then refits the winner on its inliers with the
+            // reference's own LM loop (cvhip_optimize_perspective_f, host arithmetic) and re-selects the inliers.
             FundamentalMatrixResult res;
             std::vector<uint8_t> mask(point_matches.size());
             uint32_t cnt = 0;
@@ -274,8 +275,17 @@ class FundamentalMatrix {
                                                     seed, 0, res.f.data(), &cnt, mask.data());
             if (rc == CVHIP_ERR_NO_MODEL) throw RansacError(cvhip_last_error());
             check(rc, "cvhip_ransac_perspective");
+            std::vector<uint32_t> inl;
+            inl.reserve(4 * (size_t)cnt);
             for (size_t i = 0; i < point_matches.size(); i++)
-                if (mask[i]) res.inliers.push_back(point_matches[i]);
+                if (mask[i]) inl.insert(inl.end(), flat.begin() + 4 * i, flat.begin() + 4 * i + 4);
+            std::array<double, 9> refit{};
+            int refined = 0;
+            check(cvhip_optimize_perspective_f(res.f.data(), inl.data(), (uint32_t)(inl.size() / 4), refit.data(), &refined),
+                  "cvhip_optimize_perspective_f");
+            res.f = refit; // .unwrap_or(res.f): the call returns F itself when the refit is rejected
+            for (size_t i = 0; i < point_matches.size(); i++)
+                if (fits(res.f, point_matches[i])) res.inliers.push_back(point_matches[i]); // :248-254
             return res;
         }
         std::mt19937_64 rng(seed); // the reference seeds SmallRng from the OS: runs are not reproducible there

@@ -10,7 +10,13 @@
 // published gemv / dot algorithms (column-by-column axpy; 3-vector dot = (a0*b0 + a1*b1) + a2*b2).
 #include "cvhip_internal.hpp"
 
+#include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstring>
+#include <functional>
+#include <new>
+#include <utility>
 #include <vector>
 
 namespace cvhip {
@@ -829,4 +835,254 @@ extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t
     (void)hipFree(d_F);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("ransac_perspective_models: ") + hipGetErrorString(e));
     return CVHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The final refit of the perspective model: optimize_perspective_f (fundamentalmatrix.rs:391-426) with the
+// reference's own Levenberg-Marquardt loop (least_squares, :515-621) and analytic Jacobian (f_jacobian,
+// :473-512).  Host arithmetic like the reference's (a 7x7 solve per iteration over <= a few thousand inliers);
+// hypothesis generation and scoring are the device's part.  The loop is kept as written there, also where it
+// is not the textbook method: the Jacobian's denominator terms are plain sums c = d = (F p1)_0 + (F p1)_1 +
+// (F' p2)_0 + (F' p2)_1, the step is params + (J'J + mu I)^-1 J'r, and a step that INCREASES the residual norm
+// counts as converged (reduction < 0 * norm).  nalgebra 0.35 evaluation order as in the scoring kernel, plus:
+// dot products over the inliers keep eight partial sums (blas.rs `dot`), LU is partial pivoting with
+// multipliers scaled by the reciprocal pivot, triangular solves update column by column.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+using Params7 = std::array<double, 7>;
+using Mat3 = std::array<double, 9>; // row-major
+
+struct Obs { // one match as the two homogeneous points
+    double p1[3], p2[3];
+    explicit Obs(const uint32_t *m) : p1{(double)m[0], (double)m[1], 1.0}, p2{(double)m[2], (double)m[3], 1.0} {}
+};
+
+// strided view of a column of the n x 7 Jacobian or of a plain vector
+struct Strided {
+    const double *p;
+    size_t step;
+    double operator[](size_t i) const { return p[i * step]; }
+};
+
+double long_dot(Strided a, Strided b, uint32_t n)
+{
+    double part[8] = {};
+    uint32_t i = 0;
+    for (; n - i >= 8; i += 8)
+        for (uint32_t k = 0; k < 8; k++) part[k] += a[i + k] * b[i + k];
+    double total = 0.0;
+    for (uint32_t k = 0; k < 4; k++) total += part[k] + part[k + 4];
+    for (; i < n; i++) total += a[i] * b[i];
+    return total;
+}
+
+Mat3 matrix_of(const Params7 &q) // f_from_perspective_params, :442-449: det = 0 by construction
+{
+    const double last = -(-q[0] * q[4] + q[6] * q[2] * q[4] + q[3] * q[1] - q[6] * q[1] * q[5]) / (-q[3] * q[2] + q[0] * q[5]);
+    return Mat3{q[0], q[1], q[2], q[3], q[4], q[5], q[6], last, 1.0};
+}
+
+// row vector p2' M, column vector M p1, M' p2 in nalgebra's orders
+inline void row_times(const double (&v)[3], const Mat3 &M, double (&out)[3])
+{
+    for (int j = 0; j < 3; j++) out[j] = (v[0] * M[j] + v[1] * M[3 + j]) + v[2] * M[6 + j];
+}
+inline double chain3(const double (&r)[3], const double (&v)[3])
+{
+    double acc = r[0] * v[0];
+    acc = r[1] * v[1] + acc;
+    return r[2] * v[2] + acc;
+}
+
+double residual_of(const Mat3 &M, const Obs &o) // reprojection_error, :461-471
+{
+    double r[3], mp1[3], mtp2[3];
+    row_times(o.p2, M, r);
+    const double top = chain3(r, o.p1);
+    for (int i = 0; i < 3; i++) {
+        const double row[3] = {M[3 * i], M[3 * i + 1], M[3 * i + 2]};
+        mp1[i] = chain3(row, o.p1);
+    }
+    row_times(o.p2, M, mtp2); // (M' p2)_i = dot(column i of M, p2): the same numbers as p2' M
+    return top * top / (mp1[0] * mp1[0] + mp1[1] * mp1[1] + mtp2[0] * mtp2[0] + mtp2[1] * mtp2[1]);
+}
+
+void gradient_of(const Mat3 &M, const Obs &o, double *out7) // f_jacobian, :473-512
+{
+    double mp1[3], mtp2[3];
+    for (int i = 0; i < 3; i++) {
+        const double row[3] = {M[3 * i], M[3 * i + 1], M[3 * i + 2]};
+        mp1[i] = chain3(row, o.p1);
+    }
+    for (int i = 0; i < 3; i++) mtp2[i] = (M[i] * o.p2[0] + M[3 + i] * o.p2[1]) + M[6 + i] * o.p2[2];
+    const double c = mp1[0] + mp1[1] + mtp2[0] + mtp2[1], d = c;
+    for (int e = 0; e < 7; e++) {
+        const int r = e / 3, k = e % 3;
+        const double a = o.p2[r] * o.p1[k]; // p2' E_rk p1: the other eight products are exact zeros
+        Mat3 rest = M;
+        rest[3 * r + k] = 0.0;
+        double rv[3];
+        row_times(o.p2, rest, rv);
+        const double b = chain3(rv, o.p1), x = M[3 * r + k];
+        out7[e] = 2.0 * (a * x + b) * (a * d - b * c * c * x) / (c * c * x * x + d);
+    }
+}
+
+// (J'J + mu I) x = g, nalgebra's LU::new + LU::solve; false = "Failed to compute delta vector"
+bool solve7(std::array<double, 49> &A, Params7 &x)
+{
+    constexpr int n = 7;
+    std::vector<std::pair<int, int>> swaps;
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++)
+            if (std::fabs(A[r * n + c]) > std::fabs(A[p * n + c])) p = r;
+        const double pivot = A[p * n + c];
+        if (pivot == 0.0) continue;
+        if (p != c) {
+            swaps.emplace_back(c, p);
+            for (int k = 0; k < n; k++) std::swap(A[c * n + k], A[p * n + k]);
+        }
+        const double rp = 1.0 / pivot;
+        for (int r = c + 1; r < n; r++) A[r * n + c] *= rp;
+        for (int k = c + 1; k < n; k++) {
+            const double top = A[c * n + k];
+            for (int r = c + 1; r < n; r++) A[r * n + k] = -top * A[r * n + c] + A[r * n + k];
+        }
+    }
+    for (const auto &s : swaps) std::swap(x[s.first], x[s.second]);
+    for (int c = 0; c < n; c++) {
+        const double v = x[c];
+        for (int r = c + 1; r < n; r++) x[r] = -v * A[r * n + c] + x[r];
+    }
+    for (int c = n - 1; c >= 0; c--) {
+        const double pivot = A[c * n + c];
+        if (pivot == 0.0) return false;
+        const double v = x[c] / pivot;
+        x[c] = v;
+        for (int r = 0; r < c; r++) x[r] = -v * A[r * n + c] + x[r];
+    }
+    return true;
+}
+
+// descending singular values of a 3x3 matrix from the eigenvalues of M'M (Jacobi rotations); they are only
+// compared with 1e-3 (:418-423)
+std::array<double, 3> singular3(const Mat3 &M)
+{
+    double g[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) g[i][j] = M[i] * M[j] + M[3 + i] * M[3 + j] + M[6 + i] * M[6 + j];
+    for (int sweep = 0; sweep < 32 && (g[0][1] != 0.0 || g[0][2] != 0.0 || g[1][2] != 0.0); sweep++)
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (g[p][q] == 0.0) continue;
+                const double th = (g[q][q] - g[p][p]) / (2.0 * g[p][q]);
+                const double t = std::copysign(1.0, th) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; k++) {
+                    const double u = g[k][p], v = g[k][q];
+                    g[k][p] = cs * u - sn * v;
+                    g[k][q] = sn * u + cs * v;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double u = g[p][k], v = g[q][k];
+                    g[p][k] = cs * u - sn * v;
+                    g[q][k] = sn * u + cs * v;
+                }
+            }
+    std::array<double, 3> ev{g[0][0], g[1][1], g[2][2]};
+    std::sort(ev.begin(), ev.end(), std::greater<double>());
+    for (double &v : ev) v = std::sqrt(v > 0.0 ? v : 0.0);
+    return ev;
+}
+
+// least_squares (:515-621) on this problem; false = Err
+bool levenberg_marquardt(Params7 &q, const std::vector<Obs> &obs)
+{
+    const uint32_t n = (uint32_t)obs.size();
+    std::vector<double> r(n), r_new(n), J((size_t)n * 7);
+    const auto column = [&](int j) { return Strided{J.data() + j, 7}; };
+    const auto plain = [](const double *p) { return Strided{p, 1}; };
+    const auto evaluate = [&](const Params7 &at, std::vector<double> &into) {
+        const Mat3 M = matrix_of(at);
+        for (uint32_t i = 0; i < n; i++) into[i] = residual_of(M, obs[i]);
+    };
+    Params7 g{};
+    const auto linearise = [&](const Params7 &at) { // Jacobian and J'r at `at` (r already holds its residuals)
+        const Mat3 M = matrix_of(at);
+        for (uint32_t i = 0; i < n; i++) gradient_of(M, obs[i], &J[(size_t)i * 7]);
+        for (int j = 0; j < 7; j++) g[j] = long_dot(column(j), plain(r.data()), n);
+    };
+    const auto largest = [](const Params7 &v) { return *std::max_element(v.begin(), v.end()); };
+    const auto norm7 = [&](const Params7 &v) { return std::sqrt(long_dot(plain(v.data()), plain(v.data()), 7)); };
+
+    evaluate(q, r);
+    linearise(q);
+    if (std::fabs(largest(g)) <= 1e-12) return true;
+    double mu = 0.0;
+    for (int j = 0; j < 7; j++) {
+        const double djj = long_dot(column(j), column(j), n);
+        if (j == 0 || djj >= mu) mu = djj;
+    }
+    mu *= 1e-3;
+    double nu = 2.0;
+    for (int iteration = 0; iteration < 1000; iteration++) {
+        std::array<double, 49> A;
+        for (int i = 0; i < 7; i++)
+            for (int j = 0; j < 7; j++) A[i * 7 + j] = long_dot(column(i), column(j), n);
+        for (int i = 0; i < 7; i++) A[i * 7 + i] += mu;
+        Params7 step = g;
+        if (!solve7(A, step)) return false;
+        if (norm7(step) <= 1e-12 * (norm7(q) + 1e-12)) return true;
+        Params7 trial, damped;
+        for (int j = 0; j < 7; j++) trial[j] = q[j] + step[j];
+        evaluate(trial, r_new);
+        const double before = long_dot(plain(r.data()), plain(r.data()), n);
+        const double after = long_dot(plain(r_new.data()), plain(r_new.data()), n);
+        for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + g[j];
+        const double rho = (before - after) / long_dot(plain(step.data()), plain(damped.data()), 7);
+        if (rho > 0.0) {
+            const bool converged = std::sqrt(before) - std::sqrt(after) < 0.0 * std::sqrt(before);
+            r.swap(r_new);
+            q = trial;
+            linearise(q);
+            if (converged || std::fabs(largest(g)) <= 1e-12) return true;
+            const double w = 2.0 * rho - 1.0, shrink = 1.0 - w * w * w;
+            mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
+            nu = 2.0;
+        } else {
+            mu *= nu;
+            nu *= 2.0;
+        }
+        if (std::sqrt(long_dot(plain(r.data()), plain(r.data()), n)) <= 1e-12) return true;
+    }
+    return false; // "Levenberg-Marquardt failed to converge"
+}
+
+} // namespace
+
+extern "C" int cvhip_optimize_perspective_f(const double *F, const uint32_t *matches, uint32_t n, double *out_F,
+                                            int *out_refined)
+{
+    if (!F || !out_F || !out_refined || (n && !matches)) return cvhip::fail(CVHIP_ERR_INVALID, "cvhip_optimize_perspective_f: null argument");
+    try {
+        std::vector<Obs> obs;
+        obs.reserve(n);
+        for (uint32_t i = 0; i < n; i++) obs.emplace_back(matches + (size_t)i * 4);
+        Params7 q{F[0], F[1], F[2], F[3], F[4], F[5], F[6]}; // params_from_perspective_f, :429-440
+        bool ok = levenberg_marquardt(q, obs);
+        Mat3 M{};
+        if (ok) {
+            M = matrix_of(q);
+            const Mat3 Mt{M[0], M[3], M[6], M[1], M[4], M[7], M[2], M[5], M[8]};
+            const auto s = singular3(Mt);
+            if (std::fabs(s[1]) < 1e-3 || std::fabs(s[2]) > 1e-3) ok = false; // :418-423
+        }
+        *out_refined = ok ? 1 : 0;
+        for (int k = 0; k < 9; k++) out_F[k] = ok ? M[k] : F[k]; // optimize_result: .unwrap_or(res.f), :246
+        return CVHIP_OK;
+    } catch (const std::bad_alloc &) {
+        return cvhip::fail(CVHIP_ERR_NOMEM, "cvhip_optimize_perspective_f: out of host memory");
+    }
 }

@@ -157,22 +157,17 @@ def f_from_perspective_params(p):
 
 
 def optimize_perspective_f(F, inliers):
-    """optimize_perspective_f (:391-426): Levenberg-Marquardt on the 7 free parameters minimising the
-    reprojection error over `inliers`; None when the result is not rank 2."""
-    from scipy.optimize import least_squares
-
-    p0 = np.array([F[0, 0], F[0, 1], F[0, 2], F[1, 0], F[1, 1], F[1, 2], F[2, 0]])
-    try:
-        res = least_squares(lambda p: reprojection_error(f_from_perspective_params(p), inliers), p0, method="lm", max_nfev=1000)
-    except Exception:
-        return None
-    Fo = f_from_perspective_params(res.x)
-    if not np.isfinite(Fo).all():
-        return None
-    sv = np.linalg.svd(Fo.T, compute_uv=False)
-    if abs(sv[1]) < RANSAC_RANK_EPSILON_PERSPECTIVE or abs(sv[2]) > RANSAC_RANK_EPSILON_PERSPECTIVE:
-        return None
-    return Fo
+    """optimize_perspective_f (:391-426) through cvhip_optimize_perspective_f: the reference's own
+    Levenberg-Marquardt loop (:515-621) and Jacobian (:473-512) on the 7 free parameters, then its rank test;
+    None where the reference returns None.  Host arithmetic inside libcvhip, no device involved."""
+    F = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(9))
+    m = np.ascontiguousarray(np.asarray(inliers, dtype=np.uint32).reshape(-1, 4))
+    out = np.zeros(9, dtype=np.float64)
+    refined = C.c_int(0)
+    _lib.check(_lib.lib().cvhip_optimize_perspective_f(C.c_void_p(F.ctypes.data), C.c_void_p(m.ctypes.data), len(m),
+                                                       C.c_void_p(out.ctypes.data), C.byref(refined)),
+               "cvhip_optimize_perspective_f")
+    return out.reshape(3, 3) if refined.value else None
 
 
 def find_ransac_perspective(device, matches, max_dimension: float, seed: int = 0, k: int = RANSAC_K_PERSPECTIVE,

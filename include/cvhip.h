@@ -253,7 +253,7 @@ int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, 
  * exit above 50 000 inliers; t = 0.01 * max_dimension.  `rounds` = number of 50 000-sample rounds (0 or
  * more than 20 = the reference's 20).  Not done here: validate_f's per-hypothesis LM (:205; a 7-point
  * solution has zero reprojection error on its own sample, that optimisation's fixed point) and the final
- * LM refit of optimize_result (:246-256), which stays with the caller.  out_F: the best hypothesis
+ * LM refit of optimize_result (:246-256): cvhip_optimize_perspective_f below, called by the host layers.  out_F: the best hypothesis
  * (normalised by F[2][2]); mask/count: its inliers.  Statistical parity, as above. */
 int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension,
                              uint64_t seed, uint32_t rounds, double *out_F, uint32_t *out_inlier_count,
@@ -263,6 +263,15 @@ int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_
  * t as in fits_model.  Compared against the numpy restatement on identical samples. */
 int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t *matches, uint32_t N, const uint32_t *sample_idx,
                                     uint32_t B, double t, double *out_F);
+/* optimize_perspective_f (fundamentalmatrix.rs:391-426) as optimize_result applies it to the winning model
+ * (:246): the reference's own Levenberg-Marquardt loop (least_squares, :515-621) with its analytic Jacobian
+ * (f_jacobian, :473-512) over the 7 free parameters of F (:429-449), then the rank test (:418-423).  Host
+ * arithmetic, as in the reference (no device needed): matches = the n inliers, 4 x uint32 each.  out_F = the
+ * refitted matrix and *out_refined = 1, or F itself and 0 where the reference's function returns None
+ * (`.unwrap_or(res.f)`).  The loop is restated as written, including where it departs from the textbook
+ * method (see the implementation's header); it is deterministic, so the oracle's restatement is compared
+ * value for value. */
+int cvhip_optimize_perspective_f(const double *F, const uint32_t *matches, uint32_t n, double *out_F, int *out_refined);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,8 @@ def lib():
         L.cvref_reprojection_error.restype = C.c_double
         L.cvref_reprojection_error.argtypes = [_f64p, _u32p]
         L.cvref_ransac_score.argtypes = [_f64p, C.c_uint32, _u32p, C.c_uint32, C.c_double, _u32p, _f64p]
+        L.cvref_optimize_perspective_f.restype = C.c_int
+        L.cvref_optimize_perspective_f.argtypes = [_f64p, _u32p, C.c_uint32, _f64p]
         _LIB = L
     return _LIB
 
@@ -230,6 +232,15 @@ def ransac_score(F, matches, t: float):
     err = np.zeros(H, dtype=np.float64)
     lib().cvref_ransac_score(F, H, matches, N, t, cnt, err)
     return cnt, err
+
+
+def optimize_perspective_f(F, matches):
+    """optimize_perspective_f (fundamentalmatrix.rs:391-426) -> F [3, 3], or None where the reference returns None."""
+    F = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(9))
+    matches = np.ascontiguousarray(np.asarray(matches, dtype=np.uint32).reshape(-1, 4))
+    out = np.zeros(9, dtype=np.float64)
+    ok = lib().cvref_optimize_perspective_f(F, matches, matches.shape[0], out)
+    return out.reshape(3, 3) if ok else None
 
 
 def triangulate_affine(xy):

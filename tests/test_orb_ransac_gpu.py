@@ -219,6 +219,9 @@ def test_device_perspective_ransac_recovers_planted_geometry(gpu_device, oracle)
     assert cnt[0] == mask0.sum()  # the mask is exactly fits_model of the returned F
     assert (mask0 & truth).sum() > 0.95 * truth.sum()
     F, mask = fundamentalmatrix.find_ransac_perspective_device(gpu_device, m, 2048.0, seed=5, rounds=2)
+    # optimize_result (:231-257): the reference's LM refit on the winner's inliers, deterministic -> the oracle's bits
+    want = oracle.optimize_perspective_f(F0, m[mask0])
+    assert (F == (F0 if want is None else want)).all()
     assert (mask & truth).sum() > 0.97 * truth.sum() and (mask & ~truth).sum() < 0.1 * (~truth).sum()
     assert np.median(np.abs(fundamentalmatrix.reprojection_error(F, m[truth]))) < 1.0
     F2, mask2 = fundamentalmatrix.find_ransac_perspective_device(gpu_device, m, 2048.0, seed=5, rounds=2, refit=False)
