@@ -1663,13 +1663,20 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
 
     if (wave_has && !(p.debug & 8)) {
         const uint32_t col0 = lane + (uint32_t)colshift + (uint32_t)(mnx - dx0);
-        const uint8_t *pB16 = lds + S3_B16_OFF + (w * S3_COLS + col0) * 16u;
-        const uint8_t *pB4 = lds + S3_B4_OFF + (w * S3_COLS + col0) * 4u;
-        const uint8_t *pIS = lds + S3_IS_OFF + (w * S3_COLS + lane + (uint32_t)(mnx - dx0)) * 8u;
+        const uint8_t *const bB16 = lds + S3_B16_OFF + (w * S3_COLS + col0) * 16u;
+        const uint8_t *const bB4 = lds + S3_B4_OFF + (w * S3_COLS + col0) * 4u;
+        const uint8_t *const bIS = lds + S3_IS_OFF + (w * S3_COLS + lane + (uint32_t)(mnx - dx0)) * 8u;
         const int idx_lo = (int)(lane >= 11u ? lane - 11u : 0u) * 4;
         const int nsteps = mxx - mnx + 1;
         const int ws0 = mny - dy0, wn = mxy - mny + 1; // the wave's plane window while no line steps
-        for (int step = 0; step < nsteps; step++, pB16 += 16, pB4 += 4, pIS += 8) {
+        // Inside out: from the middle of the wave's displacement range up to its end, then from the middle down to
+        // its start.  The ranges are centred on the positions predicted by the previous level, so the best matches
+        // sit around the middle and are met first; the near-misses next to them (which pass the initial threshold
+        // and would each cost a trip through the hit branch) then come after limk has risen.  Any order is exact.
+        const int mid = nsteps >> 1;
+        for (int t = 0; t < nsteps; t++) {
+            const int step = t < nsteps - mid ? mid + t : nsteps - 1 - t;
+            const uint8_t *pB16 = bB16 + step * 16, *pB4 = bB4 + step * 4, *pIS = bIS + step * 8;
             const int dx = mnx + step; // displacement along the lanes (x; y when TR)
             const bool mx = has && (uint32_t)(dx - lou) < wu;
             // first plane offset of this lane's candidates at this step, and the planes the wave needs for it
@@ -1714,9 +1721,14 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
                     for (int q = 0; q < N; q++)
                         if (mx && (uint32_t)(dy0 + S0 + q - bl) < wv && sd[q] < __builtin_inff()) evaluated++;
                 }
-                if (margin >= 0.0f) {
+                if (margin >= 0.0f && !(p.debug & 64)) {
+                    // Planes from the middle of the group outwards: every record raises limk, and the stripe through
+                    // the predicted position is where the best match usually is - once it is in, its neighbours
+                    // (typically 0.6 .. 0.9 against ~1) fail the re-test and their record bodies are skipped.  The
+                    // order is free: the contender list is unordered and re-evaluated exactly.
 #pragma unroll
-                    for (int q = 0; q < N; q++) {
+                    for (int qi = 0; qi < N; qi++) {
+                        const int q = (N - 1) / 2 + ((qi & 1) ? (qi + 1) / 2 : -(qi / 2)); // m, m+1, m-1, m+2, ...
                         const int dy = dy0 + S0 + q; // displacement across the planes (y; x when TR)
                         if (mx && (uint32_t)(dy - bl) < wv && sd[q] < __builtin_inff() && (float)num[q] >= limk * sd[q]) {
                             // back to image axes: candidate (x + ddx, y + ddy), stripe origin (ox, oy)

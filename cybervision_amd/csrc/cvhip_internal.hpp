@@ -56,7 +56,7 @@ struct CorrParams {
     int first_pass;
     // Profiling ablations (env CVHIP_DEBUG, applied to the full-resolution level only; results are then wrong on
     // purpose): 1 = skip the whole-corridor kernel, 2 = skip the filter kernels, 4 = the box kernel declines every
-    // workgroup, 8 / 16 = the box kernel skips its walk / its exact phase, 32 = box statistics in counters 1 and 2,
+    // workgroup, 8 / 16 = the box kernel skips its walk / its exact phase, 32 = box statistics in counters 1 and 2, 64 = the walk never enters its hit branch,
     // 256 = the box kernel stops after per-pixel setup, 512 = it skips staging (and its exact phase).
     int debug;
 };
