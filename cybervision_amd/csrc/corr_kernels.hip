@@ -118,6 +118,21 @@ __device__ __forceinline__ Line epipolar_line(const CorrParams &p, uint32_t px, 
     const double scale = (double)p.scale;
     // p / scale (mod.rs:389-391) with scale = 2^-k: the quotient is exact, and so is this product
     const double up = (double)(1u << p.k), p0 = (double)px * up, p1 = (double)py * up;
+    if (p.affine) { // the direction is a host-evaluated constant (CorrParams::affine); only the offset is per pixel
+        double f2 = p.F[6] * p0;
+        f2 = p.F[7] * p1 + f2;
+        f2 = p.F[8] * 1.0 + f2;
+        const double off = -scale * f2 / p.aff_div;
+        Line e;
+        const bool first = p.affine == 1;
+        e.cx = first ? p.aff_c : 1.0;
+        e.cy = first ? 1.0 : p.aff_c;
+        e.ax = first ? off : 0.0;
+        e.ay = first ? 0.0 : off;
+        e.ox = first ? 1 : 0;
+        e.oy = first ? 0 : 1;
+        return e;
+    }
     double f[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {

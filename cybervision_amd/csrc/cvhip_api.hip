@@ -197,6 +197,21 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     p.k = (uint32_t)k;
     p.first_pass = first_pass ? 1 : 0;
     {
+        const double *F = p.F;
+        p.affine = 0;
+        if (F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0 && std::isfinite(F[2]) && std::isfinite(F[5])) {
+            // l = F*p1 in nalgebra's order: (0*p0 + 0*p1) + F02*1 = F02 (a zero keeps at most its sign, which no
+            // result depends on), likewise F12
+            const bool first = std::fabs(F[2]) > std::fabs(F[5]); // mod.rs:397
+            const double div = first ? F[2] : F[5], c = first ? -F[5] / F[2] : -F[2] / F[5];
+            if (div != 0.0 && std::isfinite(c)) {
+                p.affine = first ? 1 : 2;
+                p.aff_c = c;
+                p.aff_div = div;
+            }
+        }
+    }
+    {
         static const int dbg = [] { const char *v = std::getenv("CVHIP_DEBUG"); return v ? std::atoi(v) : 0; }();
         p.debug = k == 0 ? dbg : 0; // only the full-resolution level, so coarser levels still seed it
     }

@@ -54,6 +54,12 @@ struct CorrParams {
     uint32_t k;              // this level's k
     uint32_t row0, row1;     // rows of the searched image handled by this launch
     int first_pass;
+    // Affine F (first two columns zero): F*p = (F02, F12, .) for every finite pixel, so the epipolar line's direction
+    // is one constant, evaluated once on the host with the reference's expression (mod.rs:397-408; IEEE division,
+    // the same bits as on the device).  affine = 1: the |l.x| > |l.y| branch, aff_c = -F12/F02, aff_div = F02;
+    // 2: the other one, aff_c = -F02/F12, aff_div = F12;  0: not affine (or not finite) - the generic per-pixel path.
+    int affine;
+    double aff_c, aff_div;
     // Profiling ablations (env CVHIP_DEBUG, applied to the full-resolution level only; results are then wrong on
     // purpose): 1 = skip the whole-corridor kernel, 2 = skip the filter kernels, 4 = the box kernel declines every
     // workgroup, 8 / 16 = the box kernel skips its walk / its exact phase, 32 = box statistics in counters 1 and 2, 64 = the walk never enters its hit branch,
