@@ -578,7 +578,8 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     uint64_t pass_px = (uint64_t)w1 * h1;
     if (ctx->band_mode) pass_px = (uint64_t)w1 * (ctx->band[k].sf[1] - ctx->band[k].sf[0]);
     static const uint64_t two_stream_px = [] { const char *v = std::getenv("CVHIP_TWO_STREAM_PX"); return v ? (uint64_t)std::atoll(v) : (uint64_t)(1u << 20); }();
-    if (!sharded && ctx->aux_stream && pass_px <= two_stream_px) {
+    // (bands of a multi-GPU run: always - every pass is short there, and its kernels are not timed one by one)
+    if (!sharded && ctx->aux_stream && (pass_px <= two_stream_px || ctx->band_mode)) {
         CVHIP_TRY_HIP(hipEventRecord(ctx->ev_fork, s));
         CVHIP_TRY_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
         s_rev = ctx->aux_stream;
