@@ -23,6 +23,259 @@ namespace cvhip {
 
 constexpr int RANSAC_TILE = 1024; // matches per LDS tile (16 KiB as 4 x u32)
 
+// ---------------------------------------------------------------------------------------------------------
+// optimize_perspective_f (fundamentalmatrix.rs:391-426) with the reference's own Levenberg-Marquardt loop
+// (least_squares, :515-621) and analytic Jacobian (f_jacobian, :473-512).  ONE implementation for both of its
+// call sites: validate_f runs it on every 7-point hypothesis (:201-205; on the device, inside the generator
+// kernel, n = 7) and optimize_result on the winner's inliers (:246; host arithmetic like the reference's - a 7x7
+// solve per iteration over <= a few thousand inliers).  The loop is kept as written there, also where it
+// is not the textbook method: the Jacobian's denominator terms are plain sums c = d = (F p1)_0 + (F p1)_1 +
+// (F' p2)_0 + (F' p2)_1, the step is params + (J'J + mu I)^-1 J'r, and a step that INCREASES the residual norm
+// counts as converged (reduction < 0 * norm).  nalgebra 0.35 evaluation order as in the scoring kernel, plus:
+// dot products over the inliers keep eight partial sums (blas.rs `dot`), LU is partial pivoting with
+// multipliers scaled by the reciprocal pivot, triangular solves update column by column.
+// ---------------------------------------------------------------------------------------------------------
+namespace lm {
+
+struct Obs { // one match as the two homogeneous points
+    double p1[3], p2[3];
+};
+
+__host__ __device__ inline Obs make_obs(uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2)
+{
+    return Obs{{(double)x1, (double)y1, 1.0}, {(double)x2, (double)y2, 1.0}};
+}
+
+// dot product of two strided vectors (a column of the n x 7 Jacobian, or a plain vector)
+__host__ __device__ inline double long_dot(const double *a, uint32_t sa, const double *b, uint32_t sb, uint32_t n)
+{
+    double part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    uint32_t i = 0;
+    for (; n - i >= 8; i += 8)
+        for (uint32_t k = 0; k < 8; k++) part[k] += a[(size_t)(i + k) * sa] * b[(size_t)(i + k) * sb];
+    double total = 0.0;
+    for (uint32_t k = 0; k < 4; k++) total += part[k] + part[k + 4];
+    for (; i < n; i++) total += a[(size_t)i * sa] * b[(size_t)i * sb];
+    return total;
+}
+
+__host__ __device__ inline void matrix_of(const double (&q)[7], double (&M)[9]) // f_from_perspective_params, :442-449
+{
+    const double last = -(-q[0] * q[4] + q[6] * q[2] * q[4] + q[3] * q[1] - q[6] * q[1] * q[5]) / (-q[3] * q[2] + q[0] * q[5]);
+    for (int i = 0; i < 7; i++) M[i] = q[i];
+    M[7] = last;
+    M[8] = 1.0;
+}
+
+// row vector v' M and the chained product r . v, in nalgebra's orders
+__host__ __device__ inline void row_times(const double (&v)[3], const double (&M)[9], double (&out)[3])
+{
+    for (int j = 0; j < 3; j++) out[j] = (v[0] * M[j] + v[1] * M[3 + j]) + v[2] * M[6 + j];
+}
+__host__ __device__ inline double chain3(const double (&r)[3], const double (&v)[3])
+{
+    double acc = r[0] * v[0];
+    acc = r[1] * v[1] + acc;
+    return r[2] * v[2] + acc;
+}
+
+__host__ __device__ inline double residual_of(const double (&M)[9], const Obs &o) // reprojection_error, :461-471
+{
+    double r[3], mp1[3], mtp2[3];
+    row_times(o.p2, M, r);
+    const double top = chain3(r, o.p1);
+    for (int i = 0; i < 3; i++) {
+        const double row[3] = {M[3 * i], M[3 * i + 1], M[3 * i + 2]};
+        mp1[i] = chain3(row, o.p1);
+    }
+    row_times(o.p2, M, mtp2); // (M' p2)_i = dot(column i of M, p2): the same numbers as p2' M
+    return top * top / (mp1[0] * mp1[0] + mp1[1] * mp1[1] + mtp2[0] * mtp2[0] + mtp2[1] * mtp2[1]);
+}
+
+__host__ __device__ inline void gradient_of(const double (&M)[9], const Obs &o, double *out7) // f_jacobian, :473-512
+{
+    double mp1[3], mtp2[3];
+    for (int i = 0; i < 3; i++) {
+        const double row[3] = {M[3 * i], M[3 * i + 1], M[3 * i + 2]};
+        mp1[i] = chain3(row, o.p1);
+    }
+    for (int i = 0; i < 3; i++) mtp2[i] = (M[i] * o.p2[0] + M[3 + i] * o.p2[1]) + M[6 + i] * o.p2[2];
+    const double c = mp1[0] + mp1[1] + mtp2[0] + mtp2[1], d = c;
+    for (int e = 0; e < 7; e++) {
+        const int r = e / 3, k = e % 3;
+        const double a = o.p2[r] * o.p1[k]; // p2' E_rk p1: the other eight products are exact zeros
+        double rest[9];
+        for (int i = 0; i < 9; i++) rest[i] = M[i];
+        rest[3 * r + k] = 0.0;
+        double rv[3];
+        row_times(o.p2, rest, rv);
+        const double b = chain3(rv, o.p1), x = M[3 * r + k];
+        out7[e] = 2.0 * (a * x + b) * (a * d - b * c * c * x) / (c * c * x * x + d);
+    }
+}
+
+// (J'J + mu I) x = g, nalgebra's LU::new + LU::solve; false = "Failed to compute delta vector"
+__host__ __device__ inline bool solve7(double (&A)[49], double (&x)[7])
+{
+    constexpr int n = 7;
+    int swap_a[n], swap_b[n], n_swaps = 0;
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++)
+            if (fabs(A[r * n + c]) > fabs(A[p * n + c])) p = r;
+        const double pivot = A[p * n + c];
+        if (pivot == 0.0) continue;
+        if (p != c) {
+            swap_a[n_swaps] = c;
+            swap_b[n_swaps++] = p;
+            for (int k = 0; k < n; k++) {
+                const double tmp = A[c * n + k];
+                A[c * n + k] = A[p * n + k];
+                A[p * n + k] = tmp;
+            }
+        }
+        const double rp = 1.0 / pivot;
+        for (int r = c + 1; r < n; r++) A[r * n + c] *= rp;
+        for (int k = c + 1; k < n; k++) {
+            const double top = A[c * n + k];
+            for (int r = c + 1; r < n; r++) A[r * n + k] = -top * A[r * n + c] + A[r * n + k];
+        }
+    }
+    for (int i = 0; i < n_swaps; i++) {
+        const double tmp = x[swap_a[i]];
+        x[swap_a[i]] = x[swap_b[i]];
+        x[swap_b[i]] = tmp;
+    }
+    for (int c = 0; c < n; c++) {
+        const double v = x[c];
+        for (int r = c + 1; r < n; r++) x[r] = -v * A[r * n + c] + x[r];
+    }
+    for (int c = n - 1; c >= 0; c--) {
+        const double pivot = A[c * n + c];
+        if (pivot == 0.0) return false;
+        const double v = x[c] / pivot;
+        x[c] = v;
+        for (int r = 0; r < c; r++) x[r] = -v * A[r * n + c] + x[r];
+    }
+    return true;
+}
+
+// descending singular values of a 3x3 matrix from the eigenvalues of M'M (Jacobi rotations); they are only
+// compared with 1e-3 (:362-366, :418-423)
+__host__ __device__ inline void singular3(const double (&M)[9], double (&sv)[3])
+{
+    double g[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) g[i][j] = M[i] * M[j] + M[3 + i] * M[3 + j] + M[6 + i] * M[6 + j];
+    for (int sweep = 0; sweep < 32 && (g[0][1] != 0.0 || g[0][2] != 0.0 || g[1][2] != 0.0); sweep++)
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (g[p][q] == 0.0) continue;
+                const double th = (g[q][q] - g[p][p]) / (2.0 * g[p][q]);
+                const double t = __builtin_copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; k++) {
+                    const double u = g[k][p], v = g[k][q];
+                    g[k][p] = cs * u - sn * v;
+                    g[k][q] = sn * u + cs * v;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double u = g[p][k], v = g[q][k];
+                    g[p][k] = cs * u - sn * v;
+                    g[q][k] = sn * u + cs * v;
+                }
+            }
+    double a = g[0][0], b = g[1][1], c = g[2][2];
+    if (a < b) { const double t = a; a = b; b = t; }
+    if (b < c) { const double t = b; b = c; c = t; }
+    if (a < b) { const double t = a; a = b; b = t; }
+    sv[0] = sqrt(a > 0.0 ? a : 0.0);
+    sv[1] = sqrt(b > 0.0 ? b : 0.0);
+    sv[2] = sqrt(c > 0.0 ? c : 0.0);
+}
+
+// least_squares (:515-621) on this problem; false = Err.  Workspace: r, r_new [n], J [n x 7].
+__host__ __device__ inline bool levenberg_marquardt(double (&q)[7], const Obs *obs, uint32_t n, double *r, double *r_new,
+                                                    double *J)
+{
+    double M[9], g[7];
+    const auto evaluate = [&](const double (&at)[7], double *into) {
+        matrix_of(at, M);
+        for (uint32_t i = 0; i < n; i++) into[i] = residual_of(M, obs[i]);
+    };
+    const auto linearise = [&](const double (&at)[7], const double *res) { // Jacobian and J'r at `at`
+        matrix_of(at, M);
+        for (uint32_t i = 0; i < n; i++) gradient_of(M, obs[i], &J[(size_t)i * 7]);
+        for (int j = 0; j < 7; j++) g[j] = long_dot(J + j, 7, res, 1, n);
+    };
+    const auto largest = [](const double (&v)[7]) {
+        double m = v[0];
+        for (int j = 1; j < 7; j++)
+            if (m < v[j]) m = v[j];
+        return m;
+    };
+    const auto norm7 = [](const double (&v)[7]) { return sqrt(long_dot(v, 1, v, 1, 7)); };
+
+    evaluate(q, r);
+    linearise(q, r);
+    if (fabs(largest(g)) <= 1e-12) return true;
+    double mu = 0.0;
+    for (int j = 0; j < 7; j++) {
+        const double djj = long_dot(J + j, 7, J + j, 7, n);
+        if (j == 0 || djj >= mu) mu = djj;
+    }
+    mu *= 1e-3;
+    double nu = 2.0;
+    for (int iteration = 0; iteration < 1000; iteration++) {
+        double A[49];
+        for (int i = 0; i < 7; i++)
+            for (int j = 0; j < 7; j++) A[i * 7 + j] = long_dot(J + i, 7, J + j, 7, n);
+        for (int i = 0; i < 7; i++) A[i * 7 + i] += mu;
+        double step[7];
+        for (int j = 0; j < 7; j++) step[j] = g[j];
+        if (!solve7(A, step)) return false;
+        if (norm7(step) <= 1e-12 * (norm7(q) + 1e-12)) return true;
+        double trial[7], damped[7];
+        for (int j = 0; j < 7; j++) trial[j] = q[j] + step[j];
+        evaluate(trial, r_new);
+        const double before = long_dot(r, 1, r, 1, n);
+        const double after = long_dot(r_new, 1, r_new, 1, n);
+        for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + g[j];
+        const double rho = (before - after) / long_dot(step, 1, damped, 1, 7);
+        if (rho > 0.0) {
+            const bool converged = sqrt(before) - sqrt(after) < 0.0 * sqrt(before);
+            for (uint32_t i = 0; i < n; i++) r[i] = r_new[i];
+            for (int j = 0; j < 7; j++) q[j] = trial[j];
+            linearise(q, r);
+            if (converged || fabs(largest(g)) <= 1e-12) return true;
+            const double w = 2.0 * rho - 1.0, shrink = 1.0 - w * w * w;
+            mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
+            nu = 2.0;
+        } else {
+            mu *= nu;
+            nu *= 2.0;
+        }
+        if (sqrt(long_dot(r, 1, r, 1, n)) <= 1e-12) return true;
+    }
+    return false; // "Levenberg-Marquardt failed to converge"
+}
+
+// optimize_perspective_f (:391-426): F (normalised by F[2][2]) -> out, false = None
+__host__ __device__ inline bool optimize_perspective_f(const double (&F)[9], const Obs *obs, uint32_t n, double *r,
+                                                       double *r_new, double *J, double (&out)[9])
+{
+    double q[7];
+    for (int i = 0; i < 7; i++) q[i] = F[i]; // params_from_perspective_f, :429-440
+    if (!levenberg_marquardt(q, obs, n, r, r_new, J)) return false;
+    matrix_of(q, out);
+    const double Mt[9] = {out[0], out[3], out[6], out[1], out[4], out[7], out[2], out[5], out[8]};
+    double s[3];
+    singular3(Mt, s);
+    return !(fabs(s[1]) < 1e-3 || fabs(s[2]) > 1e-3); // :418-423
+}
+
+} // namespace lm
+
 __device__ __forceinline__ double reprojection_error(const double (&F)[9], double p1x, double p1y, double p2x,
                                                      double p2y)
 {
@@ -121,76 +374,70 @@ __device__ bool affine_model_from_sample(const uint4 (&sm)[4], double (&f)[9])
         a[i][2] = (double)sm[i].x;
         a[i][3] = (double)sm[i].y;
 #pragma unroll
-        for (int j = 0; j < 4; j++) mean[j] += a[i][j] / 4.0;
+        for (int j = 0; j < 4; j++) mean[j] += a[i][j] / 4.0; // row_mean(): exact for integer coordinates
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) a[i][j] -= mean[j];
-    double m[4][4], v[4][4];
+    // SVD of the centred 4x4 by one-sided (Hestenes) Jacobi: rotate pairs of COLUMNS of A until they are mutually
+    // orthogonal; then A = U S with column norms = singular values and the accumulated rotations V.  Unlike an
+    // eigen-decomposition of A'A this keeps the small singular directions to full relative accuracy.
+    double v[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc += a[k][i] * a[k][j];
-            m[i][j] = acc;
-            v[i][j] = i == j ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 30; sweep++) { // cyclic Jacobi, fixed pivot order (static indices)
-        double off = 0.0;
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-            for (int q = p + 1; q < 4; q++) off += m[p][q] * m[p][q];
-        if (off < 1e-280) break;
+        for (int j = 0; j < 4; j++) v[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 40; sweep++) { // fixed pivot order (static indices)
+        bool rotated = false;
 #pragma unroll
         for (int p = 0; p < 4; p++)
 #pragma unroll
             for (int q = p + 1; q < 4; q++) {
-                if (fabs(m[p][q]) < 1e-300) continue;
-                const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
-                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    alpha += a[k][p] * a[k][p];
+                    beta += a[k][q] * a[k][q];
+                    gamma += a[k][p] * a[k][q];
+                }
+                if (!(fabs(gamma) > 1e-300) || !(fabs(gamma) > 1e-17 * sqrt(alpha * beta))) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double tt = __builtin_copysign(1.0, zeta) / (fabs(zeta) + sqrt(zeta * zeta + 1.0));
                 const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const double mkp = m[k][p], mkq = m[k][q];
-                    m[k][p] = c * mkp - sn * mkq;
-                    m[k][q] = sn * mkp + c * mkq;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const double mpk = m[p][k], mqk = m[q][k];
-                    m[p][k] = c * mpk - sn * mqk;
-                    m[q][k] = sn * mpk + c * mqk;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - sn * akq;
+                    a[k][q] = sn * akp + c * akq;
                     const double vkp = v[k][p], vkq = v[k][q];
                     v[k][p] = c * vkp - sn * vkq;
                     v[k][q] = sn * vkp + c * vkq;
                 }
             }
+        if (!rotated) break;
     }
-    // smallest eigenvalue -> null vector; second largest singular value must be >= 1e-3 (:272-275)
-    const double ev[4] = {m[0][0], m[1][1], m[2][2], m[3][3]};
+    double nrm[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) nrm[j] = sqrt(a[0][j] * a[0][j] + a[1][j] * a[1][j] + a[2][j] * a[2][j] + a[3][j] * a[3][j]);
+    // smallest singular value -> null vector (last row of V'); the second largest must be >= 1e-3 (:272-275)
     int last = 0;
-    double lo = ev[0], hi1 = -1.0, hi2 = -1.0;
+    double lo = nrm[0], hi1 = -1.0, hi2 = -1.0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        if (ev[i] < lo) {
-            lo = ev[i];
+        if (nrm[i] < lo) {
+            lo = nrm[i];
             last = i;
         }
-        if (ev[i] > hi1) {
+        if (nrm[i] > hi1) {
             hi2 = hi1;
-            hi1 = ev[i];
-        } else if (ev[i] > hi2) {
-            hi2 = ev[i];
+            hi1 = nrm[i];
+        } else if (nrm[i] > hi2) {
+            hi2 = nrm[i];
         }
     }
-    if (sqrt(fmax(hi2, 0.0)) < 0.001) return false;
+    if (hi2 < 0.001) return false;
     double vt[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) vt[k] = last == 0 ? v[k][0] : (last == 1 ? v[k][1] : (last == 2 ? v[k][2] : v[k][3]));
@@ -204,6 +451,7 @@ __device__ bool affine_model_from_sample(const uint4 (&sm)[4], double (&f)[9])
 __global__ __launch_bounds__(64) void ransac_generate_affine_kernel(const uint4 *__restrict__ matches, uint32_t limit,
                                                                      double t, unsigned long long seed,
                                                                      uint32_t round, uint32_t H,
+                                                                     const uint32_t *__restrict__ sample_idx,
                                                                      double *__restrict__ F)
 {
     const uint32_t h = blockIdx.x * 64 + threadIdx.x;
@@ -211,6 +459,11 @@ __global__ __launch_bounds__(64) void ransac_generate_affine_kernel(const uint4 
     unsigned long long state = mix64(seed ^ mix64(((unsigned long long)round << 32) | h));
     uint4 sm[4];
     int have = 0;
+    if (sample_idx) { // the caller's samples (test hook)
+#pragma unroll
+        for (int i = 0; i < 4; i++) sm[i] = matches[sample_idx[(size_t)h * 4 + i]];
+        have = 4;
+    }
     for (int tries = 0; tries < 256 && have < 4; tries++) { // choose_inliers, :155-175 (bounded here)
         state = mix64(state + 0x9E3779B97F4A7C15ull);
         const uint32_t idx = (uint32_t)(((state >> 32) * (unsigned long long)limit) >> 32);
@@ -252,53 +505,13 @@ __global__ __launch_bounds__(64) void ransac_generate_affine_kernel(const uint4 
 // (second singular value >= 1e-3, third <= 1e-3), normalisation by F[2][2] and sign-consistency test -
 // then validate_f's finiteness and sample-fit checks (:197-209).  The null space comes from a Householder
 // QR of A^T (its last two Q columns) instead of an SVD: any basis of the null space gives the same pencil,
-// hence the same F's.  validate_f's per-hypothesis LM (:205) is skipped: a 7-point solution has zero
-// reprojection error on its own sample, that optimisation's fixed point.  Statistical parity, as for the
-// affine model; tests compare this generator with the numpy restatement on identical samples.
+// hence the same F's.  validate_f's per-hypothesis optimize_perspective_f (:201-205) runs here too (lm:: above,
+// n = 7), including its rank test on the re-parametrised matrix.  Statistical parity, as for the affine model;
+// tests compare this generator with an independent numpy restatement (LAPACK underneath) on identical samples.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double det3(const double (&m)[9])
 {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-}
-
-// singular values of a 3x3 matrix, descending (eigenvalues of F^T F by cyclic Jacobi)
-__device__ void singular_values3(const double (&f)[9], double (&sv)[3])
-{
-    double m[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) m[i][j] = f[0 * 3 + i] * f[0 * 3 + j] + f[1 * 3 + i] * f[1 * 3 + j] + f[2 * 3 + i] * f[2 * 3 + j];
-    for (int sweep = 0; sweep < 12; sweep++) {
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int q = p + 1; q < 3; q++) {
-                if (fabs(m[p][q]) < 1e-300) continue;
-                const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
-                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const double mkp = m[k][p], mkq = m[k][q];
-                    m[k][p] = c * mkp - sn * mkq;
-                    m[k][q] = sn * mkp + c * mkq;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const double mpk = m[p][k], mqk = m[q][k];
-                    m[p][k] = c * mpk - sn * mqk;
-                    m[q][k] = sn * mpk + c * mqk;
-                }
-            }
-    }
-    double a = sqrt(fmax(m[0][0], 0.0)), b = sqrt(fmax(m[1][1], 0.0)), c = sqrt(fmax(m[2][2], 0.0));
-    if (a < b) { const double t = a; a = b; b = t; }
-    if (b < c) { const double t = b; b = c; c = t; }
-    if (a < b) { const double t = a; a = b; b = t; }
-    sv[0] = a;
-    sv[1] = b;
-    sv[2] = c;
 }
 
 // real roots of c0 x^3 + c1 x^2 + c2 x + c3 (c0 != 0), polished by Newton steps; returns their number
@@ -421,6 +634,9 @@ __device__ int perspective_models_from_sample(const uint4 (&sm)[7], double t, do
     const double c3 = d[1][1][1];
     ok[0] = ok[1] = ok[2] = false;
     if (!(fabs(c0) > 1e-300) || !(fabs(c0) < __builtin_inf())) return 0;
+    lm::Obs obs[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) obs[i] = lm::make_obs(sm[i].x, sm[i].y, sm[i].z, sm[i].w);
     double roots[3];
     const int nr = cubic_real_roots(c0, c1, c2, c3, roots);
     for (int k = 0; k < nr; k++) {
@@ -429,7 +645,10 @@ __device__ int perspective_models_from_sample(const uint4 (&sm)[7], double t, do
 #pragma unroll
         for (int i = 0; i < 9; i++) f[i] = a * n1[i] + (1.0 - a) * n2[i]; // :359
         double sv[3];
-        singular_values3(f, sv);
+        {
+            const double ft[9] = {f[0], f[3], f[6], f[1], f[4], f[7], f[2], f[5], f[8]};
+            lm::singular3(ft, sv); // f.transpose().svd, :361
+        }
         bool good = !(sv[1] < 0.001) && !(sv[2] > 0.001); // :362-366
         // e1: null vector of F^T (last right singular vector of svd(F^T), :372-373) = normal of F's columns
         double e1[3], best = -1.0;
@@ -463,6 +682,16 @@ __device__ int perspective_models_from_sample(const uint4 (&sm)[7], double t, do
         good = good && ((s0 > 0.0 && s1 > 0.0 && s2 > 0.0) || (s0 < 0.0 && s1 < 0.0 && s2 < 0.0));
 #pragma unroll
         for (int i = 0; i < 9; i++) good = good && fabs(fout[k][i]) < __builtin_inf(); // validate_f, :197-199
+        if (good) {
+            // validate_f, :201-205: optimize_perspective_f over the sample itself.  A 7-point solution has (nearly)
+            // zero reprojection error on its sample, so the LM loop almost always returns at its gradient test -
+            // but the hypothesis that goes on is f_from_perspective_params(params) (F[2][1] rebuilt from det = 0,
+            // F[2][2] = 1 exactly) and it has to pass the rank test on THAT matrix (:418-423).
+            double r[7], r_new[7], J[49], opt[9];
+            good = lm::optimize_perspective_f(fout[k], obs, 7, r, r_new, J, opt);
+#pragma unroll
+            for (int i = 0; i < 9; i++) fout[k][i] = opt[i];
+        }
         if (good) {
 #pragma unroll
             for (int i = 0; i < 7; i++) { // all sample points must fit, :206-209
@@ -687,7 +916,8 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
     for (uint32_t round = 0; e == hipSuccess && round < RANSAC_K / CHECK_INTERVAL; round++) {
         hipLaunchKernelGGL(ransac_generate_affine_kernel, dim3((CHECK_INTERVAL + 63) / 64), dim3(64), 0, s, m4,
-                           std::min(N, TOP_INLIERS), RANSAC_T, (unsigned long long)seed, round, CHECK_INTERVAL, d_F);
+                           std::min(N, TOP_INLIERS), RANSAC_T, (unsigned long long)seed, round, CHECK_INTERVAL,
+                           (const uint32_t *)nullptr, d_F);
         launch_ransac_score(d_F, CHECK_INTERVAL, d_m, N, RANSAC_T, d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, CHECK_INTERVAL,
                            RANSAC_D + RANSAC_N, d_best);
@@ -807,282 +1037,156 @@ extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *match
                          });
 }
 
-extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t *matches, uint32_t N,
-                                               const uint32_t *sample_idx, uint32_t B, double t, double *out_F)
+// Test hooks of the two generators: the models of B caller-chosen samples (`per` match indices each).
+namespace {
+template <typename Launch>
+int models_of_samples(cvhip_device *dev, const uint32_t *matches, uint32_t N, const uint32_t *sample_idx, uint32_t B,
+                      uint32_t per, uint32_t slots, double *out_F, const char *what, Launch launch)
 {
     if (!dev || !matches || !sample_idx || !out_F) return fail(CVHIP_ERR_INVALID, "null argument");
     if (B == 0) return CVHIP_OK;
-    for (size_t i = 0; i < (size_t)B * 7; i++)
+    for (size_t i = 0; i < (size_t)B * per; i++)
         if (sample_idx[i] >= N) return fail(CVHIP_ERR_INVALID, "sample index out of range");
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     hipStream_t s = dev->d.stream;
     uint32_t *d_m = nullptr, *d_idx = nullptr;
     double *d_F = nullptr;
+    const size_t f_bytes = (size_t)B * slots * 9 * sizeof(double);
     hipError_t e = hipMalloc(&d_m, (size_t)N * 16);
-    if (e == hipSuccess) e = hipMalloc(&d_idx, (size_t)B * 7 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_F, (size_t)B * 27 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_idx, (size_t)B * per * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_F, f_bytes);
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, sample_idx, (size_t)B * 7 * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, sample_idx, (size_t)B * per * sizeof(uint32_t), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(ransac_generate_perspective_kernel, dim3((B + 63) / 64), dim3(64), 0, s,
-                           reinterpret_cast<const uint4 *>(d_m), N, t, 0ull, 0u, B, (const uint32_t *)d_idx, d_F);
+        launch(reinterpret_cast<const uint4 *>(d_m), (const uint32_t *)d_idx, d_F, s);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out_F, d_F, (size_t)B * 27 * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_F, d_F, f_bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(d_m);
     (void)hipFree(d_idx);
     (void)hipFree(d_F);
-    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("ransac_perspective_models: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
     return CVHIP_OK;
 }
-
-// ---------------------------------------------------------------------------------------------------------
-// The final refit of the perspective model: optimize_perspective_f (fundamentalmatrix.rs:391-426) with the
-// reference's own Levenberg-Marquardt loop (least_squares, :515-621) and analytic Jacobian (f_jacobian,
-// :473-512).  Host arithmetic like the reference's (a 7x7 solve per iteration over <= a few thousand inliers);
-// hypothesis generation and scoring are the device's part.  The loop is kept as written there, also where it
-// is not the textbook method: the Jacobian's denominator terms are plain sums c = d = (F p1)_0 + (F p1)_1 +
-// (F' p2)_0 + (F' p2)_1, the step is params + (J'J + mu I)^-1 J'r, and a step that INCREASES the residual norm
-// counts as converged (reduction < 0 * norm).  nalgebra 0.35 evaluation order as in the scoring kernel, plus:
-// dot products over the inliers keep eight partial sums (blas.rs `dot`), LU is partial pivoting with
-// multipliers scaled by the reciprocal pivot, triangular solves update column by column.
-// ---------------------------------------------------------------------------------------------------------
-namespace {
-
-using Params7 = std::array<double, 7>;
-using Mat3 = std::array<double, 9>; // row-major
-
-struct Obs { // one match as the two homogeneous points
-    double p1[3], p2[3];
-    explicit Obs(const uint32_t *m) : p1{(double)m[0], (double)m[1], 1.0}, p2{(double)m[2], (double)m[3], 1.0} {}
-};
-
-// strided view of a column of the n x 7 Jacobian or of a plain vector
-struct Strided {
-    const double *p;
-    size_t step;
-    double operator[](size_t i) const { return p[i * step]; }
-};
-
-double long_dot(Strided a, Strided b, uint32_t n)
-{
-    double part[8] = {};
-    uint32_t i = 0;
-    for (; n - i >= 8; i += 8)
-        for (uint32_t k = 0; k < 8; k++) part[k] += a[i + k] * b[i + k];
-    double total = 0.0;
-    for (uint32_t k = 0; k < 4; k++) total += part[k] + part[k + 4];
-    for (; i < n; i++) total += a[i] * b[i];
-    return total;
-}
-
-Mat3 matrix_of(const Params7 &q) // f_from_perspective_params, :442-449: det = 0 by construction
-{
-    const double last = -(-q[0] * q[4] + q[6] * q[2] * q[4] + q[3] * q[1] - q[6] * q[1] * q[5]) / (-q[3] * q[2] + q[0] * q[5]);
-    return Mat3{q[0], q[1], q[2], q[3], q[4], q[5], q[6], last, 1.0};
-}
-
-// row vector p2' M, column vector M p1, M' p2 in nalgebra's orders
-inline void row_times(const double (&v)[3], const Mat3 &M, double (&out)[3])
-{
-    for (int j = 0; j < 3; j++) out[j] = (v[0] * M[j] + v[1] * M[3 + j]) + v[2] * M[6 + j];
-}
-inline double chain3(const double (&r)[3], const double (&v)[3])
-{
-    double acc = r[0] * v[0];
-    acc = r[1] * v[1] + acc;
-    return r[2] * v[2] + acc;
-}
-
-double residual_of(const Mat3 &M, const Obs &o) // reprojection_error, :461-471
-{
-    double r[3], mp1[3], mtp2[3];
-    row_times(o.p2, M, r);
-    const double top = chain3(r, o.p1);
-    for (int i = 0; i < 3; i++) {
-        const double row[3] = {M[3 * i], M[3 * i + 1], M[3 * i + 2]};
-        mp1[i] = chain3(row, o.p1);
-    }
-    row_times(o.p2, M, mtp2); // (M' p2)_i = dot(column i of M, p2): the same numbers as p2' M
-    return top * top / (mp1[0] * mp1[0] + mp1[1] * mp1[1] + mtp2[0] * mtp2[0] + mtp2[1] * mtp2[1]);
-}
-
-void gradient_of(const Mat3 &M, const Obs &o, double *out7) // f_jacobian, :473-512
-{
-    double mp1[3], mtp2[3];
-    for (int i = 0; i < 3; i++) {
-        const double row[3] = {M[3 * i], M[3 * i + 1], M[3 * i + 2]};
-        mp1[i] = chain3(row, o.p1);
-    }
-    for (int i = 0; i < 3; i++) mtp2[i] = (M[i] * o.p2[0] + M[3 + i] * o.p2[1]) + M[6 + i] * o.p2[2];
-    const double c = mp1[0] + mp1[1] + mtp2[0] + mtp2[1], d = c;
-    for (int e = 0; e < 7; e++) {
-        const int r = e / 3, k = e % 3;
-        const double a = o.p2[r] * o.p1[k]; // p2' E_rk p1: the other eight products are exact zeros
-        Mat3 rest = M;
-        rest[3 * r + k] = 0.0;
-        double rv[3];
-        row_times(o.p2, rest, rv);
-        const double b = chain3(rv, o.p1), x = M[3 * r + k];
-        out7[e] = 2.0 * (a * x + b) * (a * d - b * c * c * x) / (c * c * x * x + d);
-    }
-}
-
-// (J'J + mu I) x = g, nalgebra's LU::new + LU::solve; false = "Failed to compute delta vector"
-bool solve7(std::array<double, 49> &A, Params7 &x)
-{
-    constexpr int n = 7;
-    std::vector<std::pair<int, int>> swaps;
-    for (int c = 0; c < n; c++) {
-        int p = c;
-        for (int r = c + 1; r < n; r++)
-            if (std::fabs(A[r * n + c]) > std::fabs(A[p * n + c])) p = r;
-        const double pivot = A[p * n + c];
-        if (pivot == 0.0) continue;
-        if (p != c) {
-            swaps.emplace_back(c, p);
-            for (int k = 0; k < n; k++) std::swap(A[c * n + k], A[p * n + k]);
-        }
-        const double rp = 1.0 / pivot;
-        for (int r = c + 1; r < n; r++) A[r * n + c] *= rp;
-        for (int k = c + 1; k < n; k++) {
-            const double top = A[c * n + k];
-            for (int r = c + 1; r < n; r++) A[r * n + k] = -top * A[r * n + c] + A[r * n + k];
-        }
-    }
-    for (const auto &s : swaps) std::swap(x[s.first], x[s.second]);
-    for (int c = 0; c < n; c++) {
-        const double v = x[c];
-        for (int r = c + 1; r < n; r++) x[r] = -v * A[r * n + c] + x[r];
-    }
-    for (int c = n - 1; c >= 0; c--) {
-        const double pivot = A[c * n + c];
-        if (pivot == 0.0) return false;
-        const double v = x[c] / pivot;
-        x[c] = v;
-        for (int r = 0; r < c; r++) x[r] = -v * A[r * n + c] + x[r];
-    }
-    return true;
-}
-
-// descending singular values of a 3x3 matrix from the eigenvalues of M'M (Jacobi rotations); they are only
-// compared with 1e-3 (:418-423)
-std::array<double, 3> singular3(const Mat3 &M)
-{
-    double g[3][3];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) g[i][j] = M[i] * M[j] + M[3 + i] * M[3 + j] + M[6 + i] * M[6 + j];
-    for (int sweep = 0; sweep < 32 && (g[0][1] != 0.0 || g[0][2] != 0.0 || g[1][2] != 0.0); sweep++)
-        for (int p = 0; p < 2; p++)
-            for (int q = p + 1; q < 3; q++) {
-                if (g[p][q] == 0.0) continue;
-                const double th = (g[q][q] - g[p][p]) / (2.0 * g[p][q]);
-                const double t = std::copysign(1.0, th) / (std::fabs(th) + std::sqrt(th * th + 1.0));
-                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < 3; k++) {
-                    const double u = g[k][p], v = g[k][q];
-                    g[k][p] = cs * u - sn * v;
-                    g[k][q] = sn * u + cs * v;
-                }
-                for (int k = 0; k < 3; k++) {
-                    const double u = g[p][k], v = g[q][k];
-                    g[p][k] = cs * u - sn * v;
-                    g[q][k] = sn * u + cs * v;
-                }
-            }
-    std::array<double, 3> ev{g[0][0], g[1][1], g[2][2]};
-    std::sort(ev.begin(), ev.end(), std::greater<double>());
-    for (double &v : ev) v = std::sqrt(v > 0.0 ? v : 0.0);
-    return ev;
-}
-
-// least_squares (:515-621) on this problem; false = Err
-bool levenberg_marquardt(Params7 &q, const std::vector<Obs> &obs)
-{
-    const uint32_t n = (uint32_t)obs.size();
-    std::vector<double> r(n), r_new(n), J((size_t)n * 7);
-    const auto column = [&](int j) { return Strided{J.data() + j, 7}; };
-    const auto plain = [](const double *p) { return Strided{p, 1}; };
-    const auto evaluate = [&](const Params7 &at, std::vector<double> &into) {
-        const Mat3 M = matrix_of(at);
-        for (uint32_t i = 0; i < n; i++) into[i] = residual_of(M, obs[i]);
-    };
-    Params7 g{};
-    const auto linearise = [&](const Params7 &at) { // Jacobian and J'r at `at` (r already holds its residuals)
-        const Mat3 M = matrix_of(at);
-        for (uint32_t i = 0; i < n; i++) gradient_of(M, obs[i], &J[(size_t)i * 7]);
-        for (int j = 0; j < 7; j++) g[j] = long_dot(column(j), plain(r.data()), n);
-    };
-    const auto largest = [](const Params7 &v) { return *std::max_element(v.begin(), v.end()); };
-    const auto norm7 = [&](const Params7 &v) { return std::sqrt(long_dot(plain(v.data()), plain(v.data()), 7)); };
-
-    evaluate(q, r);
-    linearise(q);
-    if (std::fabs(largest(g)) <= 1e-12) return true;
-    double mu = 0.0;
-    for (int j = 0; j < 7; j++) {
-        const double djj = long_dot(column(j), column(j), n);
-        if (j == 0 || djj >= mu) mu = djj;
-    }
-    mu *= 1e-3;
-    double nu = 2.0;
-    for (int iteration = 0; iteration < 1000; iteration++) {
-        std::array<double, 49> A;
-        for (int i = 0; i < 7; i++)
-            for (int j = 0; j < 7; j++) A[i * 7 + j] = long_dot(column(i), column(j), n);
-        for (int i = 0; i < 7; i++) A[i * 7 + i] += mu;
-        Params7 step = g;
-        if (!solve7(A, step)) return false;
-        if (norm7(step) <= 1e-12 * (norm7(q) + 1e-12)) return true;
-        Params7 trial, damped;
-        for (int j = 0; j < 7; j++) trial[j] = q[j] + step[j];
-        evaluate(trial, r_new);
-        const double before = long_dot(plain(r.data()), plain(r.data()), n);
-        const double after = long_dot(plain(r_new.data()), plain(r_new.data()), n);
-        for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + g[j];
-        const double rho = (before - after) / long_dot(plain(step.data()), plain(damped.data()), 7);
-        if (rho > 0.0) {
-            const bool converged = std::sqrt(before) - std::sqrt(after) < 0.0 * std::sqrt(before);
-            r.swap(r_new);
-            q = trial;
-            linearise(q);
-            if (converged || std::fabs(largest(g)) <= 1e-12) return true;
-            const double w = 2.0 * rho - 1.0, shrink = 1.0 - w * w * w;
-            mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
-            nu = 2.0;
-        } else {
-            mu *= nu;
-            nu *= 2.0;
-        }
-        if (std::sqrt(long_dot(plain(r.data()), plain(r.data()), n)) <= 1e-12) return true;
-    }
-    return false; // "Levenberg-Marquardt failed to converge"
-}
-
 } // namespace
+
+extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t *matches, uint32_t N,
+                                               const uint32_t *sample_idx, uint32_t B, double t, double *out_F)
+{
+    return models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
+                             [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
+                                 hipLaunchKernelGGL(ransac_generate_perspective_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m4,
+                                                    N, t, 0ull, 0u, B, idx, d_F);
+                             });
+}
+
+extern "C" int cvhip_ransac_affine_models(cvhip_device *dev, const uint32_t *matches, uint32_t N,
+                                          const uint32_t *sample_idx, uint32_t B, double t, double *out_F)
+{
+    return models_of_samples(dev, matches, N, sample_idx, B, 4, 1, out_F, "ransac_affine_models",
+                             [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
+                                 hipLaunchKernelGGL(ransac_generate_affine_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m4, N, t,
+                                                    0ull, 0u, B, idx, d_F);
+                             });
+}
 
 extern "C" int cvhip_optimize_perspective_f(const double *F, const uint32_t *matches, uint32_t n, double *out_F,
                                             int *out_refined)
 {
     if (!F || !out_F || !out_refined || (n && !matches)) return cvhip::fail(CVHIP_ERR_INVALID, "cvhip_optimize_perspective_f: null argument");
     try {
-        std::vector<Obs> obs;
+        std::vector<lm::Obs> obs;
         obs.reserve(n);
-        for (uint32_t i = 0; i < n; i++) obs.emplace_back(matches + (size_t)i * 4);
-        Params7 q{F[0], F[1], F[2], F[3], F[4], F[5], F[6]}; // params_from_perspective_f, :429-440
-        bool ok = levenberg_marquardt(q, obs);
-        Mat3 M{};
-        if (ok) {
-            M = matrix_of(q);
-            const Mat3 Mt{M[0], M[3], M[6], M[1], M[4], M[7], M[2], M[5], M[8]};
-            const auto s = singular3(Mt);
-            if (std::fabs(s[1]) < 1e-3 || std::fabs(s[2]) > 1e-3) ok = false; // :418-423
-        }
+        for (uint32_t i = 0; i < n; i++) obs.push_back(lm::make_obs(matches[4 * (size_t)i], matches[4 * (size_t)i + 1], matches[4 * (size_t)i + 2], matches[4 * (size_t)i + 3]));
+        std::vector<double> r(n), r_new(n), J((size_t)n * 7);
+        double Fin[9], M[9];
+        for (int k = 0; k < 9; k++) Fin[k] = F[k];
+        const bool ok = lm::optimize_perspective_f(Fin, obs.data(), n, r.data(), r_new.data(), J.data(), M);
         *out_refined = ok ? 1 : 0;
         for (int k = 0; k < 9; k++) out_F[k] = ok ? M[k] : F[k]; // optimize_result: .unwrap_or(res.f), :246
         return CVHIP_OK;
     } catch (const std::bad_alloc &) {
         return cvhip::fail(CVHIP_ERR_NOMEM, "cvhip_optimize_perspective_f: out of host memory");
+    }
+}
+
+// fits_model (:452-458) of one F for every match: the inlier filter of optimize_result (:233-236, 248-254).
+extern "C" int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t N, double t,
+                                uint8_t *out_mask)
+{
+    if (!dev || !F || (!matches && N) || (!out_mask && N)) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (N == 0) return CVHIP_OK;
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    uint32_t *d_m = nullptr;
+    RansacBest *d_best = nullptr;
+    uint8_t *d_mask = nullptr;
+    RansacBest h_best;
+    std::memset(&h_best, 0, sizeof(h_best));
+    for (int i = 0; i < 9; i++) h_best.f[i] = F[i];
+    hipError_t e = hipMalloc(&d_m, (size_t)N * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_best, sizeof(RansacBest));
+    if (e == hipSuccess) e = hipMalloc(&d_mask, N);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_best, &h_best, sizeof(RansacBest), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ransac_inlier_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_best,
+                           reinterpret_cast<const uint4 *>(d_m), N, t, d_mask);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_mask, d_mask, N, dev_ptr(out_mask) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_m);
+    (void)hipFree(d_best);
+    (void)hipFree(d_mask);
+    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("fits_model: ") + hipGetErrorString(e));
+    return CVHIP_OK;
+}
+
+// FundamentalMatrix::new(projection, max_dimension).find_ransac(matches) as one call (fundamentalmatrix.rs:72-147
+// + optimize_result :231-257): the device RANSAC of the model, then for the perspective model the reference's LM
+// refit of the winner on its inliers and the re-selection of the inliers with the refitted matrix.
+extern "C" int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32_t *matches, uint32_t N, double max_dimension,
+                                 uint64_t seed, double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask)
+{
+    if (projection != 0 && projection != 1) return fail(CVHIP_ERR_INVALID, "projection must be 0 or 1");
+    if (projection == 0) return cvhip_ransac_affine(dev, matches, N, seed, out_F, out_inlier_count, out_inlier_mask);
+    if (!dev || !matches || !out_F) return fail(CVHIP_ERR_INVALID, "null argument");
+    try {
+        std::vector<uint32_t> host_m;
+        const uint32_t *hm = matches;
+        if (dev_ptr(matches)) { // the refit is host arithmetic: it needs the inliers on the host
+            host_m.resize((size_t)N * 4);
+            CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+            CVHIP_TRY_HIP(hipMemcpy(host_m.data(), matches, (size_t)N * 16, hipMemcpyDeviceToHost));
+            hm = host_m.data();
+        }
+        std::vector<uint8_t> mask(N ? N : 1);
+        uint32_t cnt = 0;
+        double F0[9];
+        CVHIP_TRY(cvhip_ransac_perspective(dev, matches, N, max_dimension, seed, 0, F0, &cnt, mask.data()));
+        std::vector<uint32_t> inl;
+        inl.reserve((size_t)cnt * 4);
+        for (uint32_t i = 0; i < N; i++)
+            if (mask[i]) inl.insert(inl.end(), hm + 4 * (size_t)i, hm + 4 * (size_t)i + 4);
+        int refined = 0;
+        CVHIP_TRY(cvhip_optimize_perspective_f(F0, inl.data(), (uint32_t)(inl.size() / 4), out_F, &refined)); // :246
+        // :248-254 - the inliers of the refitted matrix (of F0 itself where the refit returned None)
+        const double t = 10.0 / 1000.0 * max_dimension;
+        uint32_t n_in = 0;
+        for (uint32_t i = 0; i < N; i++) { // fits_model on the host: N <= a few 10^4, once
+            const lm::Obs o = lm::make_obs(hm[4 * (size_t)i], hm[4 * (size_t)i + 1], hm[4 * (size_t)i + 2], hm[4 * (size_t)i + 3]);
+            double M[9];
+            for (int k = 0; k < 9; k++) M[k] = out_F[k];
+            const double err = lm::residual_of(M, o);
+            const bool in = std::fabs(err) < __builtin_inf() && !(std::fabs(err) > t);
+            if (out_inlier_mask) out_inlier_mask[i] = in ? 1 : 0;
+            n_in += in ? 1u : 0u;
+        }
+        if (out_inlier_count) *out_inlier_count = n_in;
+        return CVHIP_OK;
+    } catch (const std::bad_alloc &) {
+        return cvhip::fail(CVHIP_ERR_NOMEM, "cvhip_find_ransac: out of host memory");
     }
 }

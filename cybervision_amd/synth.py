@@ -161,3 +161,91 @@ def f_tilt(theta_deg: float) -> np.ndarray:
     t = math.radians(theta_deg)
     s, c = math.sin(t), math.cos(t)
     return np.array([[0.0, 0.0, -s], [0.0, 0.0, c], [s, -c, 0.0]])
+
+
+# ---------------------------------------------------------------------------------------------
+# Three-view perspective scene (BASELINE config 5): one textured surface seen by three pinhole cameras.
+# The surface is a depth map Z0 over view 0's image plane (the "canvas"); view i is the canvas image
+# resampled through the exact projective map of camera i, so every pair of views has a true fundamental
+# matrix F_ij = K^-T [t_ij]x R_ij K^-1.  Only + - * / and floor on float64 (IEEE-exact, no libm per pixel),
+# so every platform renders identical bytes.
+# ---------------------------------------------------------------------------------------------
+def _rot(ax: float, ay: float, az: float) -> np.ndarray:
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def sfm_cameras(size: int):
+    """K and the three poses (R_i, t_i), X_cam_i = R_i X + t_i.  Mostly sideways translation with very small
+    rotations: the reference's rank test on the F22-normalised matrix (fundamentalmatrix.rs:362-366, 418-423)
+    accepts such geometry, which is also what its stereo use case looks like."""
+    f = 0.9 * size
+    K = np.array([[f, 0.0, size / 2.0], [0.0, f, size / 2.0], [0.0, 0.0, 1.0]])
+    poses = [(np.eye(3), np.zeros(3)),
+             (_rot(0.0005, -0.0010, 0.0004), np.array([-0.060, 0.002, 0.001])),
+             (_rot(-0.0004, 0.0008, -0.0003), np.array([0.050, -0.0015, -0.0012]))]
+    return K, poses
+
+
+def sfm_true_f(K, pose_i, pose_j):
+    """F with x_j^T F x_i = 0, normalised by F[2][2] like the reference's models."""
+    Ri, ti = pose_i
+    Rj, tj = pose_j
+    R = Rj @ Ri.T
+    t = tj - R @ ti
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(K)
+    F = Ki.T @ tx @ R @ Ki
+    return F / F[2, 2]
+
+
+def _sfm_depth(x, y, size: int):
+    """Z0 over the canvas: a smooth bump, 1.0 at the border down to 0.85 in the middle (polynomial only)."""
+    u, v = x / size, y / size
+    return 1.0 - 0.15 * (16.0 * u * (1.0 - u) * v * (1.0 - v))
+
+
+def _bilinear_u8(img: np.ndarray, x, y):
+    """Bilinear sample of a u8 image at float coordinates, 8.8 fixed-point weights, clamped at the border."""
+    h, w = img.shape
+    xf, yf = np.floor(x), np.floor(y)
+    fx = np.floor((x - xf) * 256.0).astype(np.int64)
+    fy = np.floor((y - yf) * 256.0).astype(np.int64)
+    x0 = np.clip(xf.astype(np.int64), 0, w - 1)
+    y0 = np.clip(yf.astype(np.int64), 0, h - 1)
+    x1 = np.clip(x0 + 1, 0, w - 1)
+    y1 = np.clip(y0 + 1, 0, h - 1)
+    v = img.astype(np.int64)
+    top = v[y0, x0] * (256 - fx) + v[y0, x1] * fx
+    bot = v[y1, x0] * (256 - fx) + v[y1, x1] * fx
+    return ((top * (256 - fy) + bot * fy + 32768) >> 16).astype(np.uint8)
+
+
+def make_sfm_views(size: int, seed: int = 1234, blocks: int | None = None):
+    """-> (views [3 x (size, size) uint8], K, poses).  The canvas carries the value-noise texture plus a layer of
+    rectangles (FAST corners); it is `size + 2*margin` wide so that all three views stay inside it."""
+    margin = max(size // 8, 16)
+    cw = size + 2 * margin
+    xs = np.arange(cw, dtype=np.int64)[None, :]
+    ys = np.arange(cw, dtype=np.int64)[:, None]
+    canvas = np.clip(texture(xs, ys, seed), 0, 255).astype(np.uint8)
+    canvas = add_blocks(canvas, count=blocks if blocks is not None else max(size * size // 2600, 40), seed=seed + 70)
+    K, poses = sfm_cameras(size)
+    Ki = np.linalg.inv(K)
+    views = []
+    gx, gy = np.meshgrid(np.arange(size, dtype=np.float64), np.arange(size, dtype=np.float64))
+    for R, t in poses:
+        # invert p_i = proj(K (R Z0(p0) K^-1 p0 + t)) for p0 by fixed-point iteration on the displacement
+        px, py = gx.copy(), gy.copy()
+        for _ in range(12):
+            z = _sfm_depth(px, py, size)
+            X = [z * (Ki[r, 0] * px + Ki[r, 1] * py + Ki[r, 2]) for r in range(3)]
+            Y = [R[r, 0] * X[0] + R[r, 1] * X[1] + R[r, 2] * X[2] + t[r] for r in range(3)]
+            q = [K[r, 0] * Y[0] + K[r, 1] * Y[1] + K[r, 2] * Y[2] for r in range(3)]
+            fx, fy = q[0] / q[2], q[1] / q[2]
+            px, py = px + (gx - fx), py + (gy - fy)
+        views.append(np.ascontiguousarray(_bilinear_u8(canvas, px + margin, py + margin)))
+    return views, K, poses

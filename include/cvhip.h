@@ -251,18 +251,36 @@ int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, 
  * system, the determinant cubic, the reference's rank and sign-consistency checks, up to three roots),
  * every surviving root scored against ALL matches, best = most inliers then smallest mean error, early
  * exit above 50 000 inliers; t = 0.01 * max_dimension.  `rounds` = number of 50 000-sample rounds (0 or
- * more than 20 = the reference's 20).  Not done here: validate_f's per-hypothesis LM (:205; a 7-point
- * solution has zero reprojection error on its own sample, that optimisation's fixed point) and the final
- * LM refit of optimize_result (:246-256): cvhip_optimize_perspective_f below, called by the host layers.  out_F: the best hypothesis
+ * more than 20 = the reference's 20).  validate_f's per-hypothesis optimize_perspective_f (:201-205: the LM
+ * over the sample and the rank test on the re-parametrised matrix) runs on the device with the rest.  Not done
+ * here: the final LM refit of optimize_result (:246-256): cvhip_optimize_perspective_f below, called by the
+ * host layers.  out_F: the best hypothesis
  * (normalised by F[2][2]); mask/count: its inliers.  Statistical parity, as above. */
 int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension,
                              uint64_t seed, uint32_t rounds, double *out_F, uint32_t *out_inlier_count,
                              uint8_t *out_inlier_mask);
-/* Test hook of the generator above: the models of B caller-chosen samples (sample_idx: 7 match indices
- * each, host memory) -> out_F: B x 3 x 9 doubles, NaN where a root does not exist or fails a check;
- * t as in fits_model.  Compared against the numpy restatement on identical samples. */
+/* Test hook of the generator above: the hypotheses of B caller-chosen samples (sample_idx: 7 match indices
+ * each, host memory) exactly as they go on to the all-matches fold - i.e. after calculate_model_perspective
+ * (:289-389) AND validate_f's finiteness test, optimize_perspective_f over the sample (LM + rank test on the
+ * re-parametrised matrix, :201-205, :391-426) and sample-fit test (:206-209) -> out_F: B x 3 x 9 doubles, NaN
+ * where a root does not exist or is rejected; t as in fits_model.  Compared with the oracle's numpy restatement
+ * (oracle/cvref_fm.py) on identical samples. */
 int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t *matches, uint32_t N, const uint32_t *sample_idx,
                                     uint32_t B, double t, double *out_F);
+/* Same for the affine generator (calculate_model_affine :260-286 + validate_f's checks): sample_idx holds 4
+ * match indices per sample -> out_F: B x 9 doubles, NaN where the sample is rejected. */
+int cvhip_ransac_affine_models(cvhip_device *dev, const uint32_t *matches, uint32_t N, const uint32_t *sample_idx,
+                               uint32_t B, double t, double *out_F);
+/* fits_model (fundamentalmatrix.rs:452-458) of one F for every match - the inlier filter of optimize_result
+ * (:233-236, 248-254).  out_mask: N bytes, 1 = inlier.  Host or device pointers. */
+int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t N, double t, uint8_t *out_mask);
+/* FundamentalMatrix::new(projection, max_dimension).find_ransac(matches) in one call (fundamentalmatrix.rs:72-147
+ * and optimize_result :231-257): cvhip_ransac_affine for projection 0 (max_dimension unused); for projection 1
+ * cvhip_ransac_perspective, then the LM refit of the winner on its inliers (cvhip_optimize_perspective_f, host
+ * arithmetic as in the reference) and the inliers of the refitted matrix.  This is what reconstruction.rs:502-526
+ * calls.  out_F: 9 doubles row-major; out_inlier_mask: N bytes (may be NULL). */
+int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32_t *matches, uint32_t N, double max_dimension,
+                      uint64_t seed, double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask);
 /* optimize_perspective_f (fundamentalmatrix.rs:391-426) as optimize_result applies it to the winning model
  * (:246): the reference's own Levenberg-Marquardt loop (least_squares, :515-621) with its analytic Jacobian
  * (f_jacobian, :473-512) over the 7 free parameters of F (:429-449), then the rank test (:418-423).  Host

@@ -23,6 +23,14 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle_fm():
+    """The numpy restatement of the model-fitting half of fundamentalmatrix.rs (oracle/ - test infrastructure only)."""
+    from oracle import cvref_fm
+
+    return cvref_fm
+
+
+@pytest.fixture(scope="session")
 def gpu_device():
     """A cvhip device on GPU 0; the HIP extension must be built and a GPU present."""
     from cybervision_amd import correlation
