@@ -1,0 +1,110 @@
+"""The hot-path calls of ImageReconstruction (src/reconstruction.rs) in the order the reference makes them,
+over the C ABI: match_keypoints (:400-500: per-level ORB on both images + KeypointMatching),
+find_fundamental_matrix (:502-526), correlate_dense (:528-603) and the pair loops of reconstruct /
+reconstruct_dense (:261-277, :680-730).  This is BASELINE config 5's workload ("3-image perspective SFM:
+ORB + RANSAC F-matrix on GPU + pairwise dense correlation").  Everything between the calls that the
+reference does on the CPU (image decode, Lanczos3 resize, triangulation, bundle adjustment) is outside
+the boundary; images arrive here as prebuilt pyramids (pyr[k] = the 1/2^k level, host arrays or device
+tensors).  No compute in Python - only the calls and their timing.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import correlation, fundamentalmatrix, orb, pointmatching
+from .fundamentalmatrix import ProjectionMode
+
+
+class ImageReconstruction:
+    def __init__(self, device, projection_mode: ProjectionMode = ProjectionMode.Perspective):
+        self.device = device
+        self.projection_mode = ProjectionMode(projection_mode)
+        self.timings_ms: dict[str, float] = {}
+
+    def _timed(self, key: str, fn):
+        self.device.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        self.device.synchronize()
+        self.timings_ms[key] = self.timings_ms.get(key, 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
+
+    # reconstruction.rs:418-458 for ONE image: levels coarse to fine, coordinates mapped back, lists concatenated
+    def extract_keypoints(self, pyramid):
+        dims = (int(pyramid[0].shape[1]), int(pyramid[0].shape[0]))
+        steps = orb.optimal_scale_steps(*dims)
+        return self._timed("orb", lambda: orb.extract_points_multiscale(self.device, pyramid[:steps + 1]))
+
+    # reconstruction.rs:400-500
+    def match_keypoints(self, keypoints1, keypoints2):
+        thr = (pointmatching.THRESHOLD_PERSPECTIVE if self.projection_mode == ProjectionMode.Perspective
+               else pointmatching.THRESHOLD_AFFINE)
+        m, _ = self._timed("match", lambda: pointmatching.match_points(self.device, keypoints1[0], keypoints1[1],
+                                                                       keypoints2[0], keypoints2[1], thr))
+        return m
+
+    # reconstruction.rs:502-526
+    def find_fundamental_matrix(self, img1_dimensions, img2_dimensions, point_matches, seed: int = 0):
+        max_dimension = float(max(img1_dimensions[0], img1_dimensions[1], img2_dimensions[0], img2_dimensions[1]))
+        fm = fundamentalmatrix.FundamentalMatrix(self.projection_mode, max_dimension)
+        return self._timed("ransac", lambda: fm.find_ransac(self.device, point_matches, seed=seed))
+
+    # reconstruction.rs:528-603 (up to complete(); triangulation is the next stage)
+    def correlate_dense(self, pyr1, pyr2, f, out_xy=None, out_corr=None):
+        def dims(img):
+            return (int(img.shape[1]), int(img.shape[0]))
+
+        steps = correlation.optimal_scale_steps(*dims(pyr1[0]))
+        mode = correlation.ProjectionMode(int(self.projection_mode))
+
+        def run():
+            pc = correlation.PointCorrelations(self.device, dims(pyr1[0]), dims(pyr2[0]), f, mode)
+            try:
+                for i in range(steps + 1):
+                    k = steps - i
+                    pc.correlate_images(pyr1[k], pyr2[k], 1.0 / float(1 << k))
+                return pc.complete(out_xy=out_xy, out_corr=out_corr)
+            finally:
+                pc.close()
+
+        return self._timed("dense", run)
+
+
+def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = ProjectionMode.Perspective, seed: int = 0,
+                      dense: bool = True):
+    """The two pair loops of `reconstruct` (reconstruction.rs:261-277 sparse, :680-730 dense) over n images:
+    for every i < j the sparse stage (ORB on both, matcher, RANSAC); then, for every pair that produced an F, the
+    dense correlation.  The reference re-extracts an image's keypoints for every pair it takes part in; the result
+    is a pure function of the image, so they are extracted once per image here.
+    -> dict: keypoints [n], pairs {(i, j): {matches, f, inliers, (xy, corr)}}, timings_ms per stage."""
+    rec = ImageReconstruction(device, projection_mode)
+    n = len(pyramids)
+    keypoints = [rec.extract_keypoints(p) for p in pyramids]
+    pairs = {}
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            di = (int(pyramids[i][0].shape[1]), int(pyramids[i][0].shape[0]))
+            dj = (int(pyramids[j][0].shape[1]), int(pyramids[j][0].shape[0]))
+            matches = rec.match_keypoints(keypoints[i], keypoints[j])
+            entry = {"matches": matches, "f": None, "inliers": None, "error": None}
+            try:
+                f, inliers, _ = rec.find_fundamental_matrix(di, dj, matches, seed=seed + 1000 * i + j)
+                entry["f"], entry["inliers"] = f, inliers
+            except Exception as exc:  # "Failed to match images" (reconstruction.rs:268-274): the pair is skipped
+                entry["error"] = str(exc)
+            pairs[(i, j)] = entry
+    if dense:
+        for (i, j), entry in pairs.items():
+            if entry["f"] is None:
+                continue
+            entry["xy"], entry["corr"] = rec.correlate_dense(pyramids[i], pyramids[j], entry["f"])
+    return {"keypoints": keypoints, "pairs": pairs, "timings_ms": dict(rec.timings_ms)}
+
+
+def match_count(xy) -> int:
+    """Number of Some cells of a dense grid (host array or device tensor)."""
+    if hasattr(xy, "data_ptr"):
+        return int((xy[..., 0] >= 0).sum().item())
+    return int((np.asarray(xy)[..., 0] >= 0).sum())

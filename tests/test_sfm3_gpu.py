@@ -1,0 +1,138 @@
+"""BASELINE config 5 end to end: three perspective views -> per-level ORB on each -> matcher (threshold 48) ->
+perspective RANSAC on the device (+ LM refit) -> three pairwise dense correlations with the perspective
+parameter set, all through the C ABI in the reference's call order (reconstruction.rs:261-277, 400-526,
+540-588, 680-730).  At 512^2 every stage is compared with the oracle on the same inputs; at 2048^2 (the
+configuration's size) with size-independent properties."""
+import numpy as np
+import pytest
+
+from cybervision_amd import fundamentalmatrix, orb, reconstruction, synth
+
+PAIRS = [(0, 1), (0, 2), (1, 2)]
+
+
+def build_views(size):
+    views, K, poses = synth.make_sfm_views(size)
+    steps = synth.optimal_scale_steps(size, size)
+    return views, [synth.box_pyramid(v, steps) for v in views], K, poses
+
+
+def oracle_keypoints(oracle, pyramid):
+    """match_keypoints' per-image loop (reconstruction.rs:418-458) on the oracle."""
+    h, w = pyramid[0].shape
+    steps = int(oracle.lib().cvref_orb_optimal_scale_steps(w, h))
+    xs, ds = [], []
+    for i in range(steps + 1):
+        k = steps - i
+        xy, desc = oracle.orb_extract(pyramid[k])
+        scale = np.float32(1.0 / (1 << k))
+        xs.append(np.floor(xy.astype(np.float32) / scale).astype(np.uint32))
+        ds.append(desc)
+    return np.concatenate(xs), np.concatenate(ds)
+
+
+def epipolar_distance(F, x1, y1, x2, y2):
+    """Distance of (x2, y2) from the epipolar line F (x1, y1, 1) in image 2, pixels."""
+    one = np.ones_like(x1, dtype=np.float64)
+    l = np.stack([x1, y1, one], axis=-1) @ np.asarray(F).T
+    return np.abs(l[..., 0] * x2 + l[..., 1] * y2 + l[..., 2]) / np.hypot(l[..., 0], l[..., 1])
+
+
+def test_sfm_scene_is_geometrically_consistent():
+    """The generator's three views obey the fundamental matrices it reports: matching canvas points project to
+    pixels with x_j' F_ij x_i = 0 (checked through the cameras, not the images)."""
+    size = 512
+    K, poses = synth.sfm_cameras(size)
+    rng = np.random.default_rng(3)
+    p0 = rng.uniform(40, size - 40, size=(200, 2))
+    Ki = np.linalg.inv(K)
+    X = (Ki @ np.stack([p0[:, 0], p0[:, 1], np.ones(200)])) * synth._sfm_depth(p0[:, 0], p0[:, 1], size)
+    px = []
+    for R, t in poses:
+        q = K @ (R @ X + t[:, None])
+        px.append(q[:2] / q[2])
+    for i, j in PAIRS:
+        F = synth.sfm_true_f(K, poses[i], poses[j])
+        assert epipolar_distance(F, px[i][0], px[i][1], px[j][0], px[j][1]).max() < 1e-6
+        sv = np.linalg.svd(F, compute_uv=False)
+        assert sv[1] >= 1e-3 and sv[2] <= 1e-9  # the reference's rank test accepts the planted geometry
+    views, _, _ = synth.make_sfm_views(128)
+    again, _, _ = synth.make_sfm_views(128)
+    assert all((a == b).all() for a, b in zip(views, again)) and views[0].std() > 10
+
+
+@pytest.mark.gpu
+def test_sfm3_every_stage_matches_oracle_512(gpu_device, oracle, oracle_fm):
+    size = 512
+    views, pyramids, K, poses = build_views(size)
+    res = reconstruction.reconstruct_pairs(gpu_device, pyramids, fundamentalmatrix.ProjectionMode.Perspective, seed=11)
+    # ORB: coordinates, order and descriptors of every level of every image
+    want_kp = [oracle_keypoints(oracle, p) for p in pyramids]
+    for (gxy, gdesc), (wxy, wdesc) in zip(res["keypoints"], want_kp):
+        assert len(wxy) > 2000 and gxy.shape == wxy.shape
+        assert (gxy == wxy).all() and (gdesc == wdesc).all()
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * size
+    for (i, j) in PAIRS:
+        e = res["pairs"][(i, j)]
+        assert e["error"] is None, e["error"]
+        # matcher: the same matches in the same (distance-sorted, stable) order
+        wm, _ = oracle.match_points(want_kp[i][0], want_kp[i][1], want_kp[j][0], want_kp[j][1], 48)
+        assert len(wm) > 1000 and e["matches"].shape == wm.shape and (e["matches"] == wm).all()
+        # RANSAC: the reference's RNG is OS-seeded, so the model is compared with the planted geometry; the inlier
+        # list is exactly fits_model of the returned F (oracle's arithmetic), F is in the refit's parametrisation
+        F = e["f"]
+        assert F[2, 2] == 1.0 and abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-9
+        cnt, _ = oracle.ransac_score(F, wm, t)
+        assert cnt[0] == len(e["inliers"]) and (e["inliers"] == wm[oracle_fm.fits_model(F, wm, t)]).all()
+        F_true = synth.sfm_true_f(K, poses[i], poses[j])
+        true_in = oracle_fm.fits_model(F_true, wm, t)
+        got_in = oracle_fm.fits_model(F, wm, t)
+        assert (got_in & true_in).sum() > 0.97 * true_in.sum()
+        # dense: bit-exact against the oracle run with the SAME recovered F and the perspective parameter set
+        wxy, wcorr, _ = oracle.correlate_dense(pyramids[i], pyramids[j], F, 1)
+        xy, corr = e["xy"], e["corr"]
+        valid = wxy[..., 0] >= 0
+        assert valid.mean() > 0.3, valid.mean()
+        assert (xy == wxy).all(), f"pair {(i, j)}: {int((xy != wxy).any(axis=-1).sum())} cells differ"
+        assert (corr.view(np.uint32)[valid] == wcorr.view(np.uint32)[valid]).all()
+        # and the surviving matches lie on the TRUE epipolar lines
+        ys, xs = np.nonzero(valid)
+        d = epipolar_distance(F_true, xs.astype(np.float64), ys.astype(np.float64), xy[..., 0][valid].astype(np.float64),
+                              xy[..., 1][valid].astype(np.float64))
+        assert np.percentile(d, 90) < 2.0, np.percentile(d, 90)
+    assert set(res["timings_ms"]) == {"orb", "match", "ransac", "dense"}
+
+
+@pytest.mark.gpu
+def test_sfm3_full_size_properties_2048(gpu_device, oracle_fm):
+    """The configuration's own size (3 x 2048^2: 4 ORB levels, 6 correlation levels): determinism of the dense
+    stage, border emptiness, score range, agreement with the planted geometry, cross-check consistency."""
+    import torch
+
+    size = 2048
+    views, pyramids, K, poses = build_views(size)
+    dev_pyr = [[torch.from_numpy(l).cuda() for l in p] for p in pyramids]
+    res = reconstruction.reconstruct_pairs(gpu_device, dev_pyr, fundamentalmatrix.ProjectionMode.Perspective, seed=5)
+    assert [len(k[0]) for k in res["keypoints"]] == [len(k[0]) for k in res["keypoints"]]
+    assert all(10000 < len(k[0]) <= 40000 for k in res["keypoints"])  # <= 10 000 per level, 4 levels
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * size
+    rec = reconstruction.ImageReconstruction(gpu_device)
+    for (i, j) in PAIRS:
+        e = res["pairs"][(i, j)]
+        assert e["error"] is None, e["error"]
+        F, F_true = e["f"], synth.sfm_true_f(K, poses[i], poses[j])
+        m = e["matches"]
+        true_in = oracle_fm.fits_model(F_true, m, t)
+        assert true_in.sum() > 5000 and (oracle_fm.fits_model(F, m, t) & true_in).sum() > 0.97 * true_in.sum()
+        xy, corr = e["xy"], e["corr"]
+        xy2, corr2 = rec.correlate_dense(dev_pyr[i], dev_pyr[j], F)
+        assert (xy == xy2).all() and (corr.view(np.uint32) == corr2.view(np.uint32)).all(), "dense stage not deterministic"
+        valid = xy[..., 0] >= 0
+        assert valid.mean() > 0.3, valid.mean()
+        assert not valid[:5].any() and not valid[-5:].any() and not valid[:, :5].any() and not valid[:, -5:].any()
+        assert (corr[valid] >= np.float32(0.5)).all() and (corr[valid] <= np.float32(1.0001)).all()
+        ys, xs = np.nonzero(valid)
+        d = epipolar_distance(F_true, xs.astype(np.float64), ys.astype(np.float64), xy[..., 0][valid].astype(np.float64),
+                              xy[..., 1][valid].astype(np.float64))
+        assert np.percentile(d, 90) < 3.0, np.percentile(d, 90)
+    assert res["timings_ms"]["dense"] > 0
