@@ -44,6 +44,7 @@ SIGNATURES = {
     "cvhip_complete": (C.c_int, [_vp, _vp, _vp]),
     "cvhip_complete_dir": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "cvhip_triangulate_affine": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cvhip_extend_tracks": (C.c_int, [_vp, _vp, C.c_uint64, _u32, _vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cvhip_ctx_set_row_shard": (C.c_int, [_vp, _u32, _u32, ALLGATHER_FN, _vp]),
     "cvhip_ctx_set_row_band": (C.c_int, [_vp, _u32, _u32]),
     "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "cvhip_ctx_set_search_version": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_borrow_inputs": (C.c_int, [_vp, C.c_int]),
     "cvhip_downsample_box": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
+    "cvhip_resize_lanczos3": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),
     "cvhip_orb_extract": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cvhip_match_points": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cvhip_ransac_affine": (C.c_int, [_vp, _vp, _u32, C.c_uint64, _vp, C.POINTER(_u32), _vp]),

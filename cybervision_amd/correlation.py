@@ -165,6 +165,25 @@ class PointCorrelations:
                                                            n.value, C.byref(n)), "cvhip_triangulate_affine")
         return pts[:n.value].copy(), p2[:n.value].copy()
 
+    def extend_tracks(self, track_p1, max_dimension2: int):
+        """Triangulation::extend_tracks (triangulation.rs:1330-1419) straight from the device grid.  track_p1: [n, 2]
+        int32, (-1, -1) = the track has no point in image 1.  -> (track_p2 [n, 2] int32 with (-1, -1) = nothing to add,
+        new_p1 [m, 2] uint32, new_p2 [m, 2] uint32): the image-2 points for the existing tracks and the new tracks."""
+        tp1 = np.ascontiguousarray(np.asarray(track_p1, dtype=np.int32).reshape(-1, 2))
+        n = len(tp1)
+        tp2 = np.full((max(n, 1), 2), -1, dtype=np.int32)
+        m = C.c_uint64(0)
+        p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        _lib.check(_lib.lib().cvhip_extend_tracks(self._h, p(tp1) if n else None, n, int(max_dimension2), p(tp2) if n else None,
+                                                  None, None, 0, C.byref(m)), "cvhip_extend_tracks")
+        n1 = np.zeros((max(m.value, 1), 2), dtype=np.uint32)
+        n2 = np.zeros((max(m.value, 1), 2), dtype=np.uint32)
+        if m.value:
+            _lib.check(_lib.lib().cvhip_extend_tracks(self._h, p(tp1) if n else None, n, int(max_dimension2),
+                                                      p(tp2) if n else None, p(n1), p(n2), m.value, C.byref(m)),
+                       "cvhip_extend_tracks")
+        return tp2[:n].copy(), n1[:m.value].copy(), n2[:m.value].copy()
+
     # -- measurement / sharding hooks -----------------------------------------------------------
     def set_profiling(self, time_kernels, count_candidates: bool):
         """time_kernels: 0/False off, 1/True every kernel class, 2 the search class only (include/cvhip.h)."""
@@ -278,3 +297,29 @@ def box_pyramid_device(device: GpuDevice, img, steps: int):
                                                    C.c_void_p(dst.data_ptr())), "cvhip_downsample_box")
         out.append(dst)
     return out
+
+
+def resize_lanczos3(device: GpuDevice, img, scale: float):
+    """SourceImage::resize (reconstruction.rs:146-162): the level image at `scale` with the `image` crate's Lanczos3
+    (cvhip_resize_lanczos3; tolerance parity, see include/cvhip.h).  img: numpy uint8 array or torch CUDA uint8 tensor;
+    the result lives where the input does."""
+    p, w, h, keep = _ptr_shape(img)
+    s = np.float32(scale)
+    nw, nh = int(np.float32(w) * s), int(np.float32(h) * s)   # (w as f32 * scale) as u32
+    if hasattr(img, "data_ptr"):
+        import torch
+
+        out = torch.empty((nh, nw), dtype=torch.uint8, device=img.device)
+        po = C.c_void_p(out.data_ptr())
+    else:
+        out = np.empty((nh, nw), dtype=np.uint8)
+        po = C.c_void_p(out.ctypes.data)
+    _lib.check(_lib.lib().cvhip_resize_lanczos3(device.handle, p, w, h, po, nw, nh), "cvhip_resize_lanczos3")
+    del keep
+    return out
+
+
+def lanczos_pyramid(device: GpuDevice, img, steps: int):
+    """[level 0, ..., level `steps`]: every level resized from the FULL-RESOLUTION image, as the reference's level
+    loops do (reconstruction.rs:421-422, 567-568), scale = 1 / (1 << k)."""
+    return [resize_lanczos3(device, img, 1.0 / float(1 << k)) for k in range(steps + 1)]

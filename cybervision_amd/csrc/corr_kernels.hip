@@ -2276,20 +2276,6 @@ void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k
 // scan of the block counts, then an ordered write of (x, y, sqrt(dx^2 + dy^2)) per track.
 // dx^2 + dy^2 is an exact integer in f64; sqrt is the correctly rounded f64 square root.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool full_res_match(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh, uint32_t k,
-                                               uint32_t gx, uint32_t gy, uint32_t &mx, uint32_t &my)
-{
-    const uint32_t mask = (1u << k) - 1u;
-    if ((gx & mask) || (gy & mask)) return false;
-    const uint32_t lx = gx >> k, ly = gy >> k;
-    if (lx >= lw || ly >= lh) return false;
-    const uint32_t c = cells[(size_t)ly * lw + lx].x;
-    if (c == CELL_NONE) return false;
-    mx = (c & 0xFFFFu) << k;
-    my = (c >> 16) << k;
-    return true;
-}
-
 __global__ __launch_bounds__(256) void tri_count_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
                                                          uint32_t k, uint32_t gw, uint32_t gh,
                                                          uint32_t *__restrict__ block_counts)
@@ -2376,6 +2362,11 @@ void launch_triangulate_affine(const uint2 *cells, uint32_t lw, uint32_t lh, uin
     if (cap)
         hipLaunchKernelGGL(tri_write_kernel, dim3(nblocks), dim3(256), 0, s, cells, lw, lh, k, gw, gh, block_counts, cap,
                            out_points3d, out_p2);
+}
+
+void launch_scan_u32(uint32_t *data, uint32_t n, uint32_t *total, hipStream_t s)
+{
+    hipLaunchKernelGGL(tri_scan_kernel, dim3(1), dim3(1024), 0, s, data, n, total);
 }
 
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, size_t n)

@@ -108,6 +108,34 @@ void launch_triangulate_affine(const uint2 *cells, uint32_t lw, uint32_t lh, uin
                                uint32_t *block_counts, uint32_t *total, double *out_points3d, uint32_t *out_p2,
                                unsigned long long cap, hipStream_t s);
 
+// single-block exclusive scan of n u32 in place, total to *total
+void launch_scan_u32(uint32_t *data, uint32_t n, uint32_t *total, hipStream_t s);
+// Triangulation::extend_tracks on the forward grid (track_kernels.hip)
+void launch_extend_tracks_match(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+                                const int2 *track_p1, unsigned long long n_tracks, uint32_t radius, int2 *out_p2,
+                                uint8_t *removed, uint32_t *oob, hipStream_t s);
+void launch_extend_tracks_new(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+                              const uint8_t *removed, uint32_t *block_counts, uint32_t *total, uint32_t *out_new_p1,
+                              uint32_t *out_new_p2, unsigned long long cap, hipStream_t s);
+
+#ifdef __HIPCC__
+// the match stored for full-resolution cell (gx, gy), if any: level cell (gx >> k, gy >> k) when both are multiples
+// of 2^k (the scatter of mod.rs:311-316), scaled back by 2^k (mod.rs:459-462)
+__device__ __forceinline__ bool full_res_match(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh, uint32_t k,
+                                               uint32_t gx, uint32_t gy, uint32_t &mx, uint32_t &my)
+{
+    const uint32_t mask = (1u << k) - 1u;
+    if ((gx & mask) || (gy & mask)) return false;
+    const uint32_t lx = gx >> k, ly = gy >> k;
+    if (lx >= lw || ly >= lh) return false;
+    const uint32_t c = cells[(size_t)ly * lw + lx].x;
+    if (c == CELL_NONE) return false;
+    mx = (c & 0xFFFFu) << k;
+    my = (c >> 16) << k;
+    return true;
+}
+#endif
+
 // ---- handles --------------------------------------------------------------------------------
 struct Device {
     int ordinal = 0;

@@ -129,6 +129,22 @@ typedef int (*cvhip_allgather_fn)(void *user, void *cells, uint64_t shard_bytes,
  * the number of Some cells (call with cap = 0 to size the buffers).  Host or device pointers. */
 int cvhip_triangulate_affine(cvhip_ctx *ctx, double *out_points3d, uint32_t *out_p2, uint64_t cap, uint64_t *out_n);
 
+/* Dense consumer, perspective pipeline — replaces Triangulation::extend_tracks (triangulation.rs:1330-1419; called
+ * right after a pair's dense correlation, :638, :697) on the device-resident forward grid.
+ *  - track_p1: the existing tracks' points in image 1, 2 int32 per track, (-1,-1) where a track has none.
+ *  - out_track_p2[i]: the image-2 point `track.add(image2_index, ..)` is called with for track i - the match of the
+ *    nearest Some cell within [p - r, p + r) (squared distance, first minimum in row-major order), r =
+ *    3 * max_dimension2 / 1000 (3 when max_dimension2 <= 1000; max_dimension2 = max(width, height) of image 2) - or
+ *    (-1,-1).  The caller applies Track::add's "only if the track has no point for this image yet" (:370-375).
+ *  - The merged points are then cleared from the remaining grid AT THEIR OWN coordinates (the reference indexes the
+ *    image-1 grid with the image-2 point, :1391-1393; out of bounds it panics - here CVHIP_ERR_INVALID), and every
+ *    remaining Some cell becomes a new track: out_new_p1 = the cell, out_new_p2 = its match, scan order, at most
+ *    `cap` written; *out_n_new = their number (call with cap = 0 to size the buffers).
+ * Integer only, bit-exact.  Host or device pointers.  Uses the context's per-pass scratch: call it between pairs. */
+int cvhip_extend_tracks(cvhip_ctx *ctx, const int32_t *track_p1, uint64_t n_tracks, uint32_t max_dimension2,
+                        int32_t *out_track_p2, uint32_t *out_new_p1, uint32_t *out_new_p2, uint64_t cap,
+                        uint64_t *out_n_new);
+
 /* Row sharding (multi-GPU): restrict the SEARCH passes of this context to shard `num` of `den`
  * equal row chunks of the searched level image: rows [num*rps, min((num+1)*rps, h_level)) with
  * rps = ceil(h_level / den).  Rows outside the band keep whatever the level grid holds until
@@ -205,6 +221,15 @@ int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
  * resident in HBM for both the ORB and the dense stage.  Host or device pointers.
  * ---------------------------------------------------------------------------------------- */
 int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint32_t w, uint32_t h, uint8_t *dst);
+
+/* SourceImage::resize (reconstruction.rs:146-162) on the device: image::imageops::resize(.., FilterType::Lanczos3) of a
+ * Luma8 image to nw x nh (the caller passes (w as f32 * scale) as u32, (h as f32 * scale) as u32, :149-150).  The
+ * `image` crate (0.25.10) is not vendored with the reference; this is its published separable algorithm (vertical pass
+ * to f32, horizontal pass, f32 weights normalised per output sample, clamp + round to nearest at the end; equal
+ * dimensions are a copy) - TOLERANCE parity: the tests allow one grey level on < 0.1 % of the pixels against an
+ * independent restatement, and nothing pins either to the crate.  Host or device pointers. */
+int cvhip_resize_lanczos3(cvhip_device *dev, const uint8_t *src, uint32_t w, uint32_t h, uint8_t *dst, uint32_t nw,
+                          uint32_t nh);
 
 /* ------------------------------------------------------------------------------------------
  * ORB — replaces orb::extract_points (orb.rs:50-84).

@@ -71,6 +71,8 @@ def lib():
                                          _u32p]
         L.cvref_triangulate_affine.restype = C.c_uint64
         L.cvref_triangulate_affine.argtypes = [_i32p, C.c_uint32, C.c_uint32, _f64p, _u32p]
+        L.cvref_extend_tracks.restype = C.c_uint64
+        L.cvref_extend_tracks.argtypes = [_i32p, C.c_uint32, C.c_uint32, _i32p, C.c_uint64, C.c_uint32, _i32p, _u32p, _u32p]
         L.cvref_reprojection_error.restype = C.c_double
         L.cvref_reprojection_error.argtypes = [_f64p, _u32p]
         L.cvref_ransac_score.argtypes = [_f64p, C.c_uint32, _u32p, C.c_uint32, C.c_double, _u32p, _f64p]
@@ -253,3 +255,20 @@ def triangulate_affine(xy):
     n = lib().cvref_triangulate_affine(xy, w, h, pts, p2)
     assert n == cap
     return pts[:n].copy(), p2[:n].copy()
+
+
+def extend_tracks(xy, track_p1, max_dimension2: int):
+    """Triangulation::extend_tracks (triangulation.rs:1330-1419) -> (track_p2[n_tracks, 2] int32 with -1 = nothing to
+    add, new_p1[n, 2] uint32, new_p2[n, 2] uint32)."""
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    h, w = xy.shape[:2]
+    track_p1 = np.ascontiguousarray(np.asarray(track_p1, dtype=np.int32).reshape(-1, 2))
+    cap = max(int((xy[..., 0] >= 0).sum()), 1)
+    tp2 = np.full((max(len(track_p1), 1), 2), -1, dtype=np.int32)
+    n1 = np.zeros((cap, 2), dtype=np.uint32)
+    n2 = np.zeros((cap, 2), dtype=np.uint32)
+    n = lib().cvref_extend_tracks(xy, w, h, track_p1 if len(track_p1) else np.zeros((1, 2), dtype=np.int32), len(track_p1),
+                                  max_dimension2, tp2, n1, n2)
+    if n == 2 ** 64 - 1:
+        raise IndexError("Index out of bounds")
+    return tp2[:len(track_p1)].copy(), n1[:n].copy(), n2[:n].copy()

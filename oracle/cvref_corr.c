@@ -676,3 +676,68 @@ uint64_t cvref_triangulate_affine(const int32_t *xy, uint32_t w, uint32_t h, dou
     }
     return n;
 }
+
+/* Triangulation::extend_tracks, triangulation.rs:1330-1419.
+ * track_p1: the existing tracks' points in image 1 (2 int32 each, (-1,-1) = the track has none: `track.get(image1_index)?`).
+ * out_track_p2[i]: the point `track.add(image2_index, ..)` is called with for track i, or (-1,-1) where the closure
+ * returns None.  Then every merged point clears remaining_points at ITS OWN (image 2) coordinates (:1391-1393, the
+ * reference indexes the image-1-sized grid with them; out of bounds panics there: return UINT64_MAX), and every
+ * remaining Some cell becomes a new track (p1 = the cell, p2 = its match), in scan order (:1397-1416).
+ * Returns the number of new tracks. */
+uint64_t cvref_extend_tracks(const int32_t *xy, uint32_t w, uint32_t h, const int32_t *track_p1, uint64_t n_tracks,
+                             uint32_t max_dimension2, int32_t *out_track_p2, uint32_t *out_new_p1, uint32_t *out_new_p2)
+{
+    /* :1346-1350, EXTEND_TRACKS_SEARCH_RADIUS = 3, TRACKS_RADIUS_DENOMINATOR = 1000 (:16, :19) */
+    const size_t search_radius = max_dimension2 > 1000 ? (size_t)3 * max_dimension2 / 1000 : 3;
+    uint8_t *removed = (uint8_t *)calloc((size_t)w * h, 1);
+    if (!removed) return UINT64_MAX;
+    for (uint64_t t = 0; t < n_tracks; t++) {
+        out_track_p2[2 * t] = out_track_p2[2 * t + 1] = -1;
+        if (track_p1[2 * t] < 0) continue;
+        const size_t px = (size_t)track_p1[2 * t], py = (size_t)track_p1[2 * t + 1];
+        const size_t min_x = px > search_radius ? px - search_radius : 0, min_y = py > search_radius ? py - search_radius : 0;
+        const size_t max_x = px + search_radius < w ? px + search_radius : w, max_y = py + search_radius < h ? py + search_radius : h;
+        int have = 0;
+        size_t min_distance = 0;
+        int32_t bx = -1, by = -1;
+        for (size_t y = min_y; y < max_y; y++) {
+            for (size_t x = min_x; x < max_x; x++) {
+                const int32_t *m = &xy[2 * ((size_t)w * y + x)];
+                if (m[0] < 0) continue;
+                const size_t dx = (x > px ? x : px) - (x < px ? x : px), dy = (y > py ? y : py) - (y < py ? y : py);
+                const size_t distance = dx * dx + dy * dy;
+                if (!have || distance < min_distance) {
+                    have = 1;
+                    min_distance = distance;
+                    bx = m[0];
+                    by = m[1];
+                }
+            }
+        }
+        if (!have) continue;
+        out_track_p2[2 * t] = bx;
+        out_track_p2[2 * t + 1] = by;
+    }
+    for (uint64_t t = 0; t < n_tracks; t++) {
+        if (out_track_p2[2 * t] < 0) continue;
+        const size_t x = (size_t)out_track_p2[2 * t], y = (size_t)out_track_p2[2 * t + 1];
+        if (x >= w || y >= h) { /* Grid::val_mut asserts (data.rs:61-64) */
+            free(removed);
+            return UINT64_MAX;
+        }
+        removed[(size_t)w * y + x] = 1;
+    }
+    uint64_t n = 0;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const size_t i = (size_t)w * y + x;
+            if (xy[2 * i] < 0 || removed[i]) continue;
+            out_new_p1[2 * n] = x;
+            out_new_p1[2 * n + 1] = y;
+            out_new_p2[2 * n] = (uint32_t)xy[2 * i];
+            out_new_p2[2 * n + 1] = (uint32_t)xy[2 * i + 1];
+            n++;
+        }
+    free(removed);
+    return n;
+}

@@ -547,6 +547,48 @@ def test_triangulate_affine_matches_oracle(gpu_device, oracle, name):
         assert len(pts) > 1000 and (pts[:, 2] >= 0).all()
 
 
+def _tracks_for(xy, seed, n=4000):
+    """Existing tracks for extend_tracks: points near dense matches, far from any, duplicates, image corners, and
+    tracks without a point in image 1."""
+    h, w = xy.shape[:2]
+    rng = np.random.default_rng(seed)
+    p = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], axis=1).astype(np.int32)
+    p[::17] = -1                                   # track.get(image1_index) is None
+    p[5:40] = p[4]                                 # several tracks at one point: all take the same match
+    p[40:44] = [[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1]]
+    return p
+
+
+@pytest.mark.parametrize("name,max_dim2", [("persp_240x180", 240), ("tilt3_200x150", 2300), ("h256", 4096), ("flat", 128)])
+def test_extend_tracks_matches_oracle(gpu_device, oracle, name, max_dim2):
+    """Triangulation::extend_tracks (triangulation.rs:1330-1419) straight from the device grid: the same image-2 point
+    for every existing track (nearest match, first minimum), the same new tracks in the same order as the oracle
+    applied to the completed grid - for the reference's three radius regimes (3, 6, 12 px)."""
+    c = cases.make_case(name)
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"], correlation.ProjectionMode(c["projection"]))
+    try:
+        for i in range(c["steps"] + 1):
+            k = c["steps"] - i
+            pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+        xy, _ = pc.complete()
+        tracks = _tracks_for(xy, seed=len(name))
+        tp2, n1, n2 = pc.extend_tracks(tracks, max_dim2)
+        e_tp2, e_n1, e_n2 = pc.extend_tracks(np.zeros((0, 2), dtype=np.int32), max_dim2)  # no tracks yet: the first pair
+    finally:
+        pc.close()
+    w_tp2, w_n1, w_n2 = oracle.extend_tracks(xy, tracks, max_dim2)
+    assert (tp2 == w_tp2).all()
+    assert n1.shape == w_n1.shape and (n1 == w_n1).all() and (n2 == w_n2).all()
+    valid = xy[..., 0] >= 0
+    assert len(e_tp2) == 0 and len(e_n1) == valid.sum() and (e_n2 == xy[valid]).all()
+    if name != "flat":
+        assert (tp2[:, 0] >= 0).sum() > 1000 and len(n1) < valid.sum()
+        assert (tp2[tracks[:, 0] < 0] == -1).all()
+
+
 def test_device_box_pyramid_equals_host(gpu_device):
     """cvhip_downsample_box reproduces synth.box_pyramid byte for byte (odd sizes included)."""
     import torch

@@ -138,3 +138,35 @@ def test_triangulate_affine_known_answers(oracle):
     pts, p2 = oracle.triangulate_affine(xy)
     assert pts.tolist() == [[4.0, 0.0, 2.0 ** 0.5], [2.0, 1.0, 5.0], [0.0, 3.0, 0.0]]
     assert p2.tolist() == [[3, 1], [5, 5], [0, 3]]
+
+
+def test_extend_tracks_known_answers(oracle):
+    """Triangulation::extend_tracks (triangulation.rs:1330-1419) on a hand-made grid: window [p - r, p + r) with r = 3,
+    first minimum in row-major order, Track-less points skipped, merged points cleared at the MATCH's coordinates (the
+    reference's indexing, :1391-1393), remaining cells become new tracks in scan order."""
+    w, h = 20, 12
+    xy = np.full((h, w, 2), -1, dtype=np.int32)
+    xy[5, 5] = (7, 6)       # A
+    xy[5, 9] = (11, 5)      # B
+    xy[2, 12] = (14, 2)     # C
+    xy[9, 3] = (5, 5)       # D: its match's coordinates are A's cell
+    tracks = np.array([[7, 5],     # equidistant to A (5,5) and B (9,5): d = 4 both -> A comes first in scan order
+                       [8, 5],     # d(A) = 9, d(B) = 1 -> B; (8+3 = 11 is exclusive, 9 is inside)
+                       [15, 2],    # C at dx = 3: x in [12, 18) -> inside
+                       [9, 2],     # C at x = 12 = 9 + 3: exclusive upper bound -> outside; nothing else within y [0, 5)
+                       [-1, -1],   # no point in image 1
+                       [19, 11]], dtype=np.int32)
+    tp2, n1, n2 = oracle.extend_tracks(xy, tracks, 1000)
+    assert tp2.tolist() == [[7, 6], [11, 5], [14, 2], [-1, -1], [-1, -1], [-1, -1]]
+    # cleared cells: (7,6) [none there], (11,5) [none], (14,2) [none] -> all four cells remain, scan order
+    assert n1.tolist() == [[12, 2], [5, 5], [9, 5], [3, 9]] and n2.tolist() == [[14, 2], [7, 6], [11, 5], [5, 5]]
+    tp2, n1, n2 = oracle.extend_tracks(xy, np.array([[3, 10]], dtype=np.int32), 1000)  # nearest is D (d = 1) -> (5, 5)
+    assert tp2.tolist() == [[5, 5]]
+    assert n1.tolist() == [[12, 2], [9, 5], [3, 9]]          # A's cell (5, 5) was cleared, D itself stays
+    # radius scales with the other image's size: 3 * 2500 / 1000 = 7
+    tp2, _, _ = oracle.extend_tracks(xy, np.array([[19, 2]], dtype=np.int32), 2500)
+    assert tp2.tolist() == [[14, 2]]
+    with pytest.raises(IndexError):
+        big = xy.copy()
+        big[5, 5] = (40, 6)
+        oracle.extend_tracks(big, np.array([[5, 5]], dtype=np.int32), 1000)
