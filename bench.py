@@ -179,6 +179,7 @@ def main():
     band_mode = False
     final_gather = None
     sim = None
+    collective = None
     if args.simulate_shard:  # single-GPU emulation of ONE rank's share of an N-GPU run (no collectives)
         num, den = (int(v) for v in args.simulate_shard.split("/"))
         sim = (num, den)
@@ -186,12 +187,38 @@ def main():
             raise SystemExit("--simulate-shard needs row-local geometry")
         band_mode = True
     elif world > 1:
-        gather = sharding.make_allgather(rank, world)
+        # Collectives: the library's own RCCL path (cvhip_rccl_*: a communicator per device handle, every collective on
+        # the handle's stream, no torch in the data path); torch.distributed only carries the 128-byte id.  If that
+        # cannot be set up (or in the one-GPU gloo rehearsal, where RCCL refuses several ranks per GPU) the
+        # torch.distributed hook is used instead - the line says which.
+        comm = None
+        if not rehearsal:
+            try:
+                uid = [sharding.RcclCommunicator.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = sharding.RcclCommunicator(dev, uid[0], rank, world)
+                collective = "library RCCL (cvhip_rccl_*), gather to rank 0"
+            except Exception as exc:  # noqa: BLE001 - reported, then the hook path takes over
+                print(f"[bench] rank {rank}: library RCCL path unavailable ({exc}); using the torch.distributed hook", flush=True)
+                comm = None
+        ok = torch.tensor([1 if comm is not None else 0], device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks take the same path
+        if int(ok[0]) == 0 and comm is not None:
+            comm.close()
+            comm = None
         band_mode = pc.set_row_band(rank, world)   # independent bands + halo, one final gather ...
-        if band_mode:
-            final_gather = gather
+        if comm is not None:
+            if band_mode:
+                final_gather = lambda cells, nbytes, n, d: pc.gather_bands_rccl(comm, 0)  # noqa: E731
+            else:
+                pc.set_row_shard_rccl(comm)        # ... or, for non-row-local geometry, an all-gather per sharded pass
         else:
-            pc.set_row_shard(rank, world, gather)  # ... or, for non-row-local geometry, an all-gather per sharded pass
+            collective = "torch.distributed all_gather hook"
+            gather = sharding.make_allgather(rank, world)
+            if band_mode:
+                final_gather = gather
+            else:
+                pc.set_row_shard(rank, world, gather)
     out_xy = torch.empty((H, W, 2), dtype=torch.int32, device="cuda")
     out_corr = torch.empty((H, W), dtype=torch.float32, device="cuda")
 
@@ -250,8 +277,10 @@ def main():
     ktimes = pc.get_kernel_times()
     pc.set_profiling(0, False)
 
-    if rehearsal and world > 1:
-        # the sharded result of the last step against an unsharded run of the same pair in this process
+    sharded_ok = None
+    if world > 1:
+        # the sharded result of the last step against an unsharded run of the same pair in this process (the rank that
+        # holds the gathered grid: rank 0 with the library's gather-to-root, every rank with an all-gather)
         pc1 = correlation.PointCorrelations(dev, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
         pc1.set_borrow_inputs(True)
         for i in range(steps + 1):
@@ -262,9 +291,15 @@ def main():
         fence()
         same = bool(torch.equal(out_xy, ref_xy)) and bool(torch.equal(out_corr.view(torch.int32), ref_corr.view(torch.int32)))
         pc1.close()
-        print(f"[rehearsal] rank {rank}/{world}: sharded result {'==' if same else '!='} unsharded result", flush=True)
-        if not same:
+        holds_result = rank == 0 or collective is None or "hook" in collective or not band_mode
+        if rehearsal:
+            print(f"[rehearsal] rank {rank}/{world}: sharded result {'==' if same else '!='} unsharded result", flush=True)
+        if holds_result and not same:
             raise SystemExit(f"rank {rank}: sharded result differs from the unsharded one")
+        sharded_ok = same
+        seen = torch.tensor([1], device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ranks_seen = int(seen[0])
 
     t = torch.tensor([dt, float(cand_local), search_ms_local], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if world > 1:
@@ -361,6 +396,10 @@ def main():
                 "sample": (f"top-left {S}x{S} crop of the same pair" if S < W else f"the whole {S}x{S} pair")
                           + f", full {csteps + 1}-level pyramid, C restatement of --mode=cpu (oracle/), {tc:.2f} s",
             }
+        if world > 1:
+            result["collective"] = collective
+            result["ranks_seen"] = ranks_seen
+            result["sharded_equals_unsharded"] = sharded_ok
         if rehearsal:
             result["rehearsal"] = f"{backend}: all {world} ranks on one GPU, gather staged through the host - not a measurement"
         print(json.dumps(result), flush=True)

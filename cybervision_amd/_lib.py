@@ -47,6 +47,13 @@ SIGNATURES = {
     "cvhip_extend_tracks": (C.c_int, [_vp, _vp, C.c_uint64, _u32, _vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cvhip_ctx_set_row_shard": (C.c_int, [_vp, _u32, _u32, ALLGATHER_FN, _vp]),
     "cvhip_ctx_set_row_band": (C.c_int, [_vp, _u32, _u32]),
+    "cvhip_rccl_unique_id": (C.c_int, [_vp]),
+    "cvhip_rccl_create": (C.c_int, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
+    "cvhip_rccl_destroy": (None, [_vp]),
+    "cvhip_rccl_allgather": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "cvhip_rccl_gather": (C.c_int, [_vp, _vp, C.c_uint64, _u32]),
+    "cvhip_ctx_set_row_shard_rccl": (C.c_int, [_vp, _vp]),
+    "cvhip_ctx_gather_bands_rccl": (C.c_int, [_vp, _vp, C.c_int]),
     "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32),
                                        C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "cvhip_ctx_set_profiling": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -54,6 +61,7 @@ SIGNATURES = {
                                         C.c_int]),
     "cvhip_ctx_get_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32), C.c_int]),
     "cvhip_ctx_get_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int]),
+    "cvhip_ctx_set_range_mode": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_search_version": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_borrow_inputs": (C.c_int, [_vp, C.c_int]),
     "cvhip_downsample_box": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),

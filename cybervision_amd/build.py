@@ -15,12 +15,13 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libcvhip.so"
-SOURCES = ["cvhip_api.hip", "corr_kernels.hip", "orb_kernels.hip", "ransac_kernels.hip", "track_kernels.hip", "resize_kernels.hip"]
+SOURCES = ["cvhip_api.hip", "corr_kernels.hip", "orb_kernels.hip", "ransac_kernels.hip", "track_kernels.hip", "resize_kernels.hip", "cvhip_rccl.hip"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
 ]
+LINK = ["-ldl"]  # cvhip_rccl.hip opens librccl.so.1 lazily (dlopen): no link-time dependency on RCCL
 
 
 def hipcc() -> str:
@@ -41,7 +42,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
+    cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES], *LINK]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -218,9 +218,25 @@ class PointCorrelations:
     def set_search_version(self, version: int):
         _lib.check(_lib.lib().cvhip_ctx_set_search_version(self._h, version), "cvhip_ctx_set_search_version")
 
+    def set_range_mode(self, mode: int):
+        """Test hook of the search-range kernel (include/cvhip.h): 0 default, 1 chain only, 2 / 3 mixed paths."""
+        _lib.check(_lib.lib().cvhip_ctx_set_range_mode(self._h, mode), "cvhip_ctx_set_range_mode")
+
+    def set_row_shard_rccl(self, comm):
+        """Bands + one RCCL all-gather per sharded search pass, issued by the library itself on the device handle's
+        stream (cvhip_ctx_set_row_shard_rccl); comm is a sharding.RcclCommunicator."""
+        _lib.check(_lib.lib().cvhip_ctx_set_row_shard_rccl(self._h, comm.handle), "cvhip_ctx_set_row_shard_rccl")
+
+    def gather_bands_rccl(self, comm, root: int = 0):
+        """Independent-band mode's single gather (cvhip_ctx_gather_bands_rccl): forward bands -> root (-1: every rank)."""
+        _lib.check(_lib.lib().cvhip_ctx_gather_bands_rccl(self._h, comm.handle, root), "cvhip_ctx_gather_bands_rccl")
+
     def set_row_shard(self, num: int, den: int, gather=None):
         """gather(cells_ptr: int, shard_bytes: int, n_shards: int, direction: int) -> None does the
-        in-place all-gather of the level grid (see cybervision_amd.sharding)."""
+        in-place all-gather of the level grid (see cybervision_amd.sharding).  Stream ordering (include/cvhip.h): with a
+        device created on the caller's stream the hook must enqueue its collective on that stream; with a device that
+        owns a private stream the library fences both sides of the hook itself (slower).  set_row_shard_rccl avoids
+        the question: the library issues the collective on its own stream."""
         if gather is None:
             cb = _lib.NULL_ALLGATHER
         else:

@@ -211,10 +211,12 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
             }
         }
     }
-    {
+#ifdef CVHIP_ABLATIONS
+    { // profiling ablations ("results are then wrong on purpose"): compiled only into -DCVHIP_ABLATIONS builds
         static const int dbg = [] { const char *v = std::getenv("CVHIP_DEBUG"); return v ? std::atoi(v) : 0; }();
         p.debug = k == 0 ? dbg : 0; // only the full-resolution level, so coarser levels still seed it
     }
+#endif
     if (c->band_mode) {
         const uint32_t *r = dir == 0 ? c->band[k].sf : c->band[k].sr;
         p.row0 = std::min(r[0], lh1);
@@ -446,9 +448,13 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     c->dir[0].gh = h1;
     c->dir[1].gw = w2;
     c->dir[1].gh = h2;
+#ifdef CVHIP_ABLATIONS
+    // environment overrides for profiling runs; the shipped library ignores the environment (kernel selection and
+    // the range-kernel test modes are set through cvhip_ctx_set_search_version / cvhip_ctx_set_range_mode)
     if (const char *v = std::getenv("CVHIP_SEARCH")) c->search_version = (v[0] >= '1' && v[0] <= '3') ? v[0] - '0' : 3;
     if (const char *v = std::getenv("CVHIP_FORCE_BOX")) c->force_box = v[0] == '1';
     if (const char *v = std::getenv("CVHIP_RANGE")) c->range_mode = (v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 0;
+#endif
     const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
     c->max_px = std::max(n1, n2);
     // Level grids are gathered in equal row chunks when sharded, so leave room for one padded
@@ -501,6 +507,12 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
     int k = 0;
     CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
+    if (ctx->band_mode) {
+        // the plan is laid out over the forward direction's pyramid: dir 1 is called with the images swapped
+        const uint32_t fw = dir == 0 ? w1 : w2, fh = dir == 0 ? h1 : h2;
+        if (k > ctx->band_steps || (ctx->w1 >> k) != fw || (ctx->h1 >> k) != fh)
+            return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
+    }
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s)); // transfer_in_images, gpu/mod.rs:274
@@ -547,6 +559,8 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     const bool sharded = !ctx->band_mode && den > 1 && std::min(h1, h2) / den >= 64;
     if (sharded && !ctx->gather)
         return fail(CVHIP_ERR_INVALID, "row-sharded context without an all-gather hook (cvhip_ctx_set_row_shard)");
+    if (ctx->band_mode && (k > ctx->band_steps || (ctx->w1 >> k) != w1 || (ctx->h1 >> k) != h1))
+        return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s));
@@ -563,8 +577,6 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         }));
     }
     report(progress, user, 0, 0.20f);
-    if (ctx->band_mode && (k > ctx->band_steps || (ctx->w1 >> k) != w1 || (ctx->h1 >> k) != h1))
-        return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
     if (!sharded) {
         ctx->shard_num = 0;
         ctx->shard_den = 1;
@@ -577,7 +589,11 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     hipStream_t s_rev = s;
     uint64_t pass_px = (uint64_t)w1 * h1;
     if (ctx->band_mode) pass_px = (uint64_t)w1 * (ctx->band[k].sf[1] - ctx->band[k].sf[0]);
+#ifdef CVHIP_ABLATIONS
     static const uint64_t two_stream_px = [] { const char *v = std::getenv("CVHIP_TWO_STREAM_PX"); return v ? (uint64_t)std::atoll(v) : (uint64_t)(1u << 20); }();
+#else
+    constexpr uint64_t two_stream_px = 1u << 20;
+#endif
     // (bands of a multi-GPU run: always - every pass is short there, and its kernels are not timed one by one)
     if (!sharded && ctx->aux_stream && (pass_px <= two_stream_px || ctx->band_mode)) {
         CVHIP_TRY_HIP(hipEventRecord(ctx->ev_fork, s));
@@ -585,12 +601,22 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         s_rev = ctx->aux_stream;
     }
     int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, false, s); // mod.rs:224-230
-    if (rc == CVHIP_OK && sharded) {
-        const DirState &ds = ctx->dir[0];
+    // A host hook enqueues its collective on a stream the library cannot see.  When the device handle was created on
+    // the CALLER's stream, the hook is required to use that same stream (include/cvhip.h) and ordering follows.  When
+    // the handle owns a private stream there is no such stream to share, so the library fences both sides itself:
+    // the search pass has finished before the hook runs, and everything the hook enqueued anywhere on this GPU has
+    // finished before the next kernel is submitted.  (The library's own RCCL path needs neither: it enqueues on s.)
+    const bool fence_hook = sharded && !ctx->gather_on_stream && ctx->dev->d.owns_stream;
+    const auto run_gather = [&](int dir) -> int {
+        const DirState &ds = ctx->dir[dir];
         const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);
-        if (ctx->gather(ctx->gather_user, ds.cells[ds.cur], shard_bytes, den, 0) != 0)
-            rc = fail(CVHIP_ERR_DEVICE, "all-gather hook failed (forward grid)");
-    }
+        if (fence_hook) CVHIP_TRY_HIP(hipStreamSynchronize(s));
+        if (ctx->gather(ctx->gather_user, ds.cells[ds.cur], shard_bytes, den, dir) != 0)
+            return fail(CVHIP_ERR_DEVICE, dir == 0 ? "all-gather hook failed (forward grid)" : "all-gather hook failed (reverse grid)");
+        if (fence_hook) CVHIP_TRY_HIP(hipDeviceSynchronize());
+        return CVHIP_OK;
+    };
+    if (rc == CVHIP_OK && sharded) rc = run_gather(0);
     report(progress, user, 0, 1.0f);
     if (rc == CVHIP_OK) rc = search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, false, s_rev); // mod.rs:231-237
     if (s_rev != s) { // join, also on the error path, before anything else touches the shared inputs
@@ -598,12 +624,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_join, 0) : ej;
         if (ew != hipSuccess && rc == CVHIP_OK) rc = fail(CVHIP_ERR_DEVICE, std::string("joining the reverse pass: ") + hipGetErrorString(ew));
     }
-    if (rc == CVHIP_OK && sharded) {
-        const DirState &ds = ctx->dir[1];
-        const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);
-        if (ctx->gather(ctx->gather_user, ds.cells[ds.cur], shard_bytes, den, 1) != 0)
-            rc = fail(CVHIP_ERR_DEVICE, "all-gather hook failed (reverse grid)");
-    }
+    if (rc == CVHIP_OK && sharded) rc = run_gather(1);
     ctx->shard_num = num;
     ctx->shard_den = den;
     CVHIP_TRY(rc);
@@ -723,6 +744,7 @@ int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_al
     ctx->shard_den = den;
     ctx->gather = gather;
     ctx->gather_user = user;
+    ctx->gather_on_stream = false; // a host hook; cvhip_ctx_set_row_shard_rccl sets it for the library's own collective
     return CVHIP_OK;
 }
 
@@ -917,6 +939,14 @@ int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
     ctx->borrow_inputs = borrow != 0;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_range_mode(cvhip_ctx *ctx, int mode)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (mode < 0 || mode > 3) return fail(CVHIP_ERR_INVALID, "range mode must be 0..3");
+    ctx->range_mode = mode;
     return CVHIP_OK;
 }
 

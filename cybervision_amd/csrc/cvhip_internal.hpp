@@ -192,6 +192,7 @@ struct cvhip_ctx {
     uint32_t shard_num = 0, shard_den = 1;
     cvhip_allgather_fn gather = nullptr;
     void *gather_user = nullptr;
+    bool gather_on_stream = false; // the gather enqueues on the device handle's stream (the library's RCCL path)
     // Independent-band mode (cvhip_ctx_set_row_band): per level k, the row intervals [lo, hi) of the
     // forward / reverse search passes (sf, sr) and cross-checks (cf, cr) this context has to compute so
     // that its band of the final forward grid is exact without any exchange.

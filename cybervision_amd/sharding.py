@@ -74,3 +74,47 @@ def make_allgather(rank: int, world: int, group=None, device: bool = True):
             dist.all_gather(outs, mine.clone(), group=group)
 
     return gather
+
+
+class RcclCommunicator:
+    """One RCCL communicator per device handle, created inside libcvhip (cvhip_rccl_*): no torch in the data path.
+    `unique_id()` is called on rank 0 and the 128 bytes distributed by the launcher (e.g. torch.distributed's
+    broadcast_object_list over the rendezvous store)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().cvhip_rccl_unique_id(buf), "cvhip_rccl_unique_id")
+        return bytes(buf)
+
+    def __init__(self, device, unique_id: bytes, rank: int, world: int):
+        from . import _lib
+
+        assert len(unique_id) == 128
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(_lib.lib().cvhip_rccl_create(device.handle, buf, rank, world, C.byref(self._h)), "cvhip_rccl_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def allgather(self, ptr: int, shard_bytes: int):
+        from . import _lib
+
+        _lib.check(_lib.lib().cvhip_rccl_allgather(self._h, C.c_void_p(ptr), shard_bytes), "cvhip_rccl_allgather")
+
+    def gather(self, ptr: int, shard_bytes: int, root: int = 0):
+        from . import _lib
+
+        _lib.check(_lib.lib().cvhip_rccl_gather(self._h, C.c_void_p(ptr), shard_bytes, root), "cvhip_rccl_gather")
+
+    def close(self):
+        from . import _lib
+
+        if getattr(self, "_h", None):
+            _lib.lib().cvhip_rccl_destroy(self._h)
+            self._h = None

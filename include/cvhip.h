@@ -118,7 +118,11 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
  * pass, on the calling thread.  `cells` is the device pointer of the level grid of direction
  * `dir`; shard r (0 <= r < n_shards) owns bytes [r*shard_bytes, (r+1)*shard_bytes).  The hook
  * must all-gather in place (e.g. ncclAllGather / torch.distributed.all_gather_into_tensor on
- * the stream given to cvhip_device_create_on_stream) and return 0, or non-zero to abort. */
+ * the stream given to cvhip_device_create_on_stream) and return 0, or non-zero to abort.
+ * Stream ordering: with a device handle created by cvhip_device_create_on_stream the hook MUST enqueue its collective
+ * on that stream (the search pass before it and the cross-checks after it are submitted there).  With a handle that
+ * owns a private stream (cvhip_device_create) the library fences both sides of the hook itself (stream synchronise
+ * before, device synchronise after) - correct, but slower.  cvhip_ctx_set_row_shard_rccl needs neither. */
 typedef int (*cvhip_allgather_fn)(void *user, void *cells, uint64_t shard_bytes, uint32_t n_shards, int dir);
 
 /* Dense consumer — replaces AffineTriangulation::triangulate + triangulate_point
@@ -168,6 +172,29 @@ int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_al
  * column-major lines): fall back to cvhip_ctx_set_row_shard + all-gather hook.  The context must be
  * driven with cvhip_correlate_level over the reference's schedule (scale = 2^-k, k = steps..0). */
 int cvhip_ctx_set_row_band(cvhip_ctx *ctx, uint32_t num, uint32_t den);
+/* ------------------------------------------------------------------------------------------
+ * The collectives of row sharding on RCCL, inside the library (no torch, no host hook): one process per GPU, one
+ * communicator per device handle, every collective enqueued on the handle's own stream - ordered with the kernels
+ * around it by construction.  librccl.so.1 is opened on first use (CVHIP_ERR_UNSUPPORTED if it cannot be).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cvhip_rccl cvhip_rccl;
+#define CVHIP_RCCL_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls this and hands the 128 bytes to every rank (launcher's store, MPI, a file). */
+int cvhip_rccl_unique_id(uint8_t *id);
+/* ncclCommInitRank on the handle's GPU; collective over all `world` ranks (<= 64). */
+int cvhip_rccl_create(cvhip_device *dev, const uint8_t *id, uint32_t rank, uint32_t world, cvhip_rccl **out);
+void cvhip_rccl_destroy(cvhip_rccl *comm);
+/* In-place all-gather of `world` chunks of shard_bytes at `buf` (device memory; this rank's chunk already in place). */
+int cvhip_rccl_allgather(cvhip_rccl *comm, void *buf, uint64_t shard_bytes);
+/* In-place gather to `root` only: every other rank sends its chunk straight into the root's buffer (grouped
+ * ncclSend/ncclRecv - on an 8-GPU xGMI node seven concurrent point-to-point transfers, not a ring). */
+int cvhip_rccl_gather(cvhip_rccl *comm, void *buf, uint64_t shard_bytes, uint32_t root);
+/* cvhip_ctx_set_row_shard(ctx, rank, world, <all-gather above>): bands + one all-gather per sharded search pass. */
+int cvhip_ctx_set_row_shard_rccl(cvhip_ctx *ctx, cvhip_rccl *comm);
+/* The single gather of independent-band mode (cvhip_ctx_set_row_band(ctx, rank, world)): after the last level, the
+ * forward level grid's bands go to `root` (root < 0: to every rank) before cvhip_complete. */
+int cvhip_ctx_gather_bands_rccl(cvhip_ctx *ctx, cvhip_rccl *comm, int root);
+
 /* Device pointer + geometry of direction `dir`'s current level grid, for the host's
  * collectives.  One 8-byte cell per level pixel, row-major lw x lh: u32 x | y << 16 in LEVEL
  * coordinates (0xFFFFFFFF = None) followed by the f32 score.  The buffer always has room for
@@ -211,6 +238,10 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
  * epipolar lines), with 2 for every other geometry and as the per-workgroup fallback; 4 = 3 with the
  * box kernel launched for every geometry (testing).  All give identical results. */
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
+/* Test hook of the search-range kernel (estimate_search_range, mod.rs:468-540): 0 (default) = integer box sums with the
+ * reference's f64 chain only where the rounding of `len` is open, 1 = the chain for every pixel, 2 / 3 = every third
+ * block of a box-sum tile through the staged / the global-memory chain.  All give identical results. */
+int cvhip_ctx_set_range_mode(cvhip_ctx *ctx, int mode);
 
 /* ------------------------------------------------------------------------------------------
  * Pyramid level on the device.  The reference builds every level with

@@ -40,3 +40,27 @@ xy, corr = pc.complete()
 print("rccl smoke ok:", int((xy[..., 0] >= 0).sum()), "matches")
 pc.close()
 dist.destroy_process_group()
+
+# the library's own RCCL path (cvhip_rccl_*), world size 1, on a device handle that owns a PRIVATE stream: the
+# communicator, the in-place all-gather / gather-to-root on a level grid, and the sharded-context wiring
+dev2 = correlation.create_gpu_context(ordinal=0)
+comm = sharding.RcclCommunicator(dev2, sharding.RcclCommunicator.unique_id(), 0, 1)
+pc = correlation.PointCorrelations(dev2, (512, 512), (512, 512), synth.f_tilt(30.0))
+pc.set_row_shard_rccl(comm)
+for i in range(steps + 1):
+    k = steps - i
+    pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+g = pc.level_grid(correlation.CorrelationDirection.Forward)
+nbytes = g["rows_per_shard"] * g["lw"] * 8
+dev2.synchronize()
+before = sharding.alias_bytes(g["cells"], nbytes, device=True).clone()
+comm.allgather(g["cells"], nbytes)
+comm.gather(g["cells"], nbytes, 0)
+pc.gather_bands_rccl(comm, 0)
+dev2.synchronize()
+assert torch.equal(before, sharding.alias_bytes(g["cells"], nbytes, device=True))
+xy2, _ = pc.complete()
+print("library rccl smoke ok:", int((xy2[..., 0] >= 0).sum()), "matches")
+pc.close()
+comm.close()
+dev2.close()

@@ -30,13 +30,15 @@ def assert_same_grid(got, want, what):
     assert np.isnan(gc[~valid]).all()
 
 
-def run_gpu(dev, c, fused=True, both=False, version=None, counters=None):
+def run_gpu(dev, c, fused=True, both=False, version=None, counters=None, range_mode=None):
     p1, p2 = cases.pyramids(c)
     h1, w1 = c["img1"].shape
     h2, w2 = c["img2"].shape
     pc = correlation.PointCorrelations(dev, (w1, h1), (w2, h2), c["F"], correlation.ProjectionMode(c["projection"]))
     if version is not None:
         pc.set_search_version(version)
+    if range_mode is not None:
+        pc.set_range_mode(range_mode)
     if counters is not None:
         pc.set_profiling(False, True)
     try:
@@ -227,8 +229,8 @@ def test_candidate_counter_matches_oracle(gpu_device, oracle):
 
 @pytest.mark.parametrize("name", ["h256", "sem320x200", "tilt3_200x150", "persp_240x180", "ragged_dims", "vert_200x260",
                                   "flat"])
-def test_search_range_sum_path_equals_chain(gpu_device, oracle, name, monkeypatch):
-    """estimate_search_range from integer box sums (CVHIP_RANGE=0, the default) against the f64 chain alone (=1)
+def test_search_range_sum_path_equals_chain(gpu_device, oracle, name):
+    """estimate_search_range from integer box sums (range mode 0, the default) against the f64 chain alone (=1)
     and against the test hooks that send every third block of a sum tile through the chain, over the staged tile
     (=2) or over global memory (=3): the same
     matches, scores and - because every corridor bound enters it - the same candidate count as the oracle."""
@@ -236,29 +238,27 @@ def test_search_range_sum_path_equals_chain(gpu_device, oracle, name, monkeypatc
     p1, p2 = cases.pyramids(c)
     _, _, cand = oracle.correlate_dense(p1, p2, c["F"], c["projection"], 8)
     want = run_oracle(oracle, c, both=True)
-    for mode in ("0", "1", "2", "3"):
-        monkeypatch.setenv("CVHIP_RANGE", mode)
+    for mode in (0, 1, 2, 3):
         cnt = {}
-        got = run_gpu(gpu_device, c, both=True, counters=cnt)
+        got = run_gpu(gpu_device, c, both=True, counters=cnt, range_mode=mode)
         assert_same_grid(got[0], want[0], f"{name} range mode {mode} forward")
         assert_same_grid(got[1], want[1], f"{name} range mode {mode} reverse")
         assert cnt["candidates"] == cand, f"{name} range mode {mode}"
 
 
 @pytest.mark.parametrize("tilt", [0.0, 3.0, 90.0])
-def test_search_range_sum_path_equals_chain_1024(gpu_device, tilt, monkeypatch):
+def test_search_range_sum_path_equals_chain_1024(gpu_device, tilt):
     a, b, _ = synth.make_pair(1024, 1024, seed=53, tilt_deg=tilt, sem_style=tilt == 0.0)
     steps = synth.optimal_scale_steps(1024, 1024)
     c = dict(img1=a, img2=b, F=synth.f_tilt(tilt), projection=0, steps=steps)
     res = {}
-    for mode in ("1", "0", "2", "3"):
-        monkeypatch.setenv("CVHIP_RANGE", mode)
+    for mode in (1, 0, 2, 3):
         cnt = {}
-        res[mode] = run_gpu(gpu_device, c, both=True, counters=cnt), cnt["candidates"]
-    for mode in ("0", "2", "3"):
+        res[mode] = run_gpu(gpu_device, c, both=True, counters=cnt, range_mode=mode), cnt["candidates"]
+    for mode in (0, 2, 3):
         for d in (0, 1):
-            assert_same_grid(res[mode][0][d], res["1"][0][d], f"tilt {tilt} range mode {mode} dir {d}")
-        assert res[mode][1] == res["1"][1] and res[mode][1] > 100_000_000
+            assert_same_grid(res[mode][0][d], res[1][0][d], f"tilt {tilt} range mode {mode} dir {d}")
+        assert res[mode][1] == res[1][1] and res[mode][1] > 100_000_000
 
 
 def test_device_resident_inputs_and_outputs(gpu_device, oracle):
