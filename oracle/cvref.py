@@ -30,13 +30,10 @@ def build(force: bool = False) -> Path:
     return so
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        so = _HERE / "libcvref.so"
-        if not so.exists():
-            build()
-        L = C.CDLL(str(so))
+def _load(so: Path):
+    if True:
+        if True:
+            L = C.CDLL(str(so))
         L.cvref_corr_new.restype = C.c_void_p
         L.cvref_corr_new.argtypes = [C.c_uint32] * 4 + [_f64p, C.c_int, C.c_int]
         L.cvref_corr_free.argtypes = [C.c_void_p]
@@ -78,8 +75,29 @@ def lib():
         L.cvref_ransac_score.argtypes = [_f64p, C.c_uint32, _u32p, C.c_uint32, C.c_double, _u32p, _f64p]
         L.cvref_optimize_perspective_f.restype = C.c_int
         L.cvref_optimize_perspective_f.argtypes = [_f64p, _u32p, C.c_uint32, _f64p]
-        _LIB = L
+    return L
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = _HERE / "libcvref.so"
+        if not so.exists():
+            build()
+        _LIB = _load(so)
     return _LIB
+
+
+_ALT = None
+
+
+def alt_lib():
+    """The sensitivity build (-DCVREF_ALT_ASSOC: the other association of nalgebra's three-term F*p / dot products)."""
+    global _ALT
+    if _ALT is None:
+        subprocess.check_call(["make", "-C", str(_HERE), "libcvref_alt.so"], stdout=subprocess.DEVNULL)
+        _ALT = _load(_HERE / "libcvref_alt.so")
+    return _ALT
 
 
 def default_threads() -> int:
@@ -89,18 +107,19 @@ def default_threads() -> int:
 class Corr:
     """PointCorrelations, CPU branch (src/correlation/mod.rs:150-245)."""
 
-    def __init__(self, dims1, dims2, F, projection: int = 0, nthreads: int | None = None):
+    def __init__(self, dims1, dims2, F, projection: int = 0, nthreads: int | None = None, alt: bool = False):
         self.w1, self.h1 = dims1
         self.w2, self.h2 = dims2
         self.nthreads = nthreads or default_threads()
+        self._lib = alt_lib() if alt else lib()
         F = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(9))
-        self._h = lib().cvref_corr_new(self.w1, self.h1, self.w2, self.h2, F, projection, self.nthreads)
+        self._h = self._lib.cvref_corr_new(self.w1, self.h1, self.w2, self.h2, F, projection, self.nthreads)
         if not self._h:
             raise MemoryError("cvref_corr_new")
 
     def close(self):
         if self._h:
-            lib().cvref_corr_free(self._h)
+            self._lib.cvref_corr_free(self._h)
             self._h = None
 
     __del__ = close
@@ -108,7 +127,7 @@ class Corr:
     def correlate_images(self, img1, img2, scale: float):
         img1 = np.ascontiguousarray(img1, dtype=np.uint8)
         img2 = np.ascontiguousarray(img2, dtype=np.uint8)
-        rc = lib().cvref_corr_correlate_images(self._h, img1, img1.shape[1], img1.shape[0], img2, img2.shape[1],
+        rc = self._lib.cvref_corr_correlate_images(self._h, img1, img1.shape[1], img1.shape[0], img2, img2.shape[1],
                                                img2.shape[0], scale)
         if rc:
             raise RuntimeError(f"cvref_corr_correlate_images rc={rc}")
@@ -116,36 +135,36 @@ class Corr:
     def step(self, img1, img2, scale: float, direction: int):
         img1 = np.ascontiguousarray(img1, dtype=np.uint8)
         img2 = np.ascontiguousarray(img2, dtype=np.uint8)
-        rc = lib().cvref_corr_step(self._h, img1, img1.shape[1], img1.shape[0], img2, img2.shape[1], img2.shape[0],
+        rc = self._lib.cvref_corr_step(self._h, img1, img1.shape[1], img1.shape[0], img2, img2.shape[1], img2.shape[0],
                                    scale, direction)
         if rc:
             raise RuntimeError(f"cvref_corr_step rc={rc}")
 
     def cross_check(self, scale: float, direction: int):
-        lib().cvref_corr_cross_check(self._h, scale, direction)
+        self._lib.cvref_corr_cross_check(self._h, scale, direction)
 
     def end_level(self):
-        lib().cvref_corr_end_level(self._h)
+        self._lib.cvref_corr_end_level(self._h)
 
     def get(self, direction: int = 0):
         w, h = (self.w1, self.h1) if direction == 0 else (self.w2, self.h2)
         xy = np.empty((h, w, 2), dtype=np.int32)
         corr = np.empty((h, w), dtype=np.float32)
-        lib().cvref_corr_get(self._h, direction, xy, corr)
+        self._lib.cvref_corr_get(self._h, direction, xy, corr)
         return xy, corr
 
     @property
     def candidates(self) -> int:
-        return int(lib().cvref_corr_candidates(self._h))
+        return int(self._lib.cvref_corr_candidates(self._h))
 
 
-def correlate_dense(pyr1, pyr2, F, projection: int = 0, nthreads: int | None = None):
+def correlate_dense(pyr1, pyr2, F, projection: int = 0, nthreads: int | None = None, alt: bool = False):
     """The level loop of correlate_dense (src/reconstruction.rs:554-588) over prebuilt pyramids
     (pyr[k] is the 1/2^k image).  Returns (xy, corr, candidates) for the forward grid."""
     steps = len(pyr1) - 1
     h1, w1 = pyr1[0].shape
     h2, w2 = pyr2[0].shape
-    c = Corr((w1, h1), (w2, h2), F, projection, nthreads)
+    c = Corr((w1, h1), (w2, h2), F, projection, nthreads, alt)
     try:
         for i in range(steps + 1):
             k = steps - i

@@ -269,9 +269,14 @@ static epipolar_line get_epipolar_line(const step_t *s, size_t px, size_t py)
     double p0 = (double)px / scale, p1 = (double)py / scale, p2 = 1.0;
     double f[3];
     for (int i = 0; i < 3; i++) {
+#ifndef CVREF_ALT_ASSOC
         double acc = s->F[i * 3 + 0] * p0;
         acc = s->F[i * 3 + 1] * p1 + acc;
         acc = s->F[i * 3 + 2] * p2 + acc;
+#else   /* sensitivity build (tests/test_oracle_corr.py): the other association of the three-term sum, to bound what
+         * depends on the unverifiable nalgebra evaluation order */
+        double acc = s->F[i * 3 + 0] * p0 + (s->F[i * 3 + 1] * p1 + s->F[i * 3 + 2] * p2);
+#endif
         f[i] = acc;
     }
     epipolar_line e;

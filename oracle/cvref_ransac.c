@@ -19,22 +19,38 @@ double cvref_reprojection_error(const double *F, const uint32_t *m)
     const double p2[3] = {(double)m[2], (double)m[3], 1.0};
     /* p2.tr_mul(f): row vector, element j = dot(p2, F[:, j]) */
     double p2t_f[3];
+#ifndef CVREF_ALT_ASSOC
     for (int j = 0; j < 3; j++) p2t_f[j] = (p2[0] * F[0 * 3 + j] + p2[1] * F[1 * 3 + j]) + p2[2] * F[2 * 3 + j];
+#else   /* sensitivity build: the other association everywhere in this function */
+    for (int j = 0; j < 3; j++) p2t_f[j] = p2[0] * F[0 * 3 + j] + (p2[1] * F[1 * 3 + j] + p2[2] * F[2 * 3 + j]);
+#endif
     /* (1x3) * p1 */
+#ifndef CVREF_ALT_ASSOC
     double p2t_f_p1 = p2t_f[0] * p1[0];
     p2t_f_p1 = p2t_f[1] * p1[1] + p2t_f_p1;
     p2t_f_p1 = p2t_f[2] * p1[2] + p2t_f_p1;
+#else
+    double p2t_f_p1 = p2t_f[0] * p1[0] + (p2t_f[1] * p1[1] + p2t_f[2] * p1[2]);
+#endif
     /* f * p1 */
     double f_p1[3];
     for (int i = 0; i < 3; i++) {
+#ifndef CVREF_ALT_ASSOC
         double acc = F[i * 3 + 0] * p1[0];
         acc = F[i * 3 + 1] * p1[1] + acc;
         acc = F[i * 3 + 2] * p1[2] + acc;
+#else
+        double acc = F[i * 3 + 0] * p1[0] + (F[i * 3 + 1] * p1[1] + F[i * 3 + 2] * p1[2]);
+#endif
         f_p1[i] = acc;
     }
     /* f.tr_mul(&p2): element i = dot(F[:, i], p2) */
     double ft_p2[3];
+#ifndef CVREF_ALT_ASSOC
     for (int i = 0; i < 3; i++) ft_p2[i] = (F[0 * 3 + i] * p2[0] + F[1 * 3 + i] * p2[1]) + F[2 * 3 + i] * p2[2];
+#else
+    for (int i = 0; i < 3; i++) ft_p2[i] = F[0 * 3 + i] * p2[0] + (F[1 * 3 + i] * p2[1] + F[2 * 3 + i] * p2[2]);
+#endif
     double nominator = p2t_f_p1 * p2t_f_p1;
     double denominator = f_p1[0] * f_p1[0] + f_p1[1] * f_p1[1] + ft_p2[0] * ft_p2[0] + ft_p2[1] * ft_p2[1];
     return nominator / denominator;
@@ -100,9 +116,13 @@ static void lm_jacobian_row(const double *F, const uint32_t *m, double *out)
     const double p2[3] = {(double)m[2], (double)m[3], 1.0};
     double f_p1[3], ft_p2[3];
     for (int i = 0; i < 3; i++) {
+#ifndef CVREF_ALT_ASSOC
         double acc = F[i * 3 + 0] * p1[0];
         acc = F[i * 3 + 1] * p1[1] + acc;
         acc = F[i * 3 + 2] * p1[2] + acc;
+#else
+        double acc = F[i * 3 + 0] * p1[0] + (F[i * 3 + 1] * p1[1] + F[i * 3 + 2] * p1[2]);
+#endif
         f_p1[i] = acc;
         ft_p2[i] = (F[0 * 3 + i] * p2[0] + F[1 * 3 + i] * p2[1]) + F[2 * 3 + i] * p2[2];
     }

@@ -338,15 +338,28 @@ def test_error_reporting(gpu_device):
         correlation.PointCorrelations(gpu_device, (8, 8), (128, 128), synth.F_HORIZONTAL)
 
 
-def test_full_size_properties_1024(gpu_device):
-    """At BASELINE's 1024^2 the oracle is too slow for CI, so check size-independent properties:
-    determinism, known-disparity recovery, cross-check consistency, border emptiness."""
+def test_config2_1024_sem_matches_oracle_and_properties(gpu_device, oracle):
+    """BASELINE config 2 (1024^2 SEM-style pair, 5 levels) at full size: bit-exact against the oracle run on all host
+    cores (a couple of seconds on the GPU box), both directions; plus the size-independent properties: determinism,
+    known-disparity recovery, cross-check consistency, border emptiness."""
+    import os
+
     a, b, d = synth.make_pair(1024, 1024, sem_style=True)
     steps = synth.optimal_scale_steps(1024, 1024)
     c = dict(img1=a, img2=b, F=synth.F_HORIZONTAL, projection=0, steps=steps)
     (fxy, fc), (rxy, rc) = run_gpu(gpu_device, c, both=True)
     (fxy2, fc2) = run_gpu(gpu_device, c)
     assert (fxy == fxy2).all() and (bits(fc) == bits(fc2)).all(), "not deterministic"
+    p1, p2 = cases.pyramids(c)
+    oc = oracle.Corr((1024, 1024), (1024, 1024), c["F"], 0, os.cpu_count())
+    try:
+        for i in range(steps + 1):
+            k = steps - i
+            oc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+        assert_same_grid((fxy, fc), oc.get(0), "1024 SEM forward")
+        assert_same_grid((rxy, rc), oc.get(1), "1024 SEM reverse")
+    finally:
+        oc.close()
     valid = fxy[..., 0] >= 0
     assert valid.mean() > 0.6
     assert not valid[:5].any() and not valid[-5:].any() and not valid[:, :5].any() and not valid[:, -5:].any()
@@ -521,6 +534,29 @@ def test_full_size_4096_filters_equal_exact_kernel():
     ys, xs = np.nonzero(vf)
     x2, y2 = fxy[..., 0][vf], fxy[..., 1][vf]
     assert (np.abs(x2 + d[y2, x2] - xs) <= 1).mean() > 0.97
+
+
+def test_config3_4096_matches_oracle_digest(gpu_device):
+    """BASELINE config 3 (the 4096^2 headline pair, 7 levels) against the ORACLE at full size: SHA-256 of the forward
+    and reverse match planes and score planes, generated by tests/tools/gen_digest_4096.py from oracle/cvref_corr.c
+    (its result is independent of the thread count and of the machine) and committed under tests/golden/."""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    want = json.loads((Path(__file__).parent / "golden" / "corr_4096_digest.json").read_text())
+    size = want["size"]
+    a, b, _ = synth.make_pair(size, size)
+    c = dict(img1=a, img2=b, F=synth.F_HORIZONTAL, projection=0, steps=synth.optimal_scale_steps(size, size))
+    cnt = {}
+    fwd, rev = run_gpu(gpu_device, c, both=True, counters=cnt)
+    assert cnt["candidates"] == want["candidates"]
+    for name, (xy, corr) in (("forward", fwd), ("reverse", rev)):
+        valid = xy[..., 0] >= 0
+        assert int(valid.sum()) == want[name]["matches"], name
+        assert hashlib.sha256(np.ascontiguousarray(xy, dtype=np.int32).tobytes()).hexdigest() == want[name]["xy_sha256"], name
+        score_bits = np.where(valid, corr.view(np.uint32), np.uint32(0))
+        assert hashlib.sha256(np.ascontiguousarray(score_bits).tobytes()).hexdigest() == want[name]["score_sha256"], name
 
 
 @pytest.mark.parametrize("name", ["tilt3_200x150", "h256", "flat"])
