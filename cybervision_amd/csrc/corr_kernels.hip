@@ -69,6 +69,13 @@ __device__ __forceinline__ Row12 load_row12(const uint8_t *p)
     return r;
 }
 __device__ __forceinline__ float byte_f32(uint32_t v, int i) { return (float)((v >> (8 * i)) & 0xFFu); }
+// (avg, stdev) of a pixel from its statistics word {window sum | VALID << 31, f32 bits of stdev} (window_stats_kernel):
+// avg = (sum of the window as f32) / 121 is the reference's own expression (mod.rs:657-671; the f32 sum of 121 bytes is
+// an exact integer), so nothing is lost by not storing it.  Pixels outside the 5-px border carry stdev = NaN.
+__device__ __forceinline__ float2 stats_of(uint2 w)
+{
+    return make_float2((float)(w.x & 0x7FFFFFFFu) / (float)KERNEL_POINT_COUNT, __uint_as_float(w.y));
+}
 
 // Serial row-major accumulation over one 11-byte window row, exactly as the reference's scalar loops do it
 // (every subtraction, product and addition separately rounded, additions in element order); the independent
@@ -185,7 +192,6 @@ constexpr int WS_PITCH = 88; // bytes per staged row: 64 + 2*5 window columns, d
 struct StatsJob { // one image's statistics pass
     const uint8_t *img;
     uint32_t w, h, row0, row1;
-    float2 *stats;
     uint2 *istats;
 };
 
@@ -223,7 +229,6 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
     const StatsJob &job = blockIdx.z == 0 ? ja : jb;
     const uint8_t *__restrict__ img = job.img;
     const uint32_t w = job.w, h = job.h, row0 = job.row0, row1 = job.row1;
-    float2 *__restrict__ stats = job.stats;
     uint2 *__restrict__ istats = job.istats;
     const TileId tid = xcd_tile();
     const uint32_t x0 = tid.x * 64, y0 = row0 + tid.y * WS_ROWS;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
     if (x >= w || ya >= row1) return;
     const float nan = __builtin_nanf("");
     float2 out_a = make_float2(nan, nan), out_b = out_a;
-    uint2 iout_a = make_uint2(0u, 0u), iout_b = iout_a;
+    uint2 iout_a = make_uint2(0u, __float_as_uint(nan)), iout_b = iout_a; // outside the border: not VALID, stdev NaN
     const bool col_in = x >= KERNEL_SIZE && x + KERNEL_SIZE < w;
     const bool in_a = col_in && ya >= KERNEL_SIZE && ya + KERNEL_SIZE < h;
     const bool in_b = col_in && yb >= KERNEL_SIZE && yb + KERNEL_SIZE < h && yb < row1;
@@ -290,20 +295,16 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
             iout_b = make_uint2(isum_b | (valid ? 0x80000000u : 0u), __float_as_uint(out_b.y));
         }
     }
-    stats[(size_t)ya * w + x] = out_a;
     istats[(size_t)ya * w + x] = iout_a;
-    if (yb < row1) {
-        stats[(size_t)yb * w + x] = out_b;
-        istats[(size_t)yb * w + x] = iout_b;
-    }
+    if (yb < row1) istats[(size_t)yb * w + x] = iout_b;
 }
 
-void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, float2 *stats_a, uint2 *istats_a,
-                              const uint8_t *img_b, uint32_t wb, uint32_t hb, float2 *stats_b, uint2 *istats_b,
+void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, uint2 *istats_a,
+                              const uint8_t *img_b, uint32_t wb, uint32_t hb, uint2 *istats_b,
                               uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s)
 {
-    const StatsJob ja{img_a, wa, ha, row0, row1 < ha ? row1 : ha, stats_a, istats_a};
-    const StatsJob jb{img_b, wb, hb, row0, row1 < hb ? row1 : hb, stats_b, istats_b};
+    const StatsJob ja{img_a, wa, ha, row0, row1 < ha ? row1 : ha, istats_a};
+    const StatsJob jb{img_b, wb, hb, row0, row1 < hb ? row1 : hb, istats_b};
     const uint32_t rows_a = ja.row1 > row0 ? ja.row1 - row0 : 0u, rows_b = jb.row1 > row0 ? jb.row1 - row0 : 0u;
     const uint32_t rows = rows_a > rows_b ? rows_a : rows_b;
     if (rows == 0) {
@@ -363,7 +364,7 @@ __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x,
 // clamping included — so the neighbour statistics are computed once and shared; each pixel then applies
 // its own validity tests and corridor bounds.  (Pixels of one block on different corridor axes, possible
 // only for perspective geometry, each get their own axis' statistics.)
-__global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const float2 *__restrict__ stats1,
+__global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const uint2 *__restrict__ stats1,
                                                             const uint2 *__restrict__ prev,
                                                             uint32_t *__restrict__ range, int mode)
 {
@@ -424,8 +425,9 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
         if (x >= p.w1 || y >= p.row1 || y < p.row0 || y >= p.h1) continue;
         const bool interior = x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
         if (!interior) continue;
-        const float2 st1 = stats1[(size_t)y * p.w1 + x];
-        if (!(finite_f32(st1.y) && !(fabsf(st1.y) < p.min_stdev))) continue; // mod.rs:334 (same outcome)
+        // (mod.rs:334, the searched pixel's stdev test, is not repeated here: every search kernel applies it in
+        // pixel_setup BEFORE it reads this pixel's interval, so the interval of a rejected pixel is never looked at -
+        // and not reading the statistics word saves 8 B per pixel of HBM traffic)
         Line e = e0;
         bool line_ok = false;
         if (quick) {
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const f
     }
 }
 
-void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range, int mode,
+void launch_search_range(const CorrParams &p, const uint2 *stats1, const uint2 *prev, uint32_t *range, int mode,
                          hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
@@ -709,8 +711,8 @@ void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                       const uint8_t *__restrict__ img2,
-                                                      const float2 *__restrict__ stats1,
-                                                      const float2 *__restrict__ stats2,
+                                                      const uint2 *__restrict__ stats1,
+                                                      const uint2 *__restrict__ stats2,
                                                       const uint32_t *__restrict__ range,
                                                       uint2 *__restrict__ out,
                                                       unsigned long long *__restrict__ cand_counter)
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
     const bool interior =
         in_image && x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1;
     if (interior) {
-        const float2 st1 = stats1[(size_t)y * p.w1 + x];
+        const float2 st1 = stats_of(stats1[(size_t)y * p.w1 + x]);
         const Line e = epipolar_line(p, x, y);
         bool ok = finite_f32(st1.y) && !(fabsf(st1.y) < p.min_stdev) && line_finite(e); // mod.rs:334-345
         uint32_t r0 = KERNEL_SIZE, r1 = corridor_end_of(p, e);
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
                     const uint32_t y2 = f64_to_u32_sat(floor(y2d));
                     if (x2 < KERNEL_SIZE || x2 >= p.w2 - KERNEL_SIZE || y2 < KERNEL_SIZE || y2 >= p.h2 - KERNEL_SIZE)
                         continue;
-                    const float2 st2 = stats2[(size_t)y2 * p.w2 + x2];
+                    const float2 st2 = stats_of(stats2[(size_t)y2 * p.w2 + x2]);
                     if (!finite_f32(st2.y) || fabsf(st2.y) < p.min_stdev) continue;
                     evaluated++;
                     const float avg2 = st2.x;
@@ -804,8 +806,8 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
     }
 }
 
-void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                   const float2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
+void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
+                   const uint2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
                    hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
@@ -919,11 +921,11 @@ struct PixelSetup {
     uint32_t r0, r1;
 };
 __device__ __forceinline__ bool pixel_setup(const CorrParams &p, uint32_t x, uint32_t y,
-                                            const float2 *__restrict__ stats1, const uint32_t *__restrict__ range,
+                                            const uint2 *__restrict__ stats1, const uint32_t *__restrict__ range,
                                             PixelSetup &ps)
 {
     if (!(x >= KERNEL_SIZE && y >= KERNEL_SIZE && x + KERNEL_SIZE < p.w1 && y + KERNEL_SIZE < p.h1)) return false;
-    ps.st1 = stats1[(size_t)y * p.w1 + x];
+    ps.st1 = stats_of(stats1[(size_t)y * p.w1 + x]);
     ps.e = epipolar_line(p, x, y);
     if (!(finite_f32(ps.st1.y) && !(fabsf(ps.st1.y) < p.min_stdev) && line_finite(ps.e))) return false; // :334-345
     ps.r0 = KERNEL_SIZE;
@@ -939,9 +941,11 @@ __device__ __forceinline__ bool pixel_setup(const CorrParams &p, uint32_t x, uin
 
 // ---- kernel A: filter ---------------------------------------------------------------------------------
 // One tile: `width` (<= 64) pixels from x0 in the four rows of row tile `ytile`.
+// Returns (uniformly for the workgroup) whether the tile holds whole-corridor pixels; only then are its contender
+// words written (each lane reads back only its own) and, when a work list is given, the tile is queued on it.
 template <bool COUNT>
-__device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const uint8_t *__restrict__ img1,
-                                                    const uint8_t *__restrict__ img2, const float2 *__restrict__ stats1,
+__device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const uint8_t *__restrict__ img1,
+                                                    const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
                                                     const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2,
                                                     const uint32_t *__restrict__ range,
                                                     unsigned long long *__restrict__ contenders, uint2 *__restrict__ out,
@@ -973,7 +977,7 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
     bool mine = in_image;
     if (only_fallback) {
         mine = in_image && (uint32_t)(contenders[(size_t)y * p.w1 + x] >> 60) == (uint32_t)CW_FALLBACK;
-        if (!__syncthreads_or(mine ? 1 : 0)) return;
+        if (!__syncthreads_or(mine ? 1 : 0)) return false;
     }
     const bool active = mine && pixel_setup(p, x, y, stats1, range, ps);
     const Line &e = ps.e;
@@ -1264,8 +1268,9 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
             if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
         }
     }
+    const int any_whole = __syncthreads_or(whole ? 1 : 0); // every thread of the workgroup is still here
     if (mine) {
-        contenders[(size_t)y * p.w1 + x] = word;
+        if (any_whole) contenders[(size_t)y * p.w1 + x] = word;
         if (!whole) out[(size_t)y * p.w1 + x] = cell;
     }
     if (counters) {
@@ -1284,30 +1289,27 @@ __device__ __forceinline__ void search2_filter_tile(const CorrParams &p, const u
             if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
         }
     }
-    if (whole_list.count) { // uniform; every thread of the workgroup is still here
-        const int any_whole = __syncthreads_or(whole ? 1 : 0);
-        if (threadIdx.x == 0 && any_whole)
-            worklist_push(whole_list, tl.x0 | (((tl.y0 - p.row0) / 4u) << 16) | (tl.nl == 64u ? 0x80000000u : 0u));
-    }
+    if (whole_list.count && threadIdx.x == 0 && any_whole)
+        worklist_push(whole_list, tl.x0 | (((tl.y0 - p.row0) / 4u) << 16) | (tl.nl == 64u ? 0x80000000u : 0u));
+    return any_whole != 0;
 }
 
 template <bool COUNT>
 __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                                  const uint8_t *__restrict__ img2,
-                                                                 const float2 *__restrict__ stats1,
+                                                                 const uint2 *__restrict__ stats1,
                                                                  const uint2 *__restrict__ istats1,
                                                                  const uint2 *__restrict__ istats2,
                                                                  const uint32_t *__restrict__ range,
                                                                  unsigned long long *__restrict__ contenders,
                                                                  uint2 *__restrict__ out,
                                                                  unsigned long long *__restrict__ counters,
-                                                                 uint32_t lds_bytes)
+                                                                 WorkList whole_list, uint32_t lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     const TileId tid = xcd_tile();
-    search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0,
-                               PixTile{tid.x * 64u, p.row0 + tid.y * 4u, 64u, false}, WorkList{nullptr, nullptr}, dyn_lds,
-                               lds_bytes);
+    (void)search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0,
+                                     PixTile{tid.x * 64u, p.row0 + tid.y * 4u, 64u, false}, whole_list, dyn_lds, lds_bytes);
 }
 
 // ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
@@ -1394,7 +1396,7 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 template <bool COUNT, bool STEP, bool TR>
 __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                            const uint8_t *__restrict__ img2,
-                                                           const float2 *__restrict__ stats1,
+                                                           const uint2 *__restrict__ stats1,
                                                            const uint2 *__restrict__ istats1,
                                                            const uint2 *__restrict__ istats2,
                                                            const uint32_t *__restrict__ range,
@@ -1537,8 +1539,10 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
     if (!eligible || !any_has) {
         // nothing to search (every pixel None), or left to the candidate-by-candidate kernel
         if (is_out) {
+            // contender words are only read for tiles on a work list: a declined tile hands its pixels over through
+            // them; a tile with nothing to search is on no list and writes none
             const bool fb = active && !eligible;
-            contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
+            if (!eligible) contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
             if (!fb) out[pix] = make_uint2(CELL_NONE, 0x7FC00000u);
         }
         if (!eligible && threadIdx.x == 0) {
@@ -1807,7 +1811,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
                 uint32_t xo = x, yo = y;
                 asm volatile("" : "+v"(xo), "+v"(yo));
                 ex = epipolar_line(p, xo, yo);
-                st1x = stats1[(size_t)yo * p.w1 + xo];
+                st1x = stats_of(stats1[(size_t)yo * p.w1 + xo]);
             }
             const float avg1 = st1x.x, sdev1 = st1x.y;
             const uint8_t *base1 = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
@@ -1847,10 +1851,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
             if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
         }
     }
-    if (is_out) {
-        contenders[pix] = word;
-        if (!whole) out[pix] = cell;
-    }
+    if (is_out && !whole) out[pix] = cell;
     if (counters) {
         uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = whole;
         if (p.debug & 32) { // diagnostics: displacements walked per wave, waves that walked
@@ -1872,7 +1873,10 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
         }
     }
     {
+        // Only a tile that goes onto the whole-corridor list has its contender words read (all of them: the settled
+        // pixels' words must say so) - every other tile writes none: 8 B per pixel of HBM traffic less.
         const int any_whole = __syncthreads_or(whole ? 1 : 0);
+        if (any_whole && is_out) contenders[pix] = word;
         if (threadIdx.x == 0 && any_whole)
             worklist_push(whole_list, TR ? (V0 | (tid.x << 16) | 0x40000000u) : ((uint32_t)U0 | (tid.y << 16)));
     }
@@ -1880,7 +1884,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
 
 // ---- kernel B: exact re-evaluation of the contenders (mod.rs:442-464), in corridor order --------------
 __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const uint8_t *__restrict__ img1,
-                                                   const uint8_t *__restrict__ img2, const float2 *__restrict__ stats1,
+                                                   const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
                                                    const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
                                                    const unsigned long long *__restrict__ contenders,
                                                    uint2 *__restrict__ out, unsigned long long *__restrict__ counters,
@@ -1900,7 +1904,7 @@ __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const ui
     uint32_t rg = 0;
     Row12 arow[KERNEL_WIDTH];
     if (mine) {
-        st1v = stats1[(size_t)y * p.w1 + x];
+        st1v = stats_of(stats1[(size_t)y * p.w1 + x]);
         if (!p.first_pass) rg = range[(size_t)y * p.w1 + x];
         const uint8_t *base = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
 #pragma unroll
@@ -2000,7 +2004,7 @@ __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const ui
 
 __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                              const uint8_t *__restrict__ img2,
-                                                             const float2 *__restrict__ stats1,
+                                                             const uint2 *__restrict__ stats1,
                                                              const uint2 *__restrict__ istats2,
                                                              const uint32_t *__restrict__ range,
                                                              const unsigned long long *__restrict__ contenders,
@@ -2018,7 +2022,7 @@ __global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const 
 template <bool COUNT>
 __global__ __launch_bounds__(256, 2) void search3_fallback_kernel(CorrParams p, const uint8_t *__restrict__ img1,
                                                                    const uint8_t *__restrict__ img2,
-                                                                   const float2 *__restrict__ stats1,
+                                                                   const uint2 *__restrict__ stats1,
                                                                    const uint2 *__restrict__ istats1,
                                                                    const uint2 *__restrict__ istats2,
                                                                    const uint32_t *__restrict__ range,
@@ -2032,10 +2036,10 @@ __global__ __launch_bounds__(256, 2) void search3_fallback_kernel(CorrParams p, 
     const uint32_t nd = *declined.count, nw = *whole_list.count;
     for (uint32_t t = blockIdx.x; t < nd; t += gridDim.x) {
         const PixTile tl = tile_of_entry(declined.items[t], p.row0);
-        search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 1, tl,
-                                   WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
+        const bool any_whole = search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out,
+                                                          counters, 1, tl, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
         __syncthreads(); // the tile's LDS is reused by the next one
-        if (!skip_exact) search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, tl);
+        if (!skip_exact && any_whole) search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, tl);
     }
     if (skip_exact) return;
     for (uint32_t t = blockIdx.x; t < nw; t += gridDim.x)
@@ -2057,22 +2061,25 @@ static uint32_t search2_lds_bytes(const CorrParams &p)
 
 constexpr int LIST_GRID = 768; // persistent workgroups of the work-list kernels (an empty list costs their dispatch)
 
-void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+// The candidate filter over every tile; tiles with whole-corridor pixels are queued on whole_list for
+// search3_fallback_kernel (launched behind it with an empty declined list).
+void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s)
+                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList whole_list,
+                           hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
     const uint32_t lds = search2_lds_bytes(p);
     if (counters)
         hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), lds, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters, lds);
+                           range, contenders, out, counters, whole_list, lds);
     else
         hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), lds, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters, lds);
+                           range, contenders, out, counters, whole_list, lds);
 }
 
-void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                              const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                              unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList declined,
                              WorkList whole_list, bool skip_exact, hipStream_t s)
@@ -2087,7 +2094,7 @@ void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uin
                            istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0, lds);
 }
 
-void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                         unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
                         bool transposed, WorkList declined, WorkList whole_list, hipStream_t s)
@@ -2121,7 +2128,7 @@ size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h)
     return along_x > along_y ? along_x : along_y;
 }
 
-void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
                           uint2 *out, unsigned long long *counters, hipStream_t s)
 {

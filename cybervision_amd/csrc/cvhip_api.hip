@@ -65,11 +65,9 @@ static void free_ctx_buffers(cvhip_ctx *c)
             c->dir[d].cells[i] = nullptr;
         }
         if (c->img[d]) (void)hipFree(c->img[d]);
-        if (c->stats[d]) (void)hipFree(c->stats[d]);
         if (c->istats[d]) (void)hipFree(c->istats[d]);
         c->istats[d] = nullptr;
         c->img[d] = nullptr;
-        c->stats[d] = nullptr;
     }
     if (c->range) (void)hipFree(c->range);
     if (c->range_rev) (void)hipFree(c->range_rev);
@@ -160,7 +158,7 @@ static int stage_images(cvhip_ctx *c, const uint8_t *img1, size_t n1, const uint
 }
 
 // One search pass (mod.rs:247-319) given level images already staged in c->img[a] (searched)
-// and c->img[b] (target) with their window statistics in c->stats[a], c->stats[b].
+// and c->img[b] (target) with their window statistics in c->istats[a], c->istats[b].
 static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2,
                        float scale, int k, int first_pass, int dir, bool zero_counts = true, hipStream_t s = nullptr)
 {
@@ -228,10 +226,10 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
     unsigned long long *cnt = c->count_candidates ? c->d_cand : nullptr;
     if (!first_pass)
-        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->stats[a], ds.cells[prev], range, c->range_mode, s); }, s));
+        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->istats[a], ds.cells[prev], range, c->range_mode, s); }, s));
     if (c->search_version == 1) {
         CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-            launch_search(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->stats[b], range, ds.cells[next], cnt, s);
+            launch_search(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[b], range, ds.cells[next], cnt, s);
         }, s));
     } else {
         if (!(p.debug & 2)) {
@@ -252,34 +250,36 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
                 const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
                 v3 = affine_form && f_major > 0.0 && f_minor <= 0.08 * f_major;
             }
+            // the search kernel -> one persistent fallback kernel over the tiles the box filter declined and the tiles
+            // with whole-corridor pixels (work lists filled by the producers)
+            uint32_t *wc = c->work + 4 * dir;
+            uint32_t *items = c->work + 8 + (size_t)dir * 2 * c->work_cap; // per-direction item arrays
+            const WorkList declined{wc, items};
+            const WorkList whole{wc + 1, items + c->work_cap};
+            // both directions' counts are zeroed once per level by cvhip_correlate_level; per-pass callers zero here
+            if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(wc, 0, 4 * sizeof(uint32_t), s));
             if (v3) {
-                // box filter -> one persistent fallback kernel over the tiles it declined and the tiles with
-                // whole-corridor pixels (work lists filled by the producers)
-                uint32_t *wc = c->work + 4 * dir;
-                uint32_t *items = c->work + 8 + (size_t)dir * 2 * c->work_cap; // per-direction item arrays
-                const WorkList declined{wc, items};
-                const WorkList whole{wc + 1, items + c->work_cap};
-                // both directions' counts are zeroed once per level by cvhip_correlate_level; per-pass callers zero here
-                if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(wc, 0, 4 * sizeof(uint32_t), s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     // exactly axis-parallel lines never step: the leaner instantiation
-                    launch_search3_box(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                    launch_search3_box(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b], range,
                                        contenders, ds.cells[next], cnt, f_minor != 0.0 || c->force_box, transposed,
                                        declined, whole, s);
                 }, s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                    launch_search3_fallback(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[a], c->istats[b], range,
+                    launch_search3_fallback(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b], range,
                                             contenders, ds.cells[next], cnt, declined, whole, (p.debug & 1) != 0, s);
                 }, s));
             } else {
+                // candidate filter over every tile; the (rare) tiles with whole-corridor pixels queue themselves for
+                // the fallback kernel, whose declined list stays empty here
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                    launch_search2_filter(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[a], c->istats[b], range,
-                                          contenders, ds.cells[next], cnt, s);
+                    launch_search2_filter(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b], range,
+                                          contenders, ds.cells[next], cnt, whole, s);
                 }, s));
                 if (!(p.debug & 1))
                     CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                        launch_search2_exact(p, c->cur_img[a], c->cur_img[b], c->stats[a], c->istats[b], range, contenders,
-                                             ds.cells[next], cnt, s);
+                        launch_search3_fallback(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b],
+                                                range, contenders, ds.cells[next], cnt, declined, whole, false, s);
                     }, s));
             }
         }
@@ -465,7 +465,6 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         const size_t ge = grid_elems(c->dir[d].gw, c->dir[d].gh);
         for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
-        if (e == hipSuccess) e = hipMalloc(&c->stats[d], c->max_px * sizeof(float2));
         if (e == hipSuccess) e = hipMalloc(&c->istats[d], c->max_px * sizeof(uint2));
     }
     if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
@@ -524,7 +523,7 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
             sr1 = ctx->band[k].st[1];
         }
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->cur_img[1], w2, h2, ctx->stats[1],
+            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->istats[0], ctx->cur_img[1], w2, h2,
                                      ctx->istats[1], sr0, sr1, ctx->min_stdev, nullptr, s);
         }));
     }
@@ -572,7 +571,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         }
         // both images in one launch, which also clears the work-list counts of the level's two search passes
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->stats[0], ctx->istats[0], ctx->cur_img[1], w2, h2, ctx->stats[1],
+            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->istats[0], ctx->cur_img[1], w2, h2,
                                      ctx->istats[1], sr0, sr1, ctx->min_stdev, ctx->work, s);
         }));
     }

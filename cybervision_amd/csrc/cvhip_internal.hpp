@@ -73,27 +73,28 @@ struct WorkList {
     uint32_t *count;
     uint32_t *items;
 };
-void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, float2 *stats_a, uint2 *istats_a,
-                              const uint8_t *img_b, uint32_t wb, uint32_t hb, float2 *stats_b, uint2 *istats_b,
+void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, uint2 *istats_a,
+                              const uint8_t *img_b, uint32_t wb, uint32_t hb, uint2 *istats_b,
                               uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s);
-void launch_search_range(const CorrParams &p, const float2 *stats1, const uint2 *prev, uint32_t *range, int mode,
+void launch_search_range(const CorrParams &p, const uint2 *stats1, const uint2 *prev, uint32_t *range, int mode,
                          hipStream_t s);
-void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
-                   const float2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
+void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
+                   const uint2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
                    hipStream_t s);
-void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                            const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, hipStream_t s);
-void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList whole_list,
+                           hipStream_t s);
+void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                              const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                              unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList declined,
                              WorkList whole_list, bool skip_exact, hipStream_t s);
-void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                         const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
                         unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
                         bool transposed, WorkList declined, WorkList whole_list, hipStream_t s);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
-void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const float2 *stats1,
+void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                           const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
                           uint2 *out, unsigned long long *counters, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
@@ -173,7 +174,7 @@ struct cvhip_ctx {
     uint8_t *img[2] = {nullptr, nullptr}; // level image staging (padded), [0]=searched [1]=target of the call
     const uint8_t *cur_img[2] = {nullptr, nullptr}; // the images the current call works on: img[] or the caller's own
     bool borrow_inputs = false;                     // cvhip_ctx_set_borrow_inputs
-    float2 *stats[2] = {nullptr, nullptr};
+    // per level pixel {window sum | VALID << 31, f32 bits of stdev}: avg = sum / 121 is derived where it is needed
     uint2 *istats[2] = {nullptr, nullptr};
     // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,
     // 3 = displacement-plane box filter (falls back to 2 per workgroup) + exact re-evaluation

@@ -302,28 +302,81 @@ __device__ __forceinline__ double reprojection_error(const double (&F)[9], doubl
     return nominator / denominator;
 }
 
+struct RansacBest {
+    double f[9];
+    double best_error;
+    uint32_t matches_count;
+    uint32_t valid;
+};
+
+// The fold of validate_f (:210-216) for a batch of hypotheses, one lane per hypothesis.
+//  * live / n_live (optional): the hypotheses to score are F[live[0 .. *n_live)] - the generators leave most slots
+//    empty (no real root, a failed rank / sign / sample-fit check), and an empty slot must not cost N error
+//    evaluations.  Slots that are not listed keep whatever out_count holds (the caller zeroes it).
+//  * bound / best (optional): a hypothesis whose count can no longer reach `min_count`, or the inlier count of the
+//    best hypothesis of the PREVIOUS rounds, cannot become the result (Ord, :623-649: more matches always win), so it
+//    is abandoned at the next tile boundary and reported with count 0 - the winner and every hypothesis that could
+//    still beat or tie it are folded completely, so the result is the reference's.
+//  * matches are converted to f64 once per tile (LDS), and the division of reprojection_error is only executed where
+//    the inlier test is open: n^2 > t * den * (1 + 2^-40) implies n^2 / den > t in f64 whatever the roundings, so
+//    such a match is an outlier without dividing (non-finite cases fall through to the exact expression).
 __global__ __launch_bounds__(64) void ransac_score_kernel(const double *__restrict__ F, uint32_t H,
                                                            const uint4 *__restrict__ matches, uint32_t N, double t,
+                                                           const uint32_t *__restrict__ live,
+                                                           const uint32_t *__restrict__ n_live, uint32_t min_count,
+                                                           const RansacBest *__restrict__ best,
                                                            uint32_t *__restrict__ out_count,
                                                            double *__restrict__ out_err_sum)
 {
-    __shared__ uint4 tile[RANSAC_TILE];
-    const uint32_t h = blockIdx.x * 64 + threadIdx.x;
-    const bool active = h < H;
+    __shared__ double tile[RANSAC_TILE][4];
+    const uint32_t n_hyp = n_live ? *n_live : H;
+    if (blockIdx.x * 64u >= n_hyp) return;
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    const bool active = j < n_hyp;
+    const uint32_t h = active ? (live ? live[j] : j) : 0u;
     double f[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) f[i] = active ? F[(size_t)h * 9 + i] : 0.0;
+    uint32_t bound = 0;
+    if (best) bound = best->valid ? max(min_count, best->matches_count) : min_count;
+    const double t_hi = t * (1.0 + 0x1p-40);
     uint32_t count = 0;
     double sum = 0.0;
+    bool alive = active;
     for (uint32_t base = 0; base < N; base += RANSAC_TILE) {
         const uint32_t n = min((uint32_t)RANSAC_TILE, N - base);
+        // count + (matches not yet seen) < bound: this hypothesis is out
+        alive = alive && !(count + (N - base) < bound);
+        if (!__any(alive)) break;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += 64) tile[i] = matches[base + i];
+        for (uint32_t i = threadIdx.x; i < n; i += 64) {
+            const uint4 m = matches[base + i];
+            tile[i][0] = (double)m.x;
+            tile[i][1] = (double)m.y;
+            tile[i][2] = (double)m.z;
+            tile[i][3] = (double)m.w;
+        }
         __syncthreads();
-        if (active) {
+        if (alive) {
             for (uint32_t i = 0; i < n; i++) {
-                const uint4 m = tile[i];
-                const double err = reprojection_error(f, (double)m.x, (double)m.y, (double)m.z, (double)m.w);
+                const double p1x = tile[i][0], p1y = tile[i][1], p2x = tile[i][2], p2y = tile[i][3];
+                // reprojection_error (:461-471) in nalgebra's evaluation order, as in reprojection_error() above
+                const double r0 = (p2x * f[0] + p2y * f[3]) + f[6];
+                const double r1 = (p2x * f[1] + p2y * f[4]) + f[7];
+                const double r2 = (p2x * f[2] + p2y * f[5]) + f[8];
+                double nn = r0 * p1x;
+                nn = r1 * p1y + nn;
+                nn = r2 + nn;
+                double a0 = f[0] * p1x;
+                a0 = f[1] * p1y + a0;
+                a0 = f[2] + a0;
+                double a1 = f[3] * p1x;
+                a1 = f[4] * p1y + a1;
+                a1 = f[5] + a1;
+                const double nominator = nn * nn;
+                const double denominator = a0 * a0 + a1 * a1 + r0 * r0 + r1 * r1; // (F' p2)_i == (p2' F)_i
+                if (nominator > t_hi * denominator) continue; // certainly err > t: an outlier, no division needed
+                const double err = nominator / denominator;
                 // fits_model: finite and |err| <= t (fundamentalmatrix.rs:452-458)
                 if (fabs(err) < __builtin_inf() && !(fabs(err) > t)) {
                     count += 1;
@@ -333,9 +386,39 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(const double *__restri
         }
     }
     if (active) {
-        out_count[h] = count;
-        out_err_sum[h] = sum;
+        out_count[h] = alive ? count : 0u;
+        out_err_sum[h] = alive ? sum : 0.0;
     }
+}
+
+// ordered compaction of the live hypothesis slots (F[9 * h] is not NaN): live[0 .. *n_live) ascending; one workgroup
+__global__ __launch_bounds__(1024) void ransac_compact_kernel(const double *__restrict__ F, uint32_t H,
+                                                               uint32_t *__restrict__ live, uint32_t *__restrict__ n_live)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < H; base += 1024) {
+        const uint32_t h = base + threadIdx.x;
+        const double f0 = h < H ? F[(size_t)h * 9] : __builtin_nan("");
+        const bool is_live = f0 == f0;
+        const unsigned long long b = __ballot(is_live);
+        if (lane == 0) wtot[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (uint32_t w = 0; w < wv; w++) off += wtot[w];
+        if (is_live) live[off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = h;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 16; w++) tot += wtot[w];
+            carry_s += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_live = carry_s;
 }
 
 void launch_ransac_score(const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
@@ -343,9 +426,21 @@ void launch_ransac_score(const double *F, uint32_t H, const uint32_t *matches, u
 {
     if (!H) return;
     hipLaunchKernelGGL(ransac_score_kernel, dim3((H + 63) / 64), dim3(64), 0, s, F, H,
-                       reinterpret_cast<const uint4 *>(matches), N, t, out_count, out_err_sum);
+                       reinterpret_cast<const uint4 *>(matches), N, t, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u,
+                       (const RansacBest *)nullptr, out_count, out_err_sum);
 }
 
+// one RANSAC round's scoring: only the live slots, abandoning what cannot reach the best of the previous rounds
+static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
+                                      uint32_t *live, uint32_t *n_live, uint32_t min_count, const RansacBest *best,
+                                      uint32_t *out_count, double *out_err_sum, hipStream_t s)
+{
+    (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(ransac_compact_kernel, dim3(1), dim3(1024), 0, s, F, H, live, n_live);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3((H + 63) / 64), dim3(64), 0, s, F, H,
+                       reinterpret_cast<const uint4 *>(matches), N, t, (const uint32_t *)live, (const uint32_t *)n_live, min_count,
+                       best, out_count, out_err_sum);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Whole affine RANSAC on the device: hypothesis generation moves next
@@ -751,13 +846,6 @@ __global__ __launch_bounds__(64) void ransac_generate_perspective_kernel(const u
         for (int i = 0; i < 9; i++) F[((size_t)h * 3 + k) * 9 + i] = ok[k] ? f[k][i] : nan;
 }
 
-struct RansacBest {
-    double f[9];
-    double best_error;
-    uint32_t matches_count;
-    uint32_t valid;
-};
-
 // Ord for RansacIterationResult (fundamentalmatrix.rs:623-649)
 __device__ __forceinline__ bool ransac_better(uint32_t ca, double ea, uint32_t cb, double eb)
 {
@@ -909,6 +997,8 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     if (e == hipSuccess) e = hipMalloc(&d_err, (size_t)CHECK_INTERVAL * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&d_best, sizeof(RansacBest));
     if (e == hipSuccess) e = hipMalloc(&d_mask, N);
+    uint32_t *d_live = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)CHECK_INTERVAL + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     RansacBest h_best;
@@ -918,7 +1008,8 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
         hipLaunchKernelGGL(ransac_generate_affine_kernel, dim3((CHECK_INTERVAL + 63) / 64), dim3(64), 0, s, m4,
                            std::min(N, TOP_INLIERS), RANSAC_T, (unsigned long long)seed, round, CHECK_INTERVAL,
                            (const uint32_t *)nullptr, d_F);
-        launch_ransac_score(d_F, CHECK_INTERVAL, d_m, N, RANSAC_T, d_cnt, d_err, s);
+        launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL, RANSAC_D + RANSAC_N, d_best,
+                                  d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, CHECK_INTERVAL,
                            RANSAC_D + RANSAC_N, d_best);
         e = hipGetLastError();
@@ -949,6 +1040,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     (void)hipFree(d_err);
     (void)hipFree(d_best);
     (void)hipFree(d_mask);
+    (void)hipFree(d_live);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("ransac_affine: ") + hipGetErrorString(e));
     return rc;
 }
@@ -972,6 +1064,8 @@ int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32
     if (e == hipSuccess) e = hipMalloc(&d_err, (size_t)H * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&d_best, sizeof(RansacBest));
     if (e == hipSuccess) e = hipMalloc(&d_mask, N);
+    uint32_t *d_live = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)H + 1) * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
@@ -980,7 +1074,7 @@ int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
     for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
         generate(m4, round, d_F, s);
-        launch_ransac_score(d_F, H, d_m, N, t, d_cnt, d_err, s);
+        launch_ransac_score_round(d_F, H, d_m, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, H, min_count, d_best);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
@@ -1009,6 +1103,7 @@ int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32
     (void)hipFree(d_err);
     (void)hipFree(d_best);
     (void)hipFree(d_mask);
+    (void)hipFree(d_live);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
     return rc;
 }
