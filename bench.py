@@ -41,28 +41,58 @@ SEARCH_KERNEL = "search3_box_kernel"   # the kernel class "search" times (search
 
 
 def algorithmic_work(level_dims, candidates):
-    """Algorithmic bytes / multiply-adds of ALL search-kernel launches of one step
-    (DESIGN.md §4).  Per (level, direction) pass, each array touched once: searched pixel = img1 u8 (1)
-    + stats1 (8) + istats1 (8) + range (4) + contender word written (8) + result cell written (8) = 37 B;
-    target pixel = img2 u8 (1) + istats2 (8) = 9 B.  Multiply-adds: 121 per evaluated candidate (the
-    11x11 integer dot)."""
+    """Algorithmic bytes / multiply-adds of ALL search-kernel launches of one step.  Per (level,
+    direction) pass, each array touched once: searched pixel = img1 u8 (1) + statistics word (8) + search interval (4)
+    + result cell written (8) = 21 B; target pixel = img2 u8 (1) + statistics word (8) = 9 B -> 30 B per level pixel.
+    Multiply-adds: 121 per evaluated candidate (the reference's 11x11 window)."""
     b = 0
     for (w1, h1, w2, h2) in level_dims:
         n1, n2 = w1 * h1, w2 * h2
-        b += n1 * 37 + n2 * 9   # forward
-        b += n2 * 37 + n1 * 9   # reverse
+        b += n1 * 21 + n2 * 9   # forward
+        b += n2 * 21 + n1 * 9   # reverse
     return b, 121.0 * candidates
+
+
+def survey_bytes(level_dims):
+    """~40 B per level pixel per direction for the WHOLE step (every kernel), each array once."""
+    return sum(40 * (w1 * h1 + w2 * h2) for (w1, h1, w2, h2) in level_dims)
+
+
+def _profile_json(name):
+    f = ROOT / "profiles" / name
+    return json.loads(f.read_text()) if f.exists() else None
 
 
 def traffic_per_launch(world):
     """HBM bytes per search-kernel launch from the rocprofv3 PMC passes of this same command
     (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied: scripts/collect_traffic.py);
     committed under profiles/.  None when no PMC data matches this configuration."""
-    f = ROOT / "profiles" / "current_traffic.json"
-    if world != 1 or not f.exists():
+    d = _profile_json("current_traffic.json")
+    if world != 1 or not d:
         return None
-    k = json.loads(f.read_text())["kernels"].get(SEARCH_KERNEL)
+    k = d["kernels"].get(SEARCH_KERNEL)
     return round(k["hbm_bytes_per_step"] / k["launches_per_step"]) if k else None
+
+
+def step_traffic(world):
+    """Measured HBM bytes of ALL kernels of one step (same PMC passes)."""
+    d = _profile_json("current_traffic.json")
+    if world != 1 or not d:
+        return None
+    return round(sum(v["hbm_bytes_per_step"] for n, v in d["kernels"].items() if "kernel" in n and "::" not in n and not n.startswith("__")))
+
+
+def valu_profile(world):
+    """VALU instruction counts of the search kernel from the SQ PMC pass of this same command
+    (scripts/collect_pmc.py -> profiles/current_pmc.json): wave-instructions per step, and for the full-resolution
+    launch the pipe-busy fraction SQ_ACTIVE_INST_VALU * 4 / SIMDs / (GRBM_GUI_ACTIVE / XCDs)."""
+    d = _profile_json("current_pmc.json")
+    if world != 1 or not d or SEARCH_KERNEL not in d["kernels"]:
+        return None
+    k = d["kernels"][SEARCH_KERNEL]
+    big = k.get("largest_launch", {})
+    return {"wave_instr_per_step": k.get("SQ_INSTS_VALU"), "valu_busy": big.get("valu_busy"),
+            "cycles_per_valu_instr": big.get("cycles_per_valu_instr")}
 
 
 def bench_sfm3(args):
@@ -324,6 +354,38 @@ def main():
         # per-rank share of the algorithmic work when sharded
         ach_gbs = bytes_alg / world / (search_ms_per_step / 1e3) / 1e9
         ach_tmacs = macs_alg / world / (search_ms_per_step / 1e3) / 1e12
+        # The dominant kernel is bound by VALU instruction issue, not by HBM and not by the matrix pipe (DESIGN.md
+        # section 6): `achieved` is the rate of VALU lane-operations it executes (wave-instructions of the PMC pass of
+        # this same command x 64 lanes / the launch time measured live with HIP events), `peak` one operation per lane
+        # per clock on 1024 SIMD-32 units at 2.4 GHz.  dot4 and DPP instructions hold the pipe for 4 cycles instead of
+        # 2, so the pipes are full (`valu_busy`, from SQ_ACTIVE_INST_VALU) well below that peak; the efficiency figure
+        # of the algorithm is `valu_lane_instr_per_candidate` (the reference spends 363 flops per candidate).
+        vp = valu_profile(world)
+        valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12
+        if vp and vp["wave_instr_per_step"]:
+            lane_ops = vp["wave_instr_per_step"] * 64.0 / world
+            ach_valu = lane_ops / (search_ms_per_step / 1e3) / 1e12
+            roofline = {"kernel": SEARCH_KERNEL, "bound": "valu", "achieved": round(ach_valu, 2), "peak": round(valu_peak, 1),
+                        "unit": "T lane-ops/s (VALU instructions x 64)", "frac": round(ach_valu / valu_peak, 4),
+                        "valu_busy": vp["valu_busy"], "cycles_per_valu_instr": vp["cycles_per_valu_instr"],
+                        "valu_lane_instr_per_candidate": round(vp["wave_instr_per_step"] * 64.0 / max(candidates, 1), 1)}
+        else:  # no PMC data for this configuration: only the HBM figures below are measured
+            roofline = {"kernel": SEARCH_KERNEL, "bound": "valu", "achieved": None, "peak": round(valu_peak, 1),
+                        "unit": "T lane-ops/s (VALU instructions x 64)", "frac": None}
+        roofline.update({
+            "traffic": traffic_per_launch(world),
+            "launches_per_step": launches_per_step,
+            "avg_launch_ms": round(search_ms_per_step / max(launches_per_step, 1), 4),
+            # secondary: the HBM side of the same kernel (compute-bound by construction: ~30 B per ~72 candidates)
+            "hbm": {"achieved": round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
+                    "algorithmic_bytes_per_step": bytes_alg,
+                    "whole_step": {"survey_8d_bytes": survey_bytes(level_dims), "measured_bytes": step_traffic(world),
+                                   "achieved_gbs_on_survey_bytes": round(survey_bytes(level_dims) / (ms_per_step / 1e3) / 1e9, 1)}},
+            # useful work: the reference-equivalent 121 multiply-adds per candidate against the dot4 issue roof - a rate
+            # of useful work, NOT a utilisation (the box filter issues ~14 multiply-adds per candidate)
+            "useful_work": {"achieved": round(ach_tmacs, 3), "peak": round(DOT4_PEAK_TMACS, 1), "unit": "T reference-equivalent multiply-adds/s",
+                            "ratio": round(ach_tmacs / DOT4_PEAK_TMACS, 4), "algorithmic_macs_per_step": macs_alg},
+        })
         result = {
             "metric": "Mpixels/s dense correlation, 4096x4096 pair" if W == 4096 else f"Mpixels/s dense correlation, {W}x{H} pair",
             "value": round(value, 3),
@@ -346,25 +408,7 @@ def main():
                                         if band_mode else f"row-sharded x{world}, RCCL all-gather per sharded pass"))
                                       + (f" [EMULATION of shard {sim[0]}/{sim[1]} on one GPU, no collective]" if sim else ""),
                        "candidates_per_step": candidates},
-            "roofline": {
-                "kernel": SEARCH_KERNEL,
-                "bound": "hbm",
-                "achieved": round(ach_gbs, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(ach_gbs / HBM_PEAK_GBS, 5),
-                "traffic": traffic_per_launch(world),
-                "launches_per_step": launches_per_step,
-                "avg_launch_ms": round(search_ms_per_step / max(launches_per_step, 1), 4),
-                "algorithmic_bytes_per_step": bytes_alg,
-                "note": "the search is compute-bound by construction (the reference spends 121 multiply-adds per "
-                        "candidate on ~0.5 B of compulsory traffic); `compute` prices the reference-equivalent "
-                        "multiply-adds against the v_dot4_u32_u8 issue roof - the box filter itself needs ~14 per "
-                        "candidate plus a wave prefix sum, so this is a rate of useful work, not of issued dot4",
-                "compute": {"bound": "valu_dot4_u8", "achieved": round(ach_tmacs, 3),  # reference-equivalent MACs
-                            "peak": round(DOT4_PEAK_TMACS, 1), "unit": "T multiply-adds/s",
-                            "frac": round(ach_tmacs / DOT4_PEAK_TMACS, 4), "algorithmic_macs_per_step": macs_alg},
-            },
+            "roofline": roofline,
             # every kernel class, from one extra fully instrumented step after the timed region
             "kernel_ms_per_step": {k: round(v["ms"], 4) for k, v in ktimes.items()},
             # the full-resolution level alone (non-first pass: the dominant level), this rank's share of the rows

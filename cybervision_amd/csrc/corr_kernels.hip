@@ -1339,11 +1339,19 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, co
 constexpr int S3_LANE0 = 11;
 constexpr int S3_OUT = S3_OUT_PX;
 constexpr int S3_COLS = 128;  // staged columns per copy / per statistics row
-constexpr int S3_MAXH = 9;    // dy planes: 20 staged rows = 9 + 10 window rows (+1)
-constexpr int S3_B16_OFF = 0;                             // [4][128] uint4: rows 0..15 of the copy
-constexpr int S3_B4_OFF = 4 * S3_COLS * 16;               // [4][128] u32:   rows 16..19
-constexpr int S3_IS_OFF = S3_B4_OFF + 4 * S3_COLS * 4;    // [12][128] uint2: candidate statistics
-constexpr int S3_LDS_BYTES = S3_IS_OFF + (S3_MAXH + 3) * S3_COLS * 8;
+// LDS plan.  The lean (rectified) instantiation walks at most 9 dy planes: 20 staged rows = 9 + 10 window rows (+1),
+// 5 dwords per line and copy.  The stepped instantiations - tilted affine lines, and perspective pairs whose 9
+// stripes leave the 9-plane plan no slack for the rows the lines cross inside a box - get 13 planes: 24 staged
+// rows, 6 dwords, 28 KB instead of 22.5 (5 workgroups per CU, which is their launch bound anyway).
+template <bool STEP> struct S3Plan {
+    static constexpr int MAXH = STEP ? 13 : 9;                       // dy planes
+    static constexpr int NDW = STEP ? 6 : 5;                         // staged dwords per line and copy
+    static constexpr int TAIL_BYTES = (NDW - 4) * 4;                 // per line: the dwords after the first four
+    static constexpr int B16_OFF = 0;                                // [4][128] uint4: rows 0..15 of the copy
+    static constexpr int TAIL_OFF = 4 * S3_COLS * 16;                // [4][128] u32 / uint2: rows 16..19 / 16..23
+    static constexpr int IS_OFF = TAIL_OFF + 4 * S3_COLS * TAIL_BYTES; // [MAXH + 3][128] uint2: candidate statistics
+    static constexpr int LDS_BYTES = IS_OFF + (MAXH + 3) * S3_COLS * 8;
+};
 
 __device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t v)
 {
@@ -1405,7 +1413,10 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
                                                            unsigned long long *__restrict__ counters,
                                                            WorkList declined, WorkList whole_list)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[S3_LDS_BYTES];
+    using Plan = S3Plan<STEP>;
+    constexpr int S3_MAXH = Plan::MAXH, NDW = Plan::NDW, S3_B16_OFF = Plan::B16_OFF, S3_TAIL_OFF = Plan::TAIL_OFF,
+                  S3_IS_OFF = Plan::IS_OFF, TAIL_BYTES = Plan::TAIL_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[Plan::LDS_BYTES];
     __shared__ int bb[6]; // min dx, min dy, max dx, max dy, max candidates of one pixel, 1 = some pixel is not a rectangle
 
     const uint32_t lane = threadIdx.x & 63;
@@ -1558,7 +1569,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
         }
         return;
     }
-    const int NPL = H > 5 ? S3_MAXH : 5; // planes computed (group A: 0..4, group B: 5..8)
+    const int NPL = H > 9 ? S3_MAXH : (H > 5 ? 9 : 5); // planes staged (lean: group A = 0..4, group B = 5..8)
     if (p.debug & 256) return; // profiling: per-pixel setup and box reduction only
 
     // ---- stage the target copies (20 bytes along v per line and copy) and the candidate statistics -------------
@@ -1567,10 +1578,10 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
         if (!TR) {
             // lines are columns: the bytes along v are a column of the image, gathered by 4x4 byte transposes
             const int nb = (ncol + 3) >> 2;
-            const int units = 4 * 5 * nb;
+            const int units = 4 * NDW * nb;
             for (int u = (int)threadIdx.x; u < units; u += 256) {
-                const int wk = u / nb, b = u - wk * nb; // wk = copy * 5 + k
-                const int cw = wk / 5, k = wk - cw * 5;
+                const int wk = u / nb, b = u - wk * nb; // wk = copy * NDW + k
+                const int cw = wk / NDW, k = wk - cw * NDW;
                 const int rr = R0 + cw + 4 * k, col = C0a + 4 * b;
                 const uint32_t d0 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 0, col);
                 const uint32_t d1 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 1, col);
@@ -1587,21 +1598,27 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
                     dst[4] = t.y;
                     dst[8] = t.z;
                     dst[12] = t.w;
+                } else if (NDW == 5) {
+                    *reinterpret_cast<uint4 *>(lds + S3_TAIL_OFF + (size_t)(cw * S3_COLS + 4 * b) * 4u) = t;
                 } else {
-                    *reinterpret_cast<uint4 *>(lds + S3_B4_OFF + (size_t)(cw * S3_COLS + 4 * b) * 4u) = t;
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(lds + S3_TAIL_OFF + (size_t)(cw * S3_COLS + 4 * b) * TAIL_BYTES) + (k - 4);
+                    dst[0] = t.x;
+                    dst[TAIL_BYTES / 4] = t.y;
+                    dst[2 * (TAIL_BYTES / 4)] = t.z;
+                    dst[3 * (TAIL_BYTES / 4)] = t.w;
                 }
             }
         } else {
             // lines are rows: the bytes along v are contiguous in the image
-            const int units = 4 * 5 * ncol;
+            const int units = 4 * NDW * ncol;
             for (int u = (int)threadIdx.x; u < units; u += 256) {
-                const int wk = u / ncol, c = u - wk * ncol; // wk = copy * 5 + k
-                const int cw = wk / 5, k = wk - cw * 5;
+                const int wk = u / ncol, c = u - wk * ncol; // wk = copy * NDW + k
+                const int cw = wk / NDW, k = wk - cw * NDW;
                 const uint32_t d = load_dword_checked(img2, (int)p.w2, (int)p.h2, C0a + c, R0 + cw + 4 * k);
                 if (k < 4)
                     *(reinterpret_cast<uint32_t *>(lds + S3_B16_OFF + (size_t)(cw * S3_COLS + c) * 16u) + k) = d;
                 else
-                    *reinterpret_cast<uint32_t *>(lds + S3_B4_OFF + (size_t)(cw * S3_COLS + c) * 4u) = d;
+                    *(reinterpret_cast<uint32_t *>(lds + S3_TAIL_OFF + (size_t)(cw * S3_COLS + c) * TAIL_BYTES) + (k - 4)) = d;
             }
         }
         const int isp = 64 + W - 1, isrows = NPL + 3;
@@ -1683,7 +1700,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
     if (wave_has && !(p.debug & 8)) {
         const uint32_t col0 = lane + (uint32_t)colshift + (uint32_t)(mnx - dx0);
         const uint8_t *const bB16 = lds + S3_B16_OFF + (w * S3_COLS + col0) * 16u;
-        const uint8_t *const bB4 = lds + S3_B4_OFF + (w * S3_COLS + col0) * 4u;
+        const uint8_t *const bB4 = lds + S3_TAIL_OFF + (w * S3_COLS + col0) * (uint32_t)TAIL_BYTES;
         const uint8_t *const bIS = lds + S3_IS_OFF + (w * S3_COLS + lane + (uint32_t)(mnx - dx0)) * 8u;
         const int idx_lo = (int)(lane >= 11u ? lane - 11u : 0u) * 4;
         const int nsteps = mxx - mnx + 1;
@@ -1695,7 +1712,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
         const int mid = nsteps >> 1;
         for (int t = 0; t < nsteps; t++) {
             const int step = t < nsteps - mid ? mid + t : nsteps - 1 - t;
-            const uint8_t *pB16 = bB16 + step * 16, *pB4 = bB4 + step * 4, *pIS = bIS + step * 8;
+            const uint8_t *pB16 = bB16 + step * 16, *pB4 = bB4 + step * TAIL_BYTES, *pIS = bIS + step * 8;
             const int dx = mnx + step; // displacement along the lanes (x; y when TR)
             const bool mx = has && (uint32_t)(dx - lou) < wu;
             // first plane offset of this lane's candidates at this step, and the planes the wave needs for it
@@ -1711,7 +1728,18 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
                 n = hi - lo + 1;
             }
             const uint4 r4 = *reinterpret_cast<const uint4 *>(pB16);
-            uint32_t raw[5] = {r4.x, r4.y, r4.z, r4.w, *reinterpret_cast<const uint32_t *>(pB4)};
+            uint32_t raw[NDW];
+            raw[0] = r4.x;
+            raw[1] = r4.y;
+            raw[2] = r4.z;
+            raw[3] = r4.w;
+            if (NDW == 5) {
+                raw[4] = *reinterpret_cast<const uint32_t *>(pB4);
+            } else {
+                const uint2 r2 = *reinterpret_cast<const uint2 *>(pB4);
+                raw[4] = r2.x;
+                raw[NDW - 1] = r2.y;
+            }
             // one group of planes: s = S0 .. S0 + N - 1 (dy = dy0 + s), all independent until the rare branch
             auto group = [&](auto s0_tag, auto n_tag) {
                 constexpr int S0 = decltype(s0_tag)::value, N = decltype(n_tag)::value;
@@ -1724,7 +1752,7 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
                     uint32_t c = __builtin_amdgcn_udot4(a[sh][0], raw[o], 0u, false);
                     c = __builtin_amdgcn_udot4(a[sh][1], raw[o + 1], c, false);
                     c = __builtin_amdgcn_udot4(a[sh][2], raw[o + 2], c, false);
-                    if (sh >= 2) c = __builtin_amdgcn_udot4(a[sh][3], raw[o + 3 < 5 ? o + 3 : 4], c, false);
+                    if (sh >= 2) c = __builtin_amdgcn_udot4(a[sh][3], raw[o + 3 < NDW ? o + 3 : NDW - 1], c, false);
                     const uint32_t pre = wave_prefix_sum(c);
                     const uint32_t s12 = pre - (uint32_t)__builtin_amdgcn_ds_bpermute(idx_lo, (int)pre);
                     num[q] = __mul24((int)s12, KERNEL_POINT_COUNT) + __mul24((int)s1, (int)is2.x);
@@ -1772,20 +1800,51 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
                 if (NPL > 5) group(I5{}, std::integral_constant<int, 4>{});
                 continue;
             }
-            const int start = min(s0, NPL - 5);
-            switch (start) {
-            case 0: group(I0{}, I5{}); break;
-            case 1: group(I1{}, I5{}); break;
-            case 2: group(I2{}, I5{}); break;
-            case 3: group(I3{}, I5{}); break;
-            default: group(I4{}, I5{}); break;
-            }
-            for (int sx = start + 5; sx < s0 + n; sx++) {
-                switch (sx) {
-                case 5: group(I5{}, I1{}); break;
-                case 6: group(std::integral_constant<int, 6>{}, I1{}); break;
-                case 7: group(std::integral_constant<int, 7>{}, I1{}); break;
-                default: group(std::integral_constant<int, 8>{}, I1{}); break;
+            if constexpr (STEP) {
+                using I6 = std::integral_constant<int, 6>;
+                using I7 = std::integral_constant<int, 7>;
+                using I8 = std::integral_constant<int, 8>;
+                using I9 = std::integral_constant<int, 9>;
+                using I10 = std::integral_constant<int, 10>;
+                using I11 = std::integral_constant<int, 11>;
+                using I12 = std::integral_constant<int, 12>;
+                const int start = min(s0, NPL - 5);
+                switch (start) {
+                case 0: group(I0{}, I5{}); break;
+                case 1: group(I1{}, I5{}); break;
+                case 2: group(I2{}, I5{}); break;
+                case 3: group(I3{}, I5{}); break;
+                case 4: group(I4{}, I5{}); break;
+                case 5: group(I5{}, I5{}); break;
+                case 6: group(I6{}, I5{}); break;
+                case 7: group(I7{}, I5{}); break;
+                default: group(I8{}, I5{}); break;
+                }
+                // the planes beyond the first five: one more interleaved group where there are three or more of them
+                // (nine stripes), else singly (five stripes whose line steps once inside the box)
+                const int rest0 = start + 5, rem = s0 + n - rest0;
+                if (rem >= 3) {
+                    switch (rest0) {
+                    case 5: group(I5{}, I5{}); break;
+                    case 6: group(I6{}, I5{}); break;
+                    case 7: group(I7{}, I5{}); break;
+                    case 8: group(I8{}, I5{}); break;
+                    case 9: group(I9{}, I4{}); break;
+                    default: group(I10{}, I3{}); break;
+                    }
+                } else {
+                    for (int sx = rest0; sx < s0 + n; sx++) {
+                        switch (sx) {
+                        case 5: group(I5{}, I1{}); break;
+                        case 6: group(I6{}, I1{}); break;
+                        case 7: group(I7{}, I1{}); break;
+                        case 8: group(I8{}, I1{}); break;
+                        case 9: group(I9{}, I1{}); break;
+                        case 10: group(I10{}, I1{}); break;
+                        case 11: group(I11{}, I1{}); break;
+                        default: group(I12{}, I1{}); break;
+                        }
+                    }
                 }
             }
         }

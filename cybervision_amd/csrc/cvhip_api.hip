@@ -57,24 +57,70 @@ static int set_device(const cvhip_device *dev)
     return CVHIP_OK;
 }
 
-static void free_ctx_buffers(cvhip_ctx *c)
+static void free_buffer_set(CtxBuffers &b)
 {
     for (int d = 0; d < 2; d++) {
+        for (int i = 0; i < 2; i++)
+            if (b.cells[d][i]) (void)hipFree(b.cells[d][i]);
+        if (b.img[d]) (void)hipFree(b.img[d]);
+        if (b.istats[d]) (void)hipFree(b.istats[d]);
+    }
+    if (b.range) (void)hipFree(b.range);
+    if (b.range_rev) (void)hipFree(b.range_rev);
+    if (b.contenders) (void)hipFree(b.contenders);
+    if (b.contenders_rev) (void)hipFree(b.contenders_rev);
+    if (b.work) (void)hipFree(b.work);
+    if (b.d_cand) (void)hipFree(b.d_cand);
+    b = CtxBuffers{};
+}
+
+// Detach the context's device buffers: parked on the device handle when `park` (and they are complete), freed otherwise.
+static void release_ctx_buffers(cvhip_ctx *c, bool park)
+{
+    CtxBuffers b;
+    b.w1 = c->w1;
+    b.h1 = c->h1;
+    b.w2 = c->w2;
+    b.h2 = c->h2;
+    bool complete = true;
+    for (int d = 0; d < 2; d++) {
         for (int i = 0; i < 2; i++) {
-            if (c->dir[d].cells[i]) (void)hipFree(c->dir[d].cells[i]);
+            b.cells[d][i] = c->dir[d].cells[i];
+            complete = complete && b.cells[d][i];
             c->dir[d].cells[i] = nullptr;
         }
-        if (c->img[d]) (void)hipFree(c->img[d]);
-        if (c->istats[d]) (void)hipFree(c->istats[d]);
-        c->istats[d] = nullptr;
+        b.img[d] = c->img[d];
+        b.istats[d] = c->istats[d];
+        complete = complete && b.img[d] && b.istats[d];
         c->img[d] = nullptr;
+        c->istats[d] = nullptr;
     }
-    if (c->range) (void)hipFree(c->range);
-    if (c->range_rev) (void)hipFree(c->range_rev);
-    if (c->contenders) (void)hipFree(c->contenders);
-    if (c->contenders_rev) (void)hipFree(c->contenders_rev);
+    b.range = c->range;
+    b.range_rev = c->range_rev;
+    b.contenders = c->contenders;
+    b.contenders_rev = c->contenders_rev;
+    b.work = c->work;
+    b.d_cand = c->d_cand;
+    complete = complete && b.range && b.range_rev && b.contenders && b.contenders_rev && b.work && b.d_cand;
+    c->range = c->range_rev = nullptr;
     c->contenders = c->contenders_rev = nullptr;
-    c->range_rev = nullptr;
+    c->work = nullptr;
+    c->d_cand = nullptr;
+    if (park && complete) {
+        auto &parked = c->dev->d.parked;
+        parked.push_back(b);
+        while (parked.size() > PARK_LIMIT) {
+            free_buffer_set(parked.front());
+            parked.erase(parked.begin());
+        }
+    } else {
+        free_buffer_set(b);
+    }
+}
+
+static void free_ctx_buffers(cvhip_ctx *c, bool park = false)
+{
+    release_ctx_buffers(c, park);
     if (c->aux_stream) {
         (void)hipStreamSynchronize(c->aux_stream);
         (void)hipStreamDestroy(c->aux_stream);
@@ -83,11 +129,6 @@ static void free_ctx_buffers(cvhip_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     c->ev_fork = c->ev_join = nullptr;
-    if (c->work) (void)hipFree(c->work);
-    c->work = nullptr;
-    if (c->d_cand) (void)hipFree(c->d_cand);
-    c->range = nullptr;
-    c->d_cand = nullptr;
     for (auto &ev : c->events) {
         (void)hipEventDestroy(ev.e0);
         (void)hipEventDestroy(ev.e1);
@@ -242,13 +283,36 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
             // to the candidate filter directly.  Purely a performance choice - both paths are exact.
             bool v3 = c->search_version >= 3;
             // column-major lines (|F*p|_x > |F*p|_y, mod.rs:397): the transposed instantiation of the box kernel
-            const bool transposed = std::fabs(p.F[2]) > std::fabs(p.F[5]);
+            bool transposed = std::fabs(p.F[2]) > std::fabs(p.F[5]);
             const double f_major = transposed ? std::fabs(p.F[2]) : std::fabs(p.F[5]);
-            const double f_minor = transposed ? std::fabs(p.F[5]) : std::fabs(p.F[2]);
-            if (v3 && !c->force_box) {
-                const double *F = p.F;
-                const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
-                v3 = affine_form && f_major > 0.0 && f_minor <= 0.08 * f_major;
+            double f_minor = transposed ? std::fabs(p.F[5]) : std::fabs(p.F[2]);
+            const double *F = p.F;
+            const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
+            if (!affine_form) {
+                // Perspective F: the line direction (l.x, l.y) = first two components of F*p is an affine function of
+                // the pixel, so "within 0.08 of one axis, on one side of it" at the four image corners holds for
+                // every pixel in between (an intersection of half-planes).  Then the per-pixel lines are near enough
+                // to one axis for the box walk, with per-step plane windows (the STEP instantiation).
+                const double up = (double)(1u << k), xs[2] = {0.0, (double)(lw1 - 1) * up}, ys[2] = {0.0, (double)(lh1 - 1) * up};
+                int along_x = 0, along_y = 0, sign_major = 0;
+                bool same_side = true;
+                for (double cx : xs)
+                    for (double cy : ys) {
+                        const double lx = (F[0] * cx + F[1] * cy) + F[2], ly = (F[3] * cx + F[4] * cy) + F[5];
+                        if (!(std::isfinite(lx) && std::isfinite(ly))) same_side = false;
+                        const bool row_major = std::fabs(lx) <= 0.08 * std::fabs(ly), col_major = std::fabs(ly) <= 0.08 * std::fabs(lx);
+                        along_x += row_major ? 1 : 0;
+                        along_y += col_major ? 1 : 0;
+                        const int sg = (row_major ? ly : lx) > 0.0 ? 1 : -1;
+                        if (sign_major == 0) sign_major = sg;
+                        same_side = same_side && sg == sign_major;
+                    }
+                const bool near_axis = same_side && (along_x == 4 || along_y == 4);
+                transposed = along_y == 4;
+                f_minor = 1.0; // lines differ per pixel: always the stepped instantiation
+                if (v3 && !c->force_box) v3 = near_axis;
+            } else if (v3 && !c->force_box) {
+                v3 = f_major > 0.0 && f_minor <= 0.08 * f_major;
             }
             // the search kernel -> one persistent fallback kernel over the tiles the box filter declined and the tiles
             // with whole-corridor pixels (work lists filled by the producers)
@@ -398,6 +462,8 @@ void cvhip_device_destroy(cvhip_device *dev)
         (void)hipStreamSynchronize(dev->d.stream);
         if (dev->d.owns_stream) (void)hipStreamDestroy(dev->d.stream);
     }
+    for (auto &b : dev->d.parked) free_buffer_set(b);
+    dev->d.parked.clear();
     delete dev;
 }
 
@@ -461,22 +527,42 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     // chunk: (rows + den - 1) rows at most; 64 extra rows cover any den <= 64.
     auto grid_elems = [](uint32_t w, uint32_t h) { return (size_t)w * ((size_t)h + 64); };
     hipError_t e = hipSuccess;
-    for (int d = 0; d < 2 && e == hipSuccess; d++) {
+    c->work_cap = 2 * search3_worklist_capacity(std::max(w1, w2), std::max(h1, h2));
+    bool reused = false;
+    for (size_t i = dev->d.parked.size(); i-- > 0 && !reused;) { // a parked set of the same dimensions (see CtxBuffers)
+        CtxBuffers &b = dev->d.parked[i];
+        if (b.w1 != w1 || b.h1 != h1 || b.w2 != w2 || b.h2 != h2) continue;
+        for (int d = 0; d < 2; d++) {
+            for (int k = 0; k < 2; k++) c->dir[d].cells[k] = b.cells[d][k];
+            c->img[d] = b.img[d];
+            c->istats[d] = b.istats[d];
+        }
+        c->range = b.range;
+        c->range_rev = b.range_rev;
+        c->contenders = b.contenders;
+        c->contenders_rev = b.contenders_rev;
+        c->work = b.work;
+        c->d_cand = b.d_cand;
+        dev->d.parked.erase(dev->d.parked.begin() + (long)i);
+        reused = true;
+    }
+    for (int d = 0; d < 2 && e == hipSuccess && !reused; d++) {
         const size_t ge = grid_elems(c->dir[d].gw, c->dir[d].gh);
         for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
         if (e == hipSuccess) e = hipMalloc(&c->istats[d], c->max_px * sizeof(uint2));
     }
-    if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->range_rev, c->max_px * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->contenders, c->max_px * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&c->contenders_rev, c->max_px * sizeof(unsigned long long));
+    if (!reused) {
+        if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->range_rev, c->max_px * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->contenders, c->max_px * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(&c->contenders_rev, c->max_px * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(&c->work, (8 + 4 * c->work_cap) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    c->work_cap = 2 * search3_worklist_capacity(std::max(w1, w2), std::max(h1, h2));
-    if (e == hipSuccess) e = hipMalloc(&c->work, (8 + 4 * c->work_cap) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
         e = hipMemsetAsync(c->img[d], 0, c->max_px + IMG_PAD, dev->d.stream);
@@ -495,7 +581,7 @@ void cvhip_ctx_destroy(cvhip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev->d.ordinal);
     (void)hipStreamSynchronize(ctx->dev->d.stream);
-    free_ctx_buffers(ctx);
+    free_ctx_buffers(ctx, true); // the buffer set is parked on the device handle for the next pair
     delete ctx;
 }
 

@@ -138,13 +138,30 @@ __device__ __forceinline__ bool full_res_match(const uint2 *__restrict__ cells, 
 #endif
 
 // ---- handles --------------------------------------------------------------------------------
+// The device buffers of one dense-correlation context.  The reference allocates them per image pair
+// (GpuContext::new -> prepare_device, gpu/mod.rs:125-163) and frees them on drop; here a destroyed context parks its
+// set on the device handle and the next context of the same dimensions takes it over (a pipeline correlates many
+// pairs of equally sized images: hipMalloc / hipFree of ~1 GB per pair cost more than a 2048^2 correlation itself).
+struct CtxBuffers {
+    uint32_t w1 = 0, h1 = 0, w2 = 0, h2 = 0;
+    uint2 *cells[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint8_t *img[2] = {nullptr, nullptr};
+    uint2 *istats[2] = {nullptr, nullptr};
+    uint32_t *range = nullptr, *range_rev = nullptr;
+    unsigned long long *contenders = nullptr, *contenders_rev = nullptr;
+    uint32_t *work = nullptr;
+    unsigned long long *d_cand = nullptr;
+};
+
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     std::string name;
     int low_power = 0;
+    std::vector<CtxBuffers> parked; // at most PARK_LIMIT sets, most recently used last
 };
+constexpr size_t PARK_LIMIT = 2;
 
 struct DirState {
     uint2 *cells[2] = {nullptr, nullptr}; // ping-pong compact level grids

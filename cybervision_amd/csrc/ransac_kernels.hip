@@ -391,34 +391,40 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(const double *__restri
     }
 }
 
-// ordered compaction of the live hypothesis slots (F[9 * h] is not NaN): live[0 .. *n_live) ascending; one workgroup
-__global__ __launch_bounds__(1024) void ransac_compact_kernel(const double *__restrict__ F, uint32_t H,
-                                                               uint32_t *__restrict__ live, uint32_t *__restrict__ n_live)
+// Ordered compaction of the live hypothesis slots (F[9 * h] is not NaN) -> live[0 .. *n_live) ascending:
+// per-1024-slot counts, a single-block scan of the (~150) counts, then the scatter.
+__global__ __launch_bounds__(1024) void ransac_live_count_kernel(const double *__restrict__ F, uint32_t H,
+                                                                  uint32_t *__restrict__ block_counts)
 {
     __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    const uint32_t h = blockIdx.x * 1024 + threadIdx.x;
+    const double f0 = h < H ? F[(size_t)h * 9] : __builtin_nan("");
+    const unsigned long long b = __ballot(f0 == f0);
+    if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = (uint32_t)__popcll(b);
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < H; base += 1024) {
-        const uint32_t h = base + threadIdx.x;
-        const double f0 = h < H ? F[(size_t)h * 9] : __builtin_nan("");
-        const bool is_live = f0 == f0;
-        const unsigned long long b = __ballot(is_live);
-        if (lane == 0) wtot[wv] = (uint32_t)__popcll(b);
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (uint32_t w = 0; w < wv; w++) off += wtot[w];
-        if (is_live) live[off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = h;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < 16; w++) tot += wtot[w];
-            carry_s += tot;
-        }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; w++) tot += wtot[w];
+        block_counts[blockIdx.x] = tot;
     }
-    if (threadIdx.x == 0) *n_live = carry_s;
+}
+__global__ __launch_bounds__(1024) void ransac_live_scatter_kernel(const double *__restrict__ F, uint32_t H,
+                                                                    const uint32_t *__restrict__ block_offsets,
+                                                                    uint32_t *__restrict__ live)
+{
+    __shared__ uint32_t wtot[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t h = blockIdx.x * 1024 + threadIdx.x;
+    const double f0 = h < H ? F[(size_t)h * 9] : __builtin_nan("");
+    const bool is_live = f0 == f0;
+    const unsigned long long b = __ballot(is_live);
+    if (lane == 0) wtot[wv] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (is_live) {
+        uint32_t off = block_offsets[blockIdx.x];
+        for (uint32_t w = 0; w < wv; w++) off += wtot[w];
+        live[off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = h;
+    }
 }
 
 void launch_ransac_score(const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
@@ -435,8 +441,13 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
                                       uint32_t *live, uint32_t *n_live, uint32_t min_count, const RansacBest *best,
                                       uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
+    // scratch: the per-block counts live in out_err_sum's first words until the score kernel overwrites them
+    uint32_t *block_counts = reinterpret_cast<uint32_t *>(out_err_sum);
+    const uint32_t nblocks = (H + 1023) / 1024;
     (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(ransac_compact_kernel, dim3(1), dim3(1024), 0, s, F, H, live, n_live);
+    hipLaunchKernelGGL(ransac_live_count_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, block_counts);
+    launch_scan_u32(block_counts, nblocks, n_live, s);
+    hipLaunchKernelGGL(ransac_live_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, (const uint32_t *)block_counts, live);
     hipLaunchKernelGGL(ransac_score_kernel, dim3((H + 63) / 64), dim3(64), 0, s, F, H,
                        reinterpret_cast<const uint4 *>(matches), N, t, (const uint32_t *)live, (const uint32_t *)n_live, min_count,
                        best, out_count, out_err_sum);
