@@ -14,6 +14,7 @@
 // (SURVEY.md §8a N3); only the empty cells are skipped.
 #include "cvhip_internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -54,6 +55,20 @@ __device__ __forceinline__ TileId xcd_tile()
     t.y = id / nx;
     t.x = id - t.y * nx;
     return t;
+}
+
+// The job of this workgroup when one launch carries the passes of both directions (blockIdx.z): the two SearchJob
+// structs are the kernel's first two arguments, i.e. they sit back to back at the start of the kernel-argument
+// segment, and the job is addressed THERE - a uniform pointer into constant memory - so that every member stays a
+// scalar load the compiler can repeat wherever it needs the value, exactly like a plain by-value argument.  (Selecting
+// between the two by-value structs instead copies them: whole-struct selection went through 700 B of scratch and
+// made the box kernel 2.5x slower; member-by-member selection kept ~70 values live in SGPRs and spilled 30-80.)
+typedef const __attribute__((address_space(4))) SearchJob *KernargJobPtr;
+__device__ __forceinline__ const SearchJob &this_job()
+{
+    static_assert(sizeof(SearchJob) % 8 == 0, "the second job must directly follow the first in the kernarg segment");
+    // (the address-space cast is undone by the compiler once this is inlined: the loads stay s_load from constant memory)
+    return *(const SearchJob *)((KernargJobPtr)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.z);
 }
 
 // 12 bytes starting at an arbitrary byte address (gfx950 global loads may be unaligned).
@@ -364,9 +379,8 @@ __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x,
 // clamping included — so the neighbour statistics are computed once and shared; each pixel then applies
 // its own validity tests and corridor bounds.  (Pixels of one block on different corridor axes, possible
 // only for perspective geometry, each get their own axis' statistics.)
-__global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const uint2 *__restrict__ stats1,
-                                                            const uint2 *__restrict__ prev,
-                                                            uint32_t *__restrict__ range, int mode)
+__device__ __forceinline__ void search_range_body(const CorrParams &p, const uint2 *__restrict__ prev,
+                                                  uint32_t *__restrict__ range, int mode)
 {
     // chain path: raw cells of the tile's window (+ slack for the predicated row reads);
     // sum path: the same words hold FA | FB | HA | HB (see below)
@@ -694,14 +708,30 @@ __global__ __launch_bounds__(256) void search_range_kernel(CorrParams p, const u
     }
 }
 
-void launch_search_range(const CorrParams &p, const uint2 *stats1, const uint2 *prev, uint32_t *range, int mode,
-                         hipStream_t s)
+// One launch serves the search passes of both directions of a level (blockIdx.z picks the job): they are independent
+// (each reads its own direction's previous grid and writes its own buffers), and on the small levels neither fills
+// the GPU alone.  The grid covers the larger of the two; workgroups beyond a job's image find nothing to do.
+__global__ __launch_bounds__(256) void search_range_kernel(SearchJob ja, SearchJob jb, int mode)
 {
-    if (p.row1 <= p.row0) return;
-    // blocks by = row0/2 .. row1/2 cover pixel rows 2by-1, 2by; bx = 0 .. w1/2 cover columns 2bx-1, 2bx
-    const uint32_t nby = (p.row1 >> 1) - (p.row0 >> 1) + 1, nbx = (p.w1 >> 1) + 1;
-    dim3 grid((nbx + 63) / 64, (nby + 3) / 4);
-    hipLaunchKernelGGL(search_range_kernel, grid, dim3(256), 0, s, p, stats1, prev, range, mode);
+    const SearchJob &j = this_job();
+    search_range_body(j.p, j.prev, j.range, mode);
+}
+
+static bool job_active(const SearchJob &j) { return j.p.row1 > j.p.row0; }
+
+void launch_search_range(const SearchJob *jobs, int n, int mode, hipStream_t s)
+{
+    uint32_t gx = 0, gy = 0;
+    for (int i = 0; i < n; i++) {
+        const CorrParams &p = jobs[i].p;
+        if (!job_active(jobs[i])) continue;
+        // blocks by = row0/2 .. row1/2 cover pixel rows 2by-1, 2by; bx = 0 .. w1/2 cover columns 2bx-1, 2bx
+        const uint32_t nby = (p.row1 >> 1) - (p.row0 >> 1) + 1, nbx = (p.w1 >> 1) + 1;
+        gx = std::max(gx, (nbx + 63) / 64);
+        gy = std::max(gy, (nby + 3) / 4);
+    }
+    if (!gx || !gy) return;
+    hipLaunchKernelGGL(search_range_kernel, dim3(gx, gy, (unsigned)n), dim3(256), 0, s, jobs[0], jobs[n - 1], mode);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1295,21 +1325,14 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256, 3) void search2_filter_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                                 const uint8_t *__restrict__ img2,
-                                                                 const uint2 *__restrict__ stats1,
-                                                                 const uint2 *__restrict__ istats1,
-                                                                 const uint2 *__restrict__ istats2,
-                                                                 const uint32_t *__restrict__ range,
-                                                                 unsigned long long *__restrict__ contenders,
-                                                                 uint2 *__restrict__ out,
-                                                                 unsigned long long *__restrict__ counters,
-                                                                 WorkList whole_list, uint32_t lds_bytes)
+__global__ __launch_bounds__(256, 3) void search2_filter_kernel(SearchJob ja, SearchJob jb, uint32_t lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    const SearchJob &j = this_job();
     const TileId tid = xcd_tile();
-    (void)search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out, counters, 0,
-                                     PixTile{tid.x * 64u, p.row0 + tid.y * 4u, 64u, false}, whole_list, dyn_lds, lds_bytes);
+    (void)search2_filter_tile<COUNT>(j.p, j.img1, j.img2, j.stats1, j.stats1, j.stats2, j.range, j.contenders, j.out,
+                                     j.counters, 0, PixTile{tid.x * 64u, j.p.row0 + tid.y * 4u, 64u, false}, j.whole,
+                                     dyn_lds, lds_bytes);
 }
 
 // ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
@@ -1402,543 +1425,30 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 // waves along x, the packed 11-byte vectors are image ROWS - for column-major lines.  Below, u is the lane axis
 // and v the other one; S12 is the same integer either way.
 template <bool COUNT, bool STEP, bool TR>
-__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                           const uint8_t *__restrict__ img2,
-                                                           const uint2 *__restrict__ stats1,
-                                                           const uint2 *__restrict__ istats1,
-                                                           const uint2 *__restrict__ istats2,
-                                                           const uint32_t *__restrict__ range,
-                                                           unsigned long long *__restrict__ contenders,
-                                                           uint2 *__restrict__ out,
-                                                           unsigned long long *__restrict__ counters,
-                                                           WorkList declined, WorkList whole_list)
+__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(SearchJob ja, SearchJob jb)
 {
-    using Plan = S3Plan<STEP>;
-    constexpr int S3_MAXH = Plan::MAXH, NDW = Plan::NDW, S3_B16_OFF = Plan::B16_OFF, S3_TAIL_OFF = Plan::TAIL_OFF,
-                  S3_IS_OFF = Plan::IS_OFF, TAIL_BYTES = Plan::TAIL_BYTES;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[Plan::LDS_BYTES];
-    __shared__ int bb[6]; // min dx, min dy, max dx, max dy, max candidates of one pixel, 1 = some pixel is not a rectangle
-
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const TileId tid = xcd_tile();
-    const int U0 = (TR ? (int)p.row0 : 0) + (int)tid.x * S3_OUT;
-    const int uc = U0 - 6 + (int)lane;        // u coordinate of this lane's image line (a column; a row when TR)
-    const int ui = U0 - S3_LANE0 + (int)lane; // u coordinate of this lane's searched pixel (its window ends at uc)
-    const uint32_t V0 = (TR ? 0u : p.row0) + tid.y * 4;
-    const uint32_t vv = V0 + w;
-    const uint32_t x = TR ? vv : (uint32_t)ui, y = TR ? (uint32_t)ui : vv;
-    const int xi = (int)x;
-    const bool is_out = lane >= (uint32_t)S3_LANE0 && x < p.w1 && y < p.row1;
-    if (threadIdx.x == 0) {
-        bb[0] = 0x7FFFFFFF;
-        bb[1] = 0x7FFFFFFF;
-        bb[2] = -0x7FFFFFFF;
-        bb[3] = -0x7FFFFFFF;
-        bb[4] = 0;
-        bb[5] = 0;
-    }
-
-    PixelSetup ps;
-    ps.st1 = make_float2(0.0f, 1.0f);
-    ps.e.cx = ps.e.cy = ps.e.ax = ps.e.ay = 0.0;
-    ps.e.ox = ps.e.oy = 0;
-    ps.r0 = ps.r1 = 0;
-    const bool active = is_out && pixel_setup(p, x, y, stats1, range, ps);
-    const Line &e = ps.e;
-    const uint32_t r0 = ps.r0, r1 = ps.r1;
-    const int cs = p.corridor_size;
-    const bool major_x = e.ox == 0; // candidates advance along x (x2 == i exactly), stripes shift y
-
-    // ---- this pixel's candidate set in displacement space ---------------------------------------------------
-    // rectangle [lox, lox+wx) x [loy, loy+wy): every stripe keeps its minor coordinate over the interval; or, for
-    // row-major lines that step inside the interval ("stepped"), the same rectangle with a row offset loy(dx)
-    // that is re-evaluated per dx with the reference's own f64 expression (mod.rs:424-429).
-    bool simple = true, stepped = false;
-    int lox = 0, loy = 0, lox_hi = 0, loy_hi = 0;
-    uint32_t wx = 0, wy = 0;
-    if (active) {
-        uint32_t m0 = 0, m0l = 0;
-        bool constant = true, consecutive = true;
-        for (int off = -cs; off <= cs; off++) {
-            // The lean instantiation is only launched for exactly axis-parallel lines (minor coefficient +-0): the
-            // minor coordinate (+-0 * i + add) + off then does not depend on i, so the far end need not be evaluated.
-            const CandXY cf = candidate_xy(e, r0, off), cl = STEP ? candidate_xy(e, r1 - 1, off) : cf;
-            const uint32_t mf = major_x ? cf.y : cf.x, ml = major_x ? cl.y : cl.x;
-            if (off == -cs) {
-                m0 = mf;
-                m0l = ml;
-            }
-            constant = constant && mf == ml;
-            consecutive = consecutive && mf == m0 + (uint32_t)(off + cs) && ml == m0l + (uint32_t)(off + cs);
-        }
-        const uint32_t lim2 = major_x ? p.w2 : p.h2;
-        const uint32_t ilo = max(r0, (uint32_t)KERNEL_SIZE), ihi = min(r1, sat_sub_u32(lim2, KERNEL_SIZE));
-        const uint32_t nmaj = ihi > ilo ? ihi - ilo : 0u;
-        const bool sane = (r1 - r0) <= CW_MAX_LEN && m0 < 0x40000000u && m0l < 0x40000000u && ilo < 0x40000000u;
-        simple = constant && consecutive && sane && (STEP || (major_x ? e.cy == 0.0 : e.cx == 0.0));
-        // (m0, m0l >= 1: the casts of mod.rs:427-428 did not saturate a negative coordinate to 0)
-        if (STEP && !simple && major_x != TR && consecutive && sane && m0 >= 1u && m0l >= 1u && nmaj > 0u && nmaj <= 64u) {
-            // the stripes must be consecutive rows at EVERY candidate, exactly as the reference rounds them:
-            // floor((cy*i + ay) + off) == floor((cy*i + ay) - cs) + off + cs.  Where the fractional part is away
-            // from 0 and 1 that is implied (the addition of a small integer is then exact enough); the few
-            // positions where the line passes through an integer row are checked stripe by stripe.
-            bool ok = true;
-            for (uint32_t i = ilo; i < ihi; i++) {
-                const double v = TR ? e.cx * (double)i + e.ax : e.cy * (double)i + e.ay;
-                const double fr = v - floor(v);
-                if (!(fr >= 9.5367431640625e-7 && fr <= 1.0 - 9.5367431640625e-7)) {
-                    const CandXY c0 = candidate_xy(e, i, -cs);
-                    const uint32_t b0 = TR ? c0.x : c0.y;
-                    for (int off = -cs + 1; off <= cs; off++) {
-                        const CandXY co = candidate_xy(e, i, off);
-                        ok = ok && (TR ? co.x : co.y) == b0 + (uint32_t)(off + cs);
-                    }
-                }
-            }
-            stepped = ok;
-        }
-        if (major_x) {
-            lox = (int)ilo - xi;
-            lox_hi = lox;
-            wx = nmaj;
-            loy = (int)min(m0, m0l) - (int)y;
-            loy_hi = (int)max(m0, m0l) - (int)y;
-            wy = (uint32_t)(2 * cs + 1);
-        } else {
-            loy = (int)ilo - (int)y;
-            loy_hi = loy;
-            wy = nmaj;
-            lox = (int)min(m0, m0l) - xi;
-            lox_hi = (int)max(m0, m0l) - xi;
-            wx = (uint32_t)(2 * cs + 1);
-        }
-    }
-    const bool has = active && (simple || stepped) && wx > 0u && wy > 0u;
-    // the same rectangle on the kernel's axes: [lou, lou+wu) along the lanes, [lov .. lov_hi, +wv) across the planes
-    const int lou = TR ? loy : lox, lov = TR ? lox : loy, lov_hi = TR ? lox_hi : loy_hi;
-    const uint32_t wu = TR ? wy : wx, wv = TR ? wx : wy;
-    // wave-uniform bounds of the wave's displacement box
-    const int mnx = wave_min_i32(has ? lou : 0x7FFFFFFF), mny = wave_min_i32(has ? lov : 0x7FFFFFFF);
-    const int mxx = wave_max_i32(has ? lou + (int)wu - 1 : -0x7FFFFFFF), mxy = wave_max_i32(has ? lov_hi + (int)wv - 1 : -0x7FFFFFFF);
-    const int need = wave_max_i32(has ? (int)min(wu * wv, 0x3FFFFFFFu) : 0);
-    const bool wave_has = mxx >= mnx;
-    const bool wave_odd = __any(active && !(simple || stepped));
-    const bool wave_step = STEP && __any(has && stepped);
-    __syncthreads(); // bb initialised
-    if (lane == 0) {
-        if (wave_has) {
-            atomicMin(&bb[0], mnx);
-            atomicMin(&bb[1], mny);
-            atomicMax(&bb[2], mxx);
-            atomicMax(&bb[3], mxy);
-            atomicMax(&bb[4], need);
-        }
-        if (wave_odd) atomicOr(&bb[5], 1);
-    }
-    __syncthreads();
-    const size_t pix = (size_t)y * p.w1 + x;
-    const bool any_has = bb[2] >= bb[0];
-    const int dx0 = bb[0], dy0 = bb[1];
-    const int W = bb[2] - bb[0] + 1, H = bb[3] - bb[1] + 1;
-    const int C0 = U0 - 6 + dx0; // target line (column; row when TR) of lane 0 at the box's first step
-    const int C0a = TR ? C0 : (C0 & ~3);
-    const int colshift = C0 - C0a;
-    const int ncol = colshift + 64 + W - 1;
-    bool eligible = !bb[5] && !(p.debug & 4);
-    if (any_has) eligible = eligible && ncol <= S3_COLS && H <= S3_MAXH && (long long)W * H <= 3ll * bb[4] + 16;
-    if (!eligible || !any_has) {
-        // nothing to search (every pixel None), or left to the candidate-by-candidate kernel
-        if (is_out) {
-            // contender words are only read for tiles on a work list: a declined tile hands its pixels over through
-            // them; a tile with nothing to search is on no list and writes none
-            const bool fb = active && !eligible;
-            if (!eligible) contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
-            if (!fb) out[pix] = make_uint2(CELL_NONE, 0x7FC00000u);
-        }
-        if (!eligible && threadIdx.x == 0) {
-            if (counters && (p.debug & 32)) { // diagnostics: declined workgroups, and why
-                atomicAdd(&counters[3], 1ull);
-                if (bb[5]) atomicAdd(&counters[0], 1ull << 32);
-                else if (!(ncol <= S3_COLS)) atomicAdd(&counters[0], 1ull << 40);
-                else if (!(H <= S3_MAXH)) atomicAdd(&counters[0], 1ull << 48);
-                else atomicAdd(&counters[0], 1ull << 56);
-            }
-            // a transposed tile is named by its first column and its index along y
-            worklist_push(declined, TR ? (V0 | (tid.x << 16) | 0x40000000u) : ((uint32_t)U0 | (tid.y << 16)));
-        }
-        return;
-    }
-    const int NPL = H > 9 ? S3_MAXH : (H > 5 ? 9 : 5); // planes staged (lean: group A = 0..4, group B = 5..8)
-    if (p.debug & 256) return; // profiling: per-pixel setup and box reduction only
-
-    // ---- stage the target copies (20 bytes along v per line and copy) and the candidate statistics -------------
-    if (!(p.debug & 512)) {
-        const int R0 = (int)V0 + dy0 - KERNEL_SIZE; // first v coordinate of copy 0
-        if (!TR) {
-            // lines are columns: the bytes along v are a column of the image, gathered by 4x4 byte transposes
-            const int nb = (ncol + 3) >> 2;
-            const int units = 4 * NDW * nb;
-            for (int u = (int)threadIdx.x; u < units; u += 256) {
-                const int wk = u / nb, b = u - wk * nb; // wk = copy * NDW + k
-                const int cw = wk / NDW, k = wk - cw * NDW;
-                const int rr = R0 + cw + 4 * k, col = C0a + 4 * b;
-                const uint32_t d0 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 0, col);
-                const uint32_t d1 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 1, col);
-                const uint32_t d2 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 2, col);
-                const uint32_t d3 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 3, col);
-                uint4 t; // 4x4 byte transpose: t.c = rows rr..rr+3 of column col + c
-                t.x = (d0 & 0xFFu) | ((d1 & 0xFFu) << 8) | ((d2 & 0xFFu) << 16) | (d3 << 24);
-                t.y = ((d0 >> 8) & 0xFFu) | (d1 & 0xFF00u) | ((d2 & 0xFF00u) << 8) | ((d3 & 0xFF00u) << 16);
-                t.z = ((d0 >> 16) & 0xFFu) | ((d1 >> 8) & 0xFF00u) | (d2 & 0xFF0000u) | ((d3 & 0xFF0000u) << 8);
-                t.w = (d0 >> 24) | ((d1 >> 16) & 0xFF00u) | ((d2 >> 8) & 0xFF0000u) | (d3 & 0xFF000000u);
-                if (k < 4) {
-                    uint32_t *dst = reinterpret_cast<uint32_t *>(lds + S3_B16_OFF + (size_t)(cw * S3_COLS + 4 * b) * 16u) + k;
-                    dst[0] = t.x;
-                    dst[4] = t.y;
-                    dst[8] = t.z;
-                    dst[12] = t.w;
-                } else if (NDW == 5) {
-                    *reinterpret_cast<uint4 *>(lds + S3_TAIL_OFF + (size_t)(cw * S3_COLS + 4 * b) * 4u) = t;
-                } else {
-                    uint32_t *dst = reinterpret_cast<uint32_t *>(lds + S3_TAIL_OFF + (size_t)(cw * S3_COLS + 4 * b) * TAIL_BYTES) + (k - 4);
-                    dst[0] = t.x;
-                    dst[TAIL_BYTES / 4] = t.y;
-                    dst[2 * (TAIL_BYTES / 4)] = t.z;
-                    dst[3 * (TAIL_BYTES / 4)] = t.w;
-                }
-            }
-        } else {
-            // lines are rows: the bytes along v are contiguous in the image
-            const int units = 4 * NDW * ncol;
-            for (int u = (int)threadIdx.x; u < units; u += 256) {
-                const int wk = u / ncol, c = u - wk * ncol; // wk = copy * NDW + k
-                const int cw = wk / NDW, k = wk - cw * NDW;
-                const uint32_t d = load_dword_checked(img2, (int)p.w2, (int)p.h2, C0a + c, R0 + cw + 4 * k);
-                if (k < 4)
-                    *(reinterpret_cast<uint32_t *>(lds + S3_B16_OFF + (size_t)(cw * S3_COLS + c) * 16u) + k) = d;
-                else
-                    *(reinterpret_cast<uint32_t *>(lds + S3_TAIL_OFF + (size_t)(cw * S3_COLS + c) * TAIL_BYTES) + (k - 4)) = d;
-            }
-        }
-        const int isp = 64 + W - 1, isrows = NPL + 3;
-        const int gu0 = U0 - S3_LANE0 + dx0; // target u of lane 0's pixel at the box's first step
-        for (int u = (int)threadIdx.x; u < isp * isrows; u += 256) {
-            const int r = u / isp, c = u - r * isp;
-            const int gv = (int)V0 + dy0 + r, gu = gu0 + c;
-            const int gx = TR ? gv : gu, gy = TR ? gu : gv;
-            // {-window sum, f32 stdev}; centres outside the image or skipped by the reference (stdev non-finite or
-            // < min_stdev, mod.rs:430-441) get stdev = +inf: their acceptance threshold can never be reached
-            uint2 v = make_uint2(0u, 0x7F800000u);
-            if (gy >= 0 && gy < (int)p.h2 && gx >= 0 && gx < (int)p.w2) {
-                const uint2 tt = istats2[(size_t)gy * p.w2 + (size_t)gx];
-                if (tt.x & 0x80000000u) v = make_uint2(0u - (tt.x & 0x7FFFFFFFu), tt.y); // -s2: N = 121*S12 + s1*(-s2) is one mul + one mad
-            }
-            *reinterpret_cast<uint2 *>(lds + S3_IS_OFF + (size_t)(r * S3_COLS + c) * 8u) = v;
-        }
-    }
-    // this lane's searched line (column uc, or row uc when TR), v-5 .. v+5, packed and pre-shifted by 0..3 bytes
-    uint32_t a[4][4];
-    {
-        uint32_t a0 = 0, a1 = 0, a2 = 0;
-        if (!TR && uc >= 0 && uc < (int)p.w1 && vv >= (uint32_t)KERNEL_SIZE && vv + KERNEL_SIZE < p.h1) {
-            const uint8_t *pc = img1 + (size_t)(vv - KERNEL_SIZE) * p.w1 + (size_t)uc;
-            uint32_t b[KERNEL_WIDTH];
-#pragma unroll
-            for (int r = 0; r < KERNEL_WIDTH; r++) b[r] = pc[(size_t)r * p.w1];
-            a0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-            a1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-            a2 = b[8] | (b[9] << 8) | (b[10] << 16);
-        }
-        if (TR && uc >= 0 && uc < (int)p.h1 && vv >= (uint32_t)KERNEL_SIZE && vv + KERNEL_SIZE < p.w1) {
-            const Row12 rr = load_row12(img1 + (size_t)uc * p.w1 + (vv - KERNEL_SIZE));
-            a0 = rr.a;
-            a1 = rr.b;
-            a2 = rr.c & 0x00FFFFFFu;
-        }
-        a[0][0] = a0;
-        a[0][1] = a1;
-        a[0][2] = a2;
-        a[0][3] = 0u;
-#pragma unroll
-        for (int q = 1; q < 4; q++) { // 128-bit left shift by q bytes
-            a[q][0] = a0 << (8 * q);
-            a[q][1] = __builtin_amdgcn_alignbyte(a1, a0, 4 - q);
-            a[q][2] = __builtin_amdgcn_alignbyte(a2, a1, 4 - q);
-            a[q][3] = __builtin_amdgcn_alignbyte(0u, a2, 4 - q);
-        }
-    }
-    const uint32_t s1 = has ? (istats1[pix].x & 0x7FFFFFFFu) : 0u;
-    const float k1 = ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT); // 121*121*sd1
-    const float c1 = 1.0f / k1;
-    __syncthreads();
-
-    unsigned long long word = 0ull;
-    uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
-    uint32_t evaluated = 0, multi = 0, whole = 0, exact_evals = 0;
-    float runmax = -__builtin_inff();
-    const float thr_lo = p.threshold - S2_DELTA;
-    unsigned long long clist = 0ull;
-    uint32_t count = 0;
-    // acceptance band in the integer domain, as in search2_filter_kernel; lanes without candidates never pass
-    float limk = has ? thr_lo * k1 * (1.0f - 9.5367431640625e-7f) : __builtin_inff();
-    auto score = [&](int num, float sd2) -> float { return (float)num * (c1 * __builtin_amdgcn_rcpf(sd2)); };
-    auto record = [&](float g, uint32_t code) {
-        const float lim = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo);
-        if (g >= lim) {
-            if (g > runmax + 2.0f * S2_DELTA) { // everything recorded so far is out of the band
-                count = 0;
-                clist = 0ull;
-            }
-            runmax = fmaxf(runmax, g);
-            limk = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo) * k1 * (1.0f - 9.5367431640625e-7f);
-            if (count < (uint32_t)S2_K) clist |= (unsigned long long)code << (15u * count);
-            count = min(count + 1u, (uint32_t)S2_K + 1u);
-        }
-    };
-
-    if (wave_has && !(p.debug & 8)) {
-        const uint32_t col0 = lane + (uint32_t)colshift + (uint32_t)(mnx - dx0);
-        const uint8_t *const bB16 = lds + S3_B16_OFF + (w * S3_COLS + col0) * 16u;
-        const uint8_t *const bB4 = lds + S3_TAIL_OFF + (w * S3_COLS + col0) * (uint32_t)TAIL_BYTES;
-        const uint8_t *const bIS = lds + S3_IS_OFF + (w * S3_COLS + lane + (uint32_t)(mnx - dx0)) * 8u;
-        const int idx_lo = (int)(lane >= 11u ? lane - 11u : 0u) * 4;
-        const int nsteps = mxx - mnx + 1;
-        const int ws0 = mny - dy0, wn = mxy - mny + 1; // the wave's plane window while no line steps
-        // Inside out: from the middle of the wave's displacement range up to its end, then from the middle down to
-        // its start.  The ranges are centred on the positions predicted by the previous level, so the best matches
-        // sit around the middle and are met first; the near-misses next to them (which pass the initial threshold
-        // and would each cost a trip through the hit branch) then come after limk has risen.  Any order is exact.
-        const int mid = nsteps >> 1;
-        for (int t = 0; t < nsteps; t++) {
-            const int step = t < nsteps - mid ? mid + t : nsteps - 1 - t;
-            const uint8_t *pB16 = bB16 + step * 16, *pB4 = bB4 + step * TAIL_BYTES, *pIS = bIS + step * 8;
-            const int dx = mnx + step; // displacement along the lanes (x; y when TR)
-            const bool mx = has && (uint32_t)(dx - lou) < wu;
-            // first plane offset of this lane's candidates at this step, and the planes the wave needs for it
-            int bl = lov, s0 = ws0, n = wn;
-            if (wave_step) {
-                if (stepped && mx) { // mod.rs:424-429
-                    const CandXY cb = candidate_xy(e, (uint32_t)((TR ? (int)y : xi) + dx), -cs);
-                    bl = TR ? (int)cb.x - xi : (int)cb.y - (int)y;
-                }
-                const int lo = wave_min_i32(mx ? bl : 0x7FFFFFFF), hi = wave_max_i32(mx ? bl + (int)wv - 1 : -0x7FFFFFFF);
-                if (hi < lo) continue; // nobody searches this step
-                s0 = lo - dy0;
-                n = hi - lo + 1;
-            }
-            const uint4 r4 = *reinterpret_cast<const uint4 *>(pB16);
-            uint32_t raw[NDW];
-            raw[0] = r4.x;
-            raw[1] = r4.y;
-            raw[2] = r4.z;
-            raw[3] = r4.w;
-            if (NDW == 5) {
-                raw[4] = *reinterpret_cast<const uint32_t *>(pB4);
-            } else {
-                const uint2 r2 = *reinterpret_cast<const uint2 *>(pB4);
-                raw[4] = r2.x;
-                raw[NDW - 1] = r2.y;
-            }
-            // one group of planes: s = S0 .. S0 + N - 1 (dy = dy0 + s), all independent until the rare branch
-            auto group = [&](auto s0_tag, auto n_tag) {
-                constexpr int S0 = decltype(s0_tag)::value, N = decltype(n_tag)::value;
-                int num[N];
-                float sd[N];
-#pragma unroll
-                for (int q = 0; q < N; q++) {
-                    const int s = S0 + q, sh = s & 3, o = s >> 2;
-                    const uint2 is2 = *reinterpret_cast<const uint2 *>(pIS + s * (S3_COLS * 8));
-                    uint32_t c = __builtin_amdgcn_udot4(a[sh][0], raw[o], 0u, false);
-                    c = __builtin_amdgcn_udot4(a[sh][1], raw[o + 1], c, false);
-                    c = __builtin_amdgcn_udot4(a[sh][2], raw[o + 2], c, false);
-                    if (sh >= 2) c = __builtin_amdgcn_udot4(a[sh][3], raw[o + 3 < NDW ? o + 3 : NDW - 1], c, false);
-                    const uint32_t pre = wave_prefix_sum(c);
-                    const uint32_t s12 = pre - (uint32_t)__builtin_amdgcn_ds_bpermute(idx_lo, (int)pre);
-                    num[q] = __mul24((int)s12, KERNEL_POINT_COUNT) + __mul24((int)s1, (int)is2.x);
-                    sd[q] = __uint_as_float(is2.y);
-                }
-                // one rarely taken branch for the group: the largest margin (float)N - limk*sd2 decides.  The fused
-                // multiply-add only pre-screens (limk is shaved by 2^-20); a hit is re-tested below.
-                float margin = __builtin_fmaf(-limk, sd[0], (float)num[0]);
-#pragma unroll
-                for (int q = 1; q < N; q++) margin = fmaxf(margin, __builtin_fmaf(-limk, sd[q], (float)num[q]));
-                if (COUNT) {
-#pragma unroll
-                    for (int q = 0; q < N; q++)
-                        if (mx && (uint32_t)(dy0 + S0 + q - bl) < wv && sd[q] < __builtin_inff()) evaluated++;
-                }
-                if (margin >= 0.0f && !(p.debug & 64)) {
-                    // Planes from the middle of the group outwards: every record raises limk, and the stripe through
-                    // the predicted position is where the best match usually is - once it is in, its neighbours
-                    // (typically 0.6 .. 0.9 against ~1) fail the re-test and their record bodies are skipped.  The
-                    // order is free: the contender list is unordered and re-evaluated exactly.
-#pragma unroll
-                    for (int qi = 0; qi < N; qi++) {
-                        const int q = (N - 1) / 2 + ((qi & 1) ? (qi + 1) / 2 : -(qi / 2)); // m, m+1, m-1, m+2, ...
-                        const int dy = dy0 + S0 + q; // displacement across the planes (y; x when TR)
-                        if (mx && (uint32_t)(dy - bl) < wv && sd[q] < __builtin_inff() && (float)num[q] >= limk * sd[q]) {
-                            // back to image axes: candidate (x + ddx, y + ddy), stripe origin (ox, oy)
-                            const int ddx = TR ? dy : dx, ddy = TR ? dx : dy, ox = TR ? bl : lox, oy = TR ? loy : bl;
-                            const uint32_t code = major_x ? ((uint32_t)(ddy - oy) << 11) | (uint32_t)(xi + ddx - (int)r0)
-                                                          : ((uint32_t)(ddx - ox) << 11) | (uint32_t)((int)y + ddy - (int)r0);
-                            record(score(num[q], sd[q]), code);
-                        }
-                    }
-                }
-            };
-            // five planes from `start` in one interleaved group, any further ones singly (planes are register-
-            // indexed, so the window position selects an instantiation)
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            using I2 = std::integral_constant<int, 2>;
-            using I3 = std::integral_constant<int, 3>;
-            using I4 = std::integral_constant<int, 4>;
-            using I5 = std::integral_constant<int, 5>;
-            if (!STEP) { // rectangles only: the workgroup's planes 0..4, and 5..8 when its box is taller
-                group(I0{}, I5{});
-                if (NPL > 5) group(I5{}, std::integral_constant<int, 4>{});
-                continue;
-            }
-            if constexpr (STEP) {
-                using I6 = std::integral_constant<int, 6>;
-                using I7 = std::integral_constant<int, 7>;
-                using I8 = std::integral_constant<int, 8>;
-                using I9 = std::integral_constant<int, 9>;
-                using I10 = std::integral_constant<int, 10>;
-                using I11 = std::integral_constant<int, 11>;
-                using I12 = std::integral_constant<int, 12>;
-                const int start = min(s0, NPL - 5);
-                switch (start) {
-                case 0: group(I0{}, I5{}); break;
-                case 1: group(I1{}, I5{}); break;
-                case 2: group(I2{}, I5{}); break;
-                case 3: group(I3{}, I5{}); break;
-                case 4: group(I4{}, I5{}); break;
-                case 5: group(I5{}, I5{}); break;
-                case 6: group(I6{}, I5{}); break;
-                case 7: group(I7{}, I5{}); break;
-                default: group(I8{}, I5{}); break;
-                }
-                // the planes beyond the first five: one more interleaved group where there are three or more of them
-                // (nine stripes), else singly (five stripes whose line steps once inside the box)
-                const int rest0 = start + 5, rem = s0 + n - rest0;
-                if (rem >= 3) {
-                    switch (rest0) {
-                    case 5: group(I5{}, I5{}); break;
-                    case 6: group(I6{}, I5{}); break;
-                    case 7: group(I7{}, I5{}); break;
-                    case 8: group(I8{}, I5{}); break;
-                    case 9: group(I9{}, I4{}); break;
-                    default: group(I10{}, I3{}); break;
-                    }
-                } else {
-                    for (int sx = rest0; sx < s0 + n; sx++) {
-                        switch (sx) {
-                        case 5: group(I5{}, I1{}); break;
-                        case 6: group(I6{}, I1{}); break;
-                        case 7: group(I7{}, I1{}); break;
-                        case 8: group(I8{}, I1{}); break;
-                        case 9: group(I9{}, I1{}); break;
-                        case 10: group(I10{}, I1{}); break;
-                        case 11: group(I11{}, I1{}); break;
-                        default: group(I12{}, I1{}); break;
-                        }
-                    }
-                }
-            }
-        }
-    }
-
-    if (has) {
-        if (count > (uint32_t)S2_K) {
-            word = CW_WHOLE << 60;
-            whole = 1;
-            evaluated = 0; // the exact kernel walks (and counts) the whole corridor
-        } else if (count > 0u && !(p.debug & (16 | 512))) { // (512: the contenders come from unstaged LDS)
-            // ---- exact re-evaluation of the contenders: mod.rs:442-464, the reference's serial f32 chain and
-            // acceptance rule; the list is unordered here, so "first maximum" is the smallest code among equals
-            multi = count > 1 ? 1u : 0u;
-            bool have = false;
-            float bcorr = 0.0f;
-            uint32_t bxy = 0, bcode = 0;
-            // Rectified instantiation: the epipolar line and the window statistics are not needed during the walk,
-            // so they are re-derived here (same expressions, same bits) instead of living in 10 registers across it.
-            Line ex = e;
-            float2 st1x = ps.st1;
-            if (!STEP) {
-                uint32_t xo = x, yo = y;
-                asm volatile("" : "+v"(xo), "+v"(yo));
-                ex = epipolar_line(p, xo, yo);
-                st1x = stats_of(stats1[(size_t)yo * p.w1 + xo]);
-            }
-            const float avg1 = st1x.x, sdev1 = st1x.y;
-            const uint8_t *base1 = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
-            for (uint32_t j = 0; j < count; j++) {
-                const uint32_t code = (uint32_t)(clist >> (15u * j)) & 0x7FFFu;
-                const CandXY c = candidate_xy(ex, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
-                const uint2 is2 = istats2[(size_t)c.y * p.w2 + c.x];
-                const float avg2 = (float)(is2.x & 0x7FFFFFFFu) / (float)KERNEL_POINT_COUNT; // == compute_point_avg
-                const float sdev2 = __uint_as_float(is2.y);
-                const uint8_t *base2 = img2 + (size_t)(c.y - KERNEL_SIZE) * p.w2 + (c.x - KERNEL_SIZE);
-                float corr = 0.0f;
-                // Both windows come straight from L1/L2 (one contender per pixel is the rule, so nothing is re-read),
-                // in three batches of rows (a real loop): all 22 row loads in flight at once would make this phase the
-                // kernel's register high-water mark (83 instead of ~50) and cost the walk its occupancy.
-#pragma unroll 1
-                for (int rb = 0; rb < 12; rb += 4) {
-                    Row12 av[4], bv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int rr = min(rb + r, KERNEL_WIDTH - 1);
-                        av[r] = load_row12(base1 + (size_t)rr * p.w1);
-                        bv[r] = load_row12(base2 + (size_t)rr * p.w2);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (rb + r < KERNEL_WIDTH) corr = row_corr_acc(corr, av[r], bv[r], avg1, avg2);
-                }
-                corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
-                exact_evals++;
-                if (corr >= p.threshold && (!have || corr > bcorr || (corr == bcorr && code < bcode))) { // mod.rs:456-464
-                    have = true;
-                    bcorr = corr;
-                    bcode = code;
-                    bxy = c.x | (c.y << 16);
-                }
-            }
-            if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
-        }
-    }
-    if (is_out && !whole) out[pix] = cell;
-    if (counters) {
-        uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = whole;
-        if (p.debug & 32) { // diagnostics: displacements walked per wave, waves that walked
-            v1 = lane == 0 && wave_has ? (uint32_t)((mxx - mnx + 1) * NPL) : 0u;
-            v2 = lane == 0 && wave_has ? 1u : 0u;
-        }
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) {
-            v0 += __shfl_down(v0, sft, 64);
-            v1 += __shfl_down(v1, sft, 64);
-            v2 += __shfl_down(v2, sft, 64);
-            v3 += __shfl_down(v3, sft, 64);
-        }
-        if (lane == 0) {
-            if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
-            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
-            if (v2) atomicAdd(&counters[2], (unsigned long long)v2);
-            if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
-        }
-    }
-    {
-        // Only a tile that goes onto the whole-corridor list has its contender words read (all of them: the settled
-        // pixels' words must say so) - every other tile writes none: 8 B per pixel of HBM traffic less.
-        const int any_whole = __syncthreads_or(whole ? 1 : 0);
-        if (any_whole && is_out) contenders[pix] = word;
-        if (threadIdx.x == 0 && any_whole)
-            worklist_push(whole_list, TR ? (V0 | (tid.x << 16) | 0x40000000u) : ((uint32_t)U0 | (tid.y << 16)));
-    }
+    const SearchJob &j = this_job(); // both directions of a level in one launch (see search_range_kernel)
+    const CorrParams &p = j.p;
+    const uint8_t *__restrict__ const img1 = j.img1, *__restrict__ const img2 = j.img2;
+    const uint2 *__restrict__ const stats1 = j.stats1, *__restrict__ const istats1 = j.stats1, *__restrict__ const istats2 = j.stats2;
+    const uint32_t *__restrict__ const range = j.range;
+    unsigned long long *__restrict__ const contenders = j.contenders, *__restrict__ const counters = j.counters;
+    uint2 *__restrict__ const out = j.out;
+    const WorkList declined = j.declined, whole_list = j.whole;
+#include "box_body.inc"
+}
+// One job per launch, plain by-value arguments.  The stepped instantiations sit at the register limit of their
+// occupancy target (96 VGPRs, 5 waves per SIMD): addressing the job through the kernel-argument pointer costs them
+// either 24 spilled VGPRs or one wave of occupancy (3-degree pair, level 0: 5.7 ms -> 7.6 / 6.6 ms), so their two
+// directions stay two launches of this form.
+template <bool COUNT, bool STEP, bool TR>
+__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_single_kernel(
+    CorrParams p, const uint8_t *__restrict__ img1, const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
+    const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
+    unsigned long long *__restrict__ contenders, uint2 *__restrict__ out, unsigned long long *__restrict__ counters,
+    WorkList declined, WorkList whole_list)
+{
+#include "box_body.inc"
 }
 
 // ---- kernel B: exact re-evaluation of the contenders (mod.rs:442-464), in corridor order --------------
@@ -2061,49 +1571,29 @@ __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const ui
     }
 }
 
-__global__ __launch_bounds__(256) void search2_exact_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                             const uint8_t *__restrict__ img2,
-                                                             const uint2 *__restrict__ stats1,
-                                                             const uint2 *__restrict__ istats2,
-                                                             const uint32_t *__restrict__ range,
-                                                             const unsigned long long *__restrict__ contenders,
-                                                             uint2 *__restrict__ out,
-                                                             unsigned long long *__restrict__ counters)
-{
-    search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters,
-                       PixTile{blockIdx.x * 64u, p.row0 + blockIdx.y * 4u, 64u, false});
-}
-
 // Search version 3, everything the box kernel left behind, in ONE persistent grid over its two work lists:
 // the tiles it declined go through the candidate filter and then, for their own > 4-contender pixels, straight
 // through the whole-corridor evaluation (each lane reads back only the contender word it wrote itself); the tiles
 // where the box kernel found such pixels only need the latter.
 template <bool COUNT>
-__global__ __launch_bounds__(256, 2) void search3_fallback_kernel(CorrParams p, const uint8_t *__restrict__ img1,
-                                                                   const uint8_t *__restrict__ img2,
-                                                                   const uint2 *__restrict__ stats1,
-                                                                   const uint2 *__restrict__ istats1,
-                                                                   const uint2 *__restrict__ istats2,
-                                                                   const uint32_t *__restrict__ range,
-                                                                   unsigned long long *__restrict__ contenders,
-                                                                   uint2 *__restrict__ out,
-                                                                   unsigned long long *__restrict__ counters,
-                                                                   WorkList declined, WorkList whole_list, int skip_exact,
-                                                                   uint32_t lds_bytes)
+__global__ __launch_bounds__(256, 2) void search3_fallback_kernel(SearchJob ja, SearchJob jb, int skip_exact, uint32_t lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-    const uint32_t nd = *declined.count, nw = *whole_list.count;
+    const SearchJob &j = this_job();
+    const CorrParams &p = j.p;
+    const uint32_t nd = *j.declined.count, nw = *j.whole.count;
     for (uint32_t t = blockIdx.x; t < nd; t += gridDim.x) {
-        const PixTile tl = tile_of_entry(declined.items[t], p.row0);
-        const bool any_whole = search2_filter_tile<COUNT>(p, img1, img2, stats1, istats1, istats2, range, contenders, out,
-                                                          counters, 1, tl, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
+        const PixTile tl = tile_of_entry(j.declined.items[t], p.row0);
+        const bool any_whole = search2_filter_tile<COUNT>(p, j.img1, j.img2, j.stats1, j.stats1, j.stats2, j.range, j.contenders,
+                                                          j.out, j.counters, 1, tl, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
         __syncthreads(); // the tile's LDS is reused by the next one
-        if (!skip_exact && any_whole) search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters, tl);
+        if (!skip_exact && any_whole)
+            search2_exact_tile(p, j.img1, j.img2, j.stats1, j.stats2, j.range, j.contenders, j.out, j.counters, tl);
     }
     if (skip_exact) return;
     for (uint32_t t = blockIdx.x; t < nw; t += gridDim.x)
-        search2_exact_tile(p, img1, img2, stats1, istats2, range, contenders, out, counters,
-                           tile_of_entry(whole_list.items[t], p.row0));
+        search2_exact_tile(p, j.img1, j.img2, j.stats1, j.stats2, j.range, j.contenders, j.out, j.counters,
+                           tile_of_entry(j.whole.items[t], p.row0));
 }
 
 // LDS per workgroup of the candidate filter.  A 64x4 tile's candidate box is as tall as the lines are steep: for
@@ -2120,62 +1610,72 @@ static uint32_t search2_lds_bytes(const CorrParams &p)
 
 constexpr int LIST_GRID = 768; // persistent workgroups of the work-list kernels (an empty list costs their dispatch)
 
-// The candidate filter over every tile; tiles with whole-corridor pixels are queued on whole_list for
-// search3_fallback_kernel (launched behind it with an empty declined list).
-void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                           const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList whole_list,
-                           hipStream_t s)
+// The candidate filter over every tile; tiles with whole-corridor pixels queue themselves on the job's whole list
+// for search3_fallback_kernel (launched behind it; its declined list stays empty).
+void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s)
 {
-    if (p.row1 <= p.row0) return;
-    dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
-    const uint32_t lds = search2_lds_bytes(p);
-    if (counters)
-        hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), lds, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters, whole_list, lds);
+    uint32_t gx = 0, gy = 0, lds = 0;
+    for (int i = 0; i < n; i++) {
+        const CorrParams &p = jobs[i].p;
+        if (!job_active(jobs[i])) continue;
+        gx = std::max(gx, (p.w1 + 63) / 64);
+        gy = std::max(gy, (p.row1 - p.row0 + 3) / 4);
+        lds = std::max(lds, search2_lds_bytes(p));
+    }
+    if (!gx || !gy) return;
+    const dim3 grid(gx, gy, (unsigned)n);
+    if (jobs[0].counters)
+        hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds);
     else
-        hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), lds, s, p, img1, img2, stats1, istats1, istats2,
-                           range, contenders, out, counters, whole_list, lds);
+        hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds);
 }
 
-void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                             const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                             unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList declined,
-                             WorkList whole_list, bool skip_exact, hipStream_t s)
+void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s)
 {
-    if (p.row1 <= p.row0) return;
-    const uint32_t lds = search2_lds_bytes(p);
-    if (counters)
-        hipLaunchKernelGGL(search3_fallback_kernel<true>, dim3(LIST_GRID), dim3(256), lds, s, p, img1, img2, stats1, istats1,
-                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0, lds);
+    uint32_t lds = 0;
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+        any = any || job_active(jobs[i]);
+        lds = std::max(lds, search2_lds_bytes(jobs[i].p));
+    }
+    if (!any) return;
+    const dim3 grid(LIST_GRID, 1, (unsigned)n);
+    if (jobs[0].counters)
+        hipLaunchKernelGGL(search3_fallback_kernel<true>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
     else
-        hipLaunchKernelGGL(search3_fallback_kernel<false>, dim3(LIST_GRID), dim3(256), lds, s, p, img1, img2, stats1, istats1,
-                           istats2, range, contenders, out, counters, declined, whole_list, skip_exact ? 1 : 0, lds);
+        hipLaunchKernelGGL(search3_fallback_kernel<false>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
 }
 
-void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                        const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
-                        bool transposed, WorkList declined, WorkList whole_list, hipStream_t s)
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, hipStream_t s)
 {
-    if (p.row1 <= p.row0) return;
     // lanes along x, 4 rows per workgroup - or, transposed, lanes along y and 4 columns per workgroup
-    const dim3 grid = transposed ? dim3((p.row1 - p.row0 + S3_OUT - 1) / S3_OUT, (p.w1 + 3) / 4)
-                                 : dim3((p.w1 + S3_OUT - 1) / S3_OUT, (p.row1 - p.row0 + 3) / 4);
-    auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats1, istats2, range, contenders, out,
-                           counters, declined, whole_list);
+    uint32_t gx = 0, gy = 0;
+    for (int i = 0; i < n; i++) {
+        const CorrParams &p = jobs[i].p;
+        if (!job_active(jobs[i])) continue;
+        gx = std::max(gx, transposed ? (p.row1 - p.row0 + S3_OUT - 1) / S3_OUT : (p.w1 + S3_OUT - 1) / S3_OUT);
+        gy = std::max(gy, transposed ? (p.w1 + 3) / 4 : (p.row1 - p.row0 + 3) / 4);
+    }
+    if (!gx || !gy) return;
+    const dim3 grid(gx, gy, (unsigned)n);
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]); };
+    auto launch_each = [&](auto kernel) { // the stepped instantiations: one launch per job (see search3_box_single_kernel)
+        for (int i = 0; i < n; i++)
+            if (job_active(jobs[i]))
+                hipLaunchKernelGGL(kernel, dim3(gx, gy, 1), dim3(256), 0, s, jobs[i].p, jobs[i].img1, jobs[i].img2, jobs[i].stats1,
+                                   jobs[i].stats1, jobs[i].stats2, (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out,
+                                   jobs[i].counters, jobs[i].declined, jobs[i].whole);
     };
-    const int variant = (counters ? 4 : 0) | (stepped_lines ? 2 : 0) | (transposed ? 1 : 0);
+    const int variant = (jobs[0].counters ? 4 : 0) | (stepped_lines ? 2 : 0) | (transposed ? 1 : 0);
     switch (variant) {
     case 0: launch(search3_box_kernel<false, false, false>); break;
     case 1: launch(search3_box_kernel<false, false, true>); break;
-    case 2: launch(search3_box_kernel<false, true, false>); break;
-    case 3: launch(search3_box_kernel<false, true, true>); break;
+    case 2: launch_each(search3_box_single_kernel<false, true, false>); break;
+    case 3: launch_each(search3_box_single_kernel<false, true, true>); break;
     case 4: launch(search3_box_kernel<true, false, false>); break;
     case 5: launch(search3_box_kernel<true, false, true>); break;
-    case 6: launch(search3_box_kernel<true, true, false>); break;
-    default: launch(search3_box_kernel<true, true, true>); break;
+    case 6: launch_each(search3_box_single_kernel<true, true, false>); break;
+    default: launch_each(search3_box_single_kernel<true, true, true>); break;
     }
 }
 
@@ -2185,16 +1685,6 @@ size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h)
     const size_t along_x = (size_t)((max_w + S3_OUT - 1) / S3_OUT) * ((max_h + 3) / 4 + 1);
     const size_t along_y = (size_t)((max_h + S3_OUT - 1) / S3_OUT) * ((max_w + 3) / 4 + 1); // transposed tiles
     return along_x > along_y ? along_x : along_y;
-}
-
-void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                          const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
-                          uint2 *out, unsigned long long *counters, hipStream_t s)
-{
-    if (p.row1 <= p.row0) return;
-    dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
-    hipLaunchKernelGGL(search2_exact_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, istats2, range, contenders,
-                       out, counters);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -121,14 +121,6 @@ static void release_ctx_buffers(cvhip_ctx *c, bool park)
 static void free_ctx_buffers(cvhip_ctx *c, bool park = false)
 {
     release_ctx_buffers(c, park);
-    if (c->aux_stream) {
-        (void)hipStreamSynchronize(c->aux_stream);
-        (void)hipStreamDestroy(c->aux_stream);
-        c->aux_stream = nullptr;
-    }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    c->ev_fork = c->ev_join = nullptr;
     for (auto &ev : c->events) {
         (void)hipEventDestroy(ev.e0);
         (void)hipEventDestroy(ev.e1);
@@ -198,15 +190,22 @@ static int stage_images(cvhip_ctx *c, const uint8_t *img1, size_t n1, const uint
     return CVHIP_OK;
 }
 
-// One search pass (mod.rs:247-319) given level images already staged in c->img[a] (searched)
-// and c->img[b] (target) with their window statistics in c->istats[a], c->istats[b].
-static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2,
-                       float scale, int k, int first_pass, int dir, bool zero_counts = true, hipStream_t s = nullptr)
+// One search pass (mod.rs:247-319) given level images already staged in c->img[a] (searched) and c->img[b] (target)
+// with their window statistics in c->istats[a], c->istats[b]: plan_pass validates the call and fills the job,
+// launch_passes submits one pass - or the two independent passes of a level in the same launches - and commit_pass
+// makes the new grid the direction's current one.
+struct PassPlan {
+    SearchJob job;
+    int dir = 0, next = 0;
+    uint32_t lw = 0, lh = 0, k = 0;
+    enum Kind { EXACT_V1, BOX, FILTER } kind = FILTER;
+    bool stepped = false, transposed = false;
+};
+
+static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2, float scale,
+                     int k, int first_pass, int dir, PassPlan &plan)
 {
     DirState &ds = c->dir[dir];
-    if (!s) s = c->dev->d.stream;
-    uint32_t *range = dir == 0 ? c->range : c->range_rev;
-    unsigned long long *contenders = dir == 0 ? c->contenders : c->contenders_rev;
     if (lw1 != (ds.gw >> k) || lh1 != (ds.gh >> k))
         return fail(CVHIP_ERR_UNSUPPORTED, "level dims must be floor(full * scale) (reconstruction.rs:146-152)");
     if (!first_pass) {
@@ -214,7 +213,7 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
         if ((int)ds.k <= k)
             return fail(CVHIP_ERR_UNSUPPORTED, "scale must shrink by powers of two from level to level");
     }
-    CorrParams p;
+    CorrParams &p = plan.job.p;
     std::memset(&p, 0, sizeof(p));
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) p.F[i * 3 + j] = dir == 0 ? c->F[i * 3 + j] : c->F[j * 3 + i]; // mod.rs:268-271
@@ -235,19 +234,18 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     p.pk = ds.k;
     p.k = (uint32_t)k;
     p.first_pass = first_pass ? 1 : 0;
-    {
-        const double *F = p.F;
-        p.affine = 0;
-        if (F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0 && std::isfinite(F[2]) && std::isfinite(F[5])) {
-            // l = F*p1 in nalgebra's order: (0*p0 + 0*p1) + F02*1 = F02 (a zero keeps at most its sign, which no
-            // result depends on), likewise F12
-            const bool first = std::fabs(F[2]) > std::fabs(F[5]); // mod.rs:397
-            const double div = first ? F[2] : F[5], c = first ? -F[5] / F[2] : -F[2] / F[5];
-            if (div != 0.0 && std::isfinite(c)) {
-                p.affine = first ? 1 : 2;
-                p.aff_c = c;
-                p.aff_div = div;
-            }
+    const double *F = p.F;
+    const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
+    p.affine = 0;
+    if (affine_form && std::isfinite(F[2]) && std::isfinite(F[5])) {
+        // l = F*p1 in nalgebra's order: (0*p0 + 0*p1) + F02*1 = F02 (a zero keeps at most its sign, which no
+        // result depends on), likewise F12
+        const bool first = std::fabs(F[2]) > std::fabs(F[5]); // mod.rs:397
+        const double div = first ? F[2] : F[5], cc = first ? -F[5] / F[2] : -F[2] / F[5];
+        if (div != 0.0 && std::isfinite(cc)) {
+            p.affine = first ? 1 : 2;
+            p.aff_c = cc;
+            p.aff_div = div;
         }
     }
 #ifdef CVHIP_ABLATIONS
@@ -263,98 +261,135 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
     } else {
         shard_rows(c, lh1, &p.row0, &p.row1);
     }
+    plan.dir = dir;
+    plan.lw = lw1;
+    plan.lh = lh1;
+    plan.k = (uint32_t)k;
+    plan.next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
+    SearchJob &j = plan.job;
+    j.img1 = c->cur_img[a];
+    j.img2 = c->cur_img[b];
+    j.stats1 = c->istats[a];
+    j.stats2 = c->istats[b];
+    j.prev = ds.cells[ds.cur];
+    j.range = dir == 0 ? c->range : c->range_rev;
+    j.contenders = dir == 0 ? c->contenders : c->contenders_rev;
+    j.out = ds.cells[plan.next];
+    j.counters = c->count_candidates ? c->d_cand : nullptr;
+    // the search kernel -> one persistent fallback kernel over the tiles the box filter declined and the tiles with
+    // whole-corridor pixels (work lists filled by the producers)
+    uint32_t *wc = c->work + 4 * dir;
+    uint32_t *items = c->work + 8 + (size_t)dir * 2 * c->work_cap; // per-direction item arrays
+    j.declined = WorkList{wc, items};
+    j.whole = WorkList{wc + 1, items + c->work_cap};
 
-    const int prev = ds.cur, next = first_pass && !ds.valid ? ds.cur : 1 - ds.cur;
-    unsigned long long *cnt = c->count_candidates ? c->d_cand : nullptr;
-    if (!first_pass)
-        CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(p, c->istats[a], ds.cells[prev], range, c->range_mode, s); }, s));
+    // Which search kernel.  Version 3: the box filter is the search; the candidate filter only walks the workgroups it
+    // declines (timed with the other fallback work, class K_EXACT).  The box walk pays where the candidate sets of
+    // neighbouring pixels are (nearly) the same few image rows (columns): axis-near epipolar lines.  For an affine F
+    // (F*p = (a, b, .) for every pixel) that is known up front: lines within ~4.5 degrees of the x or y axis (each extra
+    // line crossed inside a workgroup's displacement box is one more plane per step).  Steeper lines go to the
+    // candidate filter directly.  Purely a performance choice - every path is exact.
+    plan.kind = PassPlan::FILTER;
     if (c->search_version == 1) {
-        CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-            launch_search(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[b], range, ds.cells[next], cnt, s);
-        }, s));
-    } else {
-        if (!(p.debug & 2)) {
-            // Version 3: the box filter is the search; the candidate filter only walks the workgroups it declines
-            // (timed with the other fallback work, class K_EXACT).  The box walk pays where the candidate sets of
-            // neighbouring pixels are (nearly) the same few image rows (columns): axis-near epipolar lines.  For an
-            // affine F (F*p = (a, b, .) for every pixel) that is known up front: lines within ~4.5 degrees of the x
-            // or y axis (each extra line crossed inside a workgroup's displacement box is one more plane per step;
-            // beyond 9 the workgroups decline anyway).  Steeper lines and perspective F (lines differ per pixel) go
-            // to the candidate filter directly.  Purely a performance choice - both paths are exact.
-            bool v3 = c->search_version >= 3;
-            // column-major lines (|F*p|_x > |F*p|_y, mod.rs:397): the transposed instantiation of the box kernel
-            bool transposed = std::fabs(p.F[2]) > std::fabs(p.F[5]);
-            const double f_major = transposed ? std::fabs(p.F[2]) : std::fabs(p.F[5]);
-            double f_minor = transposed ? std::fabs(p.F[5]) : std::fabs(p.F[2]);
-            const double *F = p.F;
-            const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
-            if (!affine_form) {
-                // Perspective F: the line direction (l.x, l.y) = first two components of F*p is an affine function of
-                // the pixel, so "within 0.08 of one axis, on one side of it" at the four image corners holds for
-                // every pixel in between (an intersection of half-planes).  Then the per-pixel lines are near enough
-                // to one axis for the box walk, with per-step plane windows (the STEP instantiation).
-                const double up = (double)(1u << k), xs[2] = {0.0, (double)(lw1 - 1) * up}, ys[2] = {0.0, (double)(lh1 - 1) * up};
-                int along_x = 0, along_y = 0, sign_major = 0;
-                bool same_side = true;
-                for (double cx : xs)
-                    for (double cy : ys) {
-                        const double lx = (F[0] * cx + F[1] * cy) + F[2], ly = (F[3] * cx + F[4] * cy) + F[5];
-                        if (!(std::isfinite(lx) && std::isfinite(ly))) same_side = false;
-                        const bool row_major = std::fabs(lx) <= 0.08 * std::fabs(ly), col_major = std::fabs(ly) <= 0.08 * std::fabs(lx);
-                        along_x += row_major ? 1 : 0;
-                        along_y += col_major ? 1 : 0;
-                        const int sg = (row_major ? ly : lx) > 0.0 ? 1 : -1;
-                        if (sign_major == 0) sign_major = sg;
-                        same_side = same_side && sg == sign_major;
-                    }
-                const bool near_axis = same_side && (along_x == 4 || along_y == 4);
-                transposed = along_y == 4;
-                f_minor = 1.0; // lines differ per pixel: always the stepped instantiation
-                if (v3 && !c->force_box) v3 = near_axis;
-            } else if (v3 && !c->force_box) {
-                v3 = f_major > 0.0 && f_minor <= 0.08 * f_major;
+        plan.kind = PassPlan::EXACT_V1;
+        return CVHIP_OK;
+    }
+    bool v3 = c->search_version >= 3;
+    // column-major lines (|F*p|_x > |F*p|_y, mod.rs:397): the transposed instantiation of the box kernel
+    bool transposed = std::fabs(F[2]) > std::fabs(F[5]);
+    const double f_major = transposed ? std::fabs(F[2]) : std::fabs(F[5]);
+    double f_minor = transposed ? std::fabs(F[5]) : std::fabs(F[2]);
+    if (!affine_form) {
+        // Perspective F: the line direction (l.x, l.y) = first two components of F*p is an affine function of the pixel,
+        // so "within 0.08 of one axis, on one side of it" at the four image corners holds for every pixel in between
+        // (an intersection of half-planes).  Then the per-pixel lines are near enough to one axis for the box walk, with
+        // per-step plane windows (the STEP instantiation).
+        const double up = (double)(1u << k), xs[2] = {0.0, (double)(lw1 - 1) * up}, ys[2] = {0.0, (double)(lh1 - 1) * up};
+        int along_x = 0, along_y = 0, sign_major = 0;
+        bool same_side = true;
+        for (double cx : xs)
+            for (double cy : ys) {
+                const double lx = (F[0] * cx + F[1] * cy) + F[2], ly = (F[3] * cx + F[4] * cy) + F[5];
+                if (!(std::isfinite(lx) && std::isfinite(ly))) same_side = false;
+                const bool row_major = std::fabs(lx) <= 0.08 * std::fabs(ly), col_major = std::fabs(ly) <= 0.08 * std::fabs(lx);
+                along_x += row_major ? 1 : 0;
+                along_y += col_major ? 1 : 0;
+                const int sg = (row_major ? ly : lx) > 0.0 ? 1 : -1;
+                if (sign_major == 0) sign_major = sg;
+                same_side = same_side && sg == sign_major;
             }
-            // the search kernel -> one persistent fallback kernel over the tiles the box filter declined and the tiles
-            // with whole-corridor pixels (work lists filled by the producers)
-            uint32_t *wc = c->work + 4 * dir;
-            uint32_t *items = c->work + 8 + (size_t)dir * 2 * c->work_cap; // per-direction item arrays
-            const WorkList declined{wc, items};
-            const WorkList whole{wc + 1, items + c->work_cap};
-            // both directions' counts are zeroed once per level by cvhip_correlate_level; per-pass callers zero here
-            if (zero_counts) CVHIP_TRY_HIP(hipMemsetAsync(wc, 0, 4 * sizeof(uint32_t), s));
-            if (v3) {
-                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                    // exactly axis-parallel lines never step: the leaner instantiation
-                    launch_search3_box(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b], range,
-                                       contenders, ds.cells[next], cnt, f_minor != 0.0 || c->force_box, transposed,
-                                       declined, whole, s);
-                }, s));
-                CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                    launch_search3_fallback(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b], range,
-                                            contenders, ds.cells[next], cnt, declined, whole, (p.debug & 1) != 0, s);
-                }, s));
+        const bool near_axis = same_side && (along_x == 4 || along_y == 4);
+        transposed = along_y == 4;
+        f_minor = 1.0; // lines differ per pixel: always the stepped instantiation
+        if (v3 && !c->force_box) v3 = near_axis;
+    } else if (v3 && !c->force_box) {
+        v3 = f_major > 0.0 && f_minor <= 0.08 * f_major;
+    }
+    if (v3) {
+        plan.kind = PassPlan::BOX;
+        plan.stepped = f_minor != 0.0 || c->force_box; // exactly axis-parallel lines never step: the leaner instantiation
+        plan.transposed = transposed;
+    }
+    return CVHIP_OK;
+}
+
+// n = 1, or the two passes of one level (independent: each reads its own direction's previous grid and writes its own
+// buffers); passes that need the same kernels go out in the same launches (blockIdx.z), anything else one by one.
+static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts, hipStream_t s)
+{
+    const bool together = n == 2 && plans[0].kind == plans[1].kind && plans[0].kind != PassPlan::EXACT_V1 &&
+                          plans[0].stepped == plans[1].stepped && plans[0].transposed == plans[1].transposed &&
+                          plans[0].job.p.first_pass == plans[1].job.p.first_pass;
+    for (int i = 0; i < n; i += together ? 2 : 1) {
+        const int m = together ? 2 : 1;
+        SearchJob jobs[2] = {plans[i].job, plans[i + m - 1].job};
+        const PassPlan &pl = plans[i];
+        const CorrParams &p = pl.job.p;
+        if (!p.first_pass)
+            CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(jobs, m, c->range_mode, s); }, s));
+        if (pl.kind == PassPlan::EXACT_V1) {
+            CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
+                launch_search(p, pl.job.img1, pl.job.img2, pl.job.stats1, pl.job.stats2, pl.job.range, pl.job.out,
+                              pl.job.counters, s);
+            }, s));
+        } else if (!(p.debug & 2)) {
+            // both directions' work-list counts are zeroed once per level by the statistics kernel of
+            // cvhip_correlate_level; per-pass callers zero here
+            if (zero_counts)
+                for (int q = 0; q < m; q++) CVHIP_TRY_HIP(hipMemsetAsync(jobs[q].declined.count, 0, 4 * sizeof(uint32_t), s));
+            if (pl.kind == PassPlan::BOX) {
+                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] { launch_search3_box(jobs, m, pl.stepped, pl.transposed, s); }, s));
+                CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s); }, s));
             } else {
                 // candidate filter over every tile; the (rare) tiles with whole-corridor pixels queue themselves for
                 // the fallback kernel, whose declined list stays empty here
-                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                    launch_search2_filter(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b], range,
-                                          contenders, ds.cells[next], cnt, whole, s);
-                }, s));
+                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] { launch_search2_filter(jobs, m, s); }, s));
                 if (!(p.debug & 1))
-                    CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] {
-                        launch_search3_fallback(p, c->cur_img[a], c->cur_img[b], c->istats[a], c->istats[a], c->istats[b],
-                                                range, contenders, ds.cells[next], cnt, declined, whole, false, s);
-                    }, s));
+                    CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, false, s); }, s));
             }
         }
     }
     CVHIP_TRY_HIP(hipGetLastError());
+    return CVHIP_OK;
+}
 
-    ds.cur = next;
+static void commit_pass(cvhip_ctx *c, const PassPlan &plan)
+{
+    DirState &ds = c->dir[plan.dir];
+    ds.cur = plan.next;
     ds.valid = true;
-    ds.lw = lw1;
-    ds.lh = lh1;
-    ds.k = (uint32_t)k;
+    ds.lw = plan.lw;
+    ds.lh = plan.lh;
+    ds.k = plan.k;
+}
+
+static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2,
+                       float scale, int k, int first_pass, int dir)
+{
+    PassPlan plan;
+    CVHIP_TRY(plan_pass(c, a, b, lw1, lh1, lw2, lh2, scale, k, first_pass, dir, plan));
+    CVHIP_TRY(launch_passes(c, &plan, 1, true, c->dev->d.stream));
+    commit_pass(c, plan);
     return CVHIP_OK;
 }
 
@@ -560,9 +595,6 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         if (e == hipSuccess) e = hipMalloc(&c->work, (8 + 4 * c->work_cap) * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&c->d_cand, 4 * sizeof(unsigned long long));
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
         e = hipMemsetAsync(c->img[d], 0, c->max_px + IMG_PAD, dev->d.stream);
@@ -667,25 +699,8 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         ctx->shard_den = 1;
     }
     // The two search passes of a level are independent (each reads only its own direction's previous grid and
-    // writes only its own), so unless a gather has to run between them the reverse pass goes to a second
-    // stream: on the small levels - and on the short bands of a many-GPU run - neither fills the GPU alone.
-    // Only where one pass leaves the GPU partly idle (<= 1 M searched pixels: ~5 k workgroups for 1.5 k resident
-    // ones); the big levels keep their launches back to back, which also keeps their per-kernel timings clean.
-    hipStream_t s_rev = s;
-    uint64_t pass_px = (uint64_t)w1 * h1;
-    if (ctx->band_mode) pass_px = (uint64_t)w1 * (ctx->band[k].sf[1] - ctx->band[k].sf[0]);
-#ifdef CVHIP_ABLATIONS
-    static const uint64_t two_stream_px = [] { const char *v = std::getenv("CVHIP_TWO_STREAM_PX"); return v ? (uint64_t)std::atoll(v) : (uint64_t)(1u << 20); }();
-#else
-    constexpr uint64_t two_stream_px = 1u << 20;
-#endif
-    // (bands of a multi-GPU run: always - every pass is short there, and its kernels are not timed one by one)
-    if (!sharded && ctx->aux_stream && (pass_px <= two_stream_px || ctx->band_mode)) {
-        CVHIP_TRY_HIP(hipEventRecord(ctx->ev_fork, s));
-        CVHIP_TRY_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-        s_rev = ctx->aux_stream;
-    }
-    int rc = search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, false, s); // mod.rs:224-230
+    // writes only its own), so they go out in the same launches: on the small levels - and on the short bands of a
+    // many-GPU run - neither fills the GPU alone, and a level costs five dependent launches instead of eight.
     // A host hook enqueues its collective on a stream the library cannot see.  When the device handle was created on
     // the CALLER's stream, the hook is required to use that same stream (include/cvhip.h) and ordering follows.  When
     // the handle owns a private stream there is no such stream to share, so the library fences both sides itself:
@@ -701,14 +716,16 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         if (fence_hook) CVHIP_TRY_HIP(hipDeviceSynchronize());
         return CVHIP_OK;
     };
-    if (rc == CVHIP_OK && sharded) rc = run_gather(0);
-    report(progress, user, 0, 1.0f);
-    if (rc == CVHIP_OK) rc = search_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, false, s_rev); // mod.rs:231-237
-    if (s_rev != s) { // join, also on the error path, before anything else touches the shared inputs
-        const hipError_t ej = hipEventRecord(ctx->ev_join, s_rev);
-        const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_join, 0) : ej;
-        if (ew != hipSuccess && rc == CVHIP_OK) rc = fail(CVHIP_ERR_DEVICE, std::string("joining the reverse pass: ") + hipGetErrorString(ew));
+    PassPlan plans[2];
+    int rc = plan_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, plans[0]);                 // mod.rs:224-230
+    if (rc == CVHIP_OK) rc = plan_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, plans[1]); // mod.rs:231-237
+    if (rc == CVHIP_OK) rc = launch_passes(ctx, plans, 2, false, s);
+    if (rc == CVHIP_OK) {
+        commit_pass(ctx, plans[0]);
+        commit_pass(ctx, plans[1]);
     }
+    report(progress, user, 0, 1.0f);
+    if (rc == CVHIP_OK && sharded) rc = run_gather(0);
     if (rc == CVHIP_OK && sharded) rc = run_gather(1);
     ctx->shard_num = num;
     ctx->shard_den = den;

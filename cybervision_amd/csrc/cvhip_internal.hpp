@@ -76,27 +76,27 @@ struct WorkList {
 void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, uint2 *istats_a,
                               const uint8_t *img_b, uint32_t wb, uint32_t hb, uint2 *istats_b,
                               uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s);
-void launch_search_range(const CorrParams &p, const uint2 *stats1, const uint2 *prev, uint32_t *range, int mode,
-                         hipStream_t s);
+// One direction's search pass of a level: everything its kernels need.  The kernels of the two directions of a level
+// are launched together (jobs[0], jobs[1] -> blockIdx.z); per-pass callers launch one job.
+struct SearchJob {
+    CorrParams p;
+    const uint8_t *img1, *img2; // searched / target level image
+    const uint2 *stats1, *stats2; // their statistics words
+    const uint2 *prev;            // this direction's previous-level grid (search range)
+    uint32_t *range;              // search interval per searched pixel
+    unsigned long long *contenders;
+    uint2 *out;                   // this level's grid
+    unsigned long long *counters; // device counters or nullptr
+    WorkList declined, whole;
+};
+void launch_search_range(const SearchJob *jobs, int n, int mode, hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                    const uint2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
                    hipStream_t s);
-void launch_search2_filter(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                           const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                           unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList whole_list,
-                           hipStream_t s);
-void launch_search3_fallback(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                             const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                             unsigned long long *contenders, uint2 *out, unsigned long long *counters, WorkList declined,
-                             WorkList whole_list, bool skip_exact, hipStream_t s);
-void launch_search3_box(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                        const uint2 *istats1, const uint2 *istats2, const uint32_t *range,
-                        unsigned long long *contenders, uint2 *out, unsigned long long *counters, bool stepped_lines,
-                        bool transposed, WorkList declined, WorkList whole_list, hipStream_t s);
+void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s);
+void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s);
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, hipStream_t s);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
-void launch_search2_exact(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                          const uint2 *istats2, const uint32_t *range, const unsigned long long *contenders,
-                          uint2 *out, unsigned long long *counters, hipStream_t s);
 void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
 void launch_cross_check_pair(uint2 *fwd, uint2 *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
@@ -201,8 +201,6 @@ struct cvhip_ctx {
     // per-direction scratch of a search pass (the two passes of a level are independent and run on two streams)
     uint32_t *range = nullptr, *range_rev = nullptr;
     unsigned long long *contenders = nullptr, *contenders_rev = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
-    hipStream_t aux_stream = nullptr; // the reverse pass of cvhip_correlate_level, forked from / joined to the device's stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *work = nullptr;                 // tile work lists: per direction {declined n, whole n, declined scan, whole scan}, then two item arrays
     size_t work_cap = 0;                      // items per list
     size_t max_px = 0;

@@ -224,7 +224,8 @@ def test_candidate_counter_matches_oracle(gpu_device, oracle):
         pc.close()
     _, _, cand = oracle.correlate_dense(p1, p2, c["F"], 0, 8)
     assert prof["candidates"] == cand
-    assert prof["launches"] == 2 * (c["steps"] + 1) and prof["search_ms"] > 0.0
+    # one search launch per level: the forward and the reverse pass of a level share their launches
+    assert prof["launches"] == c["steps"] + 1 and prof["search_ms"] > 0.0
 
 
 @pytest.mark.parametrize("name", ["h256", "sem320x200", "tilt3_200x150", "persp_240x180", "ragged_dims", "vert_200x260",

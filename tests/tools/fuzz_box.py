@@ -15,6 +15,8 @@ import torch  # noqa: E402,F401
 from cybervision_amd import correlation, synth  # noqa: E402
 from oracle import cvref  # noqa: E402
 
+PERSPECTIVE = "--perspective" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--perspective"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 MAXDIM = int(sys.argv[3]) if len(sys.argv) > 3 else 420
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -30,6 +32,18 @@ for it in range(N):
         b = np.ascontiguousarray(np.pad(b, ((0, int(rng.integers(1, 20))), (0, int(rng.integers(1, 20)))), mode="edge"))
     proj = int(rng.integers(0, 2)) if abs(tilt) < 5 else 0
     F = synth.f_tilt(tilt) if tilt != 0.0 else synth.F_HORIZONTAL
+    if PERSPECTIVE:
+        # a true perspective F (per-pixel epipolar lines): mostly sideways (or, every third case, vertical) camera
+        # translation with small random rotations and a little motion along the optical axis
+        proj = 1
+        size = max(w, h)
+        K = np.array([[0.9 * size, 0.0, w / 2.0], [0.0, 0.9 * size, h / 2.0], [0.0, 0.0, 1.0]])
+        ang = rng.uniform(-0.004, 0.004, size=3) * float(rng.choice([0.2, 1.0, 3.0]))
+        R = synth._rot(*ang)
+        t = np.array([1.0, rng.uniform(-0.06, 0.06), rng.uniform(-0.03, 0.03)])
+        if it % 3 == 2:
+            t = t[[1, 0, 2]]
+        F = synth.sfm_true_f(K, (np.eye(3), np.zeros(3)), (R, t * 0.05))
     steps = synth.optimal_scale_steps(a.shape[1], a.shape[0])
     p1, p2 = synth.box_pyramid(a, steps), synth.box_pyramid(b, steps)
     want = cvref.correlate_dense(p1, p2, F, proj)
