@@ -325,6 +325,9 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
     } else if (v3 && !c->force_box) {
         v3 = f_major > 0.0 && f_minor <= 0.08 * f_major;
     }
+    // The first pass searches the whole line: its displacement boxes are wider than the box kernel's 61 steps, every
+    // workgroup would decline - straight to the candidate filter (one launch less on the latency-bound coarsest level).
+    if (first_pass && !c->force_box) v3 = false;
     if (v3) {
         plan.kind = PassPlan::BOX;
         plan.stepped = f_minor != 0.0 || c->force_box; // exactly axis-parallel lines never step: the leaner instantiation
