@@ -19,7 +19,8 @@
 // bit-identical to glibc.
 #include "cvhip_internal.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cmath>
 #include <vector>
@@ -702,12 +703,12 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     hipLaunchKernelGGL(harris_kernel, dim3((n_fast + 63) / 64), dim3(64), 0, s, d_img, w, h, d_kp, d_total, n_fast, k7,
                        d_keys, d_idx);
     size_t tmp_bytes = 0;
-    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_idx,
-                                                               d_idx_sorted, (int)n_fast, 0, 64, s));
+    CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx_sorted,
+                                                 (size_t)n_fast, 0u, 64u, s));
     uint8_t *d_tmp = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_tmp, tmp_bytes));
-    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx,
-                                                               d_idx_sorted, (int)n_fast, 0, 64, s));
+    CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx_sorted,
+                                                 (size_t)n_fast, 0u, 64u, s));
     const uint32_t count = std::min(n_fast, MAX_KEYPOINTS); // entries past the Some(...) ones carry idx = ~0
 
     // 3. blur of the original image, patch moments
@@ -810,12 +811,10 @@ extern "C" int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const 
     hipLaunchKernelGGL(iota_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, d_q, n1);
     // stable ascending sort by distance (sort_by_key, pointmatching.rs:74); unmatched = ~0 go last
     size_t tmp_bytes = 0;
-    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_bd, d_bd_sorted, d_q, d_q_sorted, (int)n1, 0,
-                                                     32, s));
+    CVHIP_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_bd, d_bd_sorted, d_q, d_q_sorted, (size_t)n1, 0u, 32u, s));
     uint8_t *d_tmp = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_tmp, tmp_bytes));
-    CVHIP_TRY_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_bd, d_bd_sorted, d_q, d_q_sorted, (int)n1, 0, 32,
-                                                     s));
+    CVHIP_TRY_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_bd, d_bd_sorted, d_q, d_q_sorted, (size_t)n1, 0u, 32u, s));
     hipLaunchKernelGGL(match_gather_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, d_q_sorted, d_bd_sorted, d_bj, d_xy1,
                        d_xy2, n1, d_om, d_od, d_n);
     uint32_t n = 0;

@@ -320,7 +320,9 @@ struct RansacBest {
 //  * matches are converted to f64 once per tile (LDS), and the division of reprojection_error is only executed where
 //    the inlier test is open: n^2 > t * den * (1 + 2^-40) implies n^2 / den > t in f64 whatever the roundings, so
 //    such a match is an outlier without dividing (non-finite cases fall through to the exact expression).
-__global__ __launch_bounds__(64) void ransac_score_kernel(const double *__restrict__ F, uint32_t H,
+constexpr int SCORE_BLOCK = 256; // hypotheses per workgroup: four waves share one staged tile of matches (32 KB), so five
+                                 // workgroups = 20 waves fit a CU (one wave per 32 KB tile left the SIMDs at 1 wave each)
+__global__ __launch_bounds__(SCORE_BLOCK) void ransac_score_kernel(const double *__restrict__ F, uint32_t H,
                                                            const uint4 *__restrict__ matches, uint32_t N, double t,
                                                            const uint32_t *__restrict__ live,
                                                            const uint32_t *__restrict__ n_live, uint32_t min_count,
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(const double *__restri
 {
     __shared__ double tile[RANSAC_TILE][4];
     const uint32_t n_hyp = n_live ? *n_live : H;
-    if (blockIdx.x * 64u >= n_hyp) return;
-    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * (uint32_t)SCORE_BLOCK >= n_hyp) return;
+    const uint32_t j = blockIdx.x * SCORE_BLOCK + threadIdx.x;
     const bool active = j < n_hyp;
     const uint32_t h = active ? (live ? live[j] : j) : 0u;
     double f[9];
@@ -347,9 +349,8 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(const double *__restri
         const uint32_t n = min((uint32_t)RANSAC_TILE, N - base);
         // count + (matches not yet seen) < bound: this hypothesis is out
         alive = alive && !(count + (N - base) < bound);
-        if (!__any(alive)) break;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += 64) {
+        if (!__syncthreads_or(alive ? 1 : 0)) break; // (also the barrier before the tile is overwritten)
+        for (uint32_t i = threadIdx.x; i < n; i += SCORE_BLOCK) {
             const uint4 m = matches[base + i];
             tile[i][0] = (double)m.x;
             tile[i][1] = (double)m.y;
@@ -431,7 +432,7 @@ void launch_ransac_score(const double *F, uint32_t H, const uint32_t *matches, u
                          uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
     if (!H) return;
-    hipLaunchKernelGGL(ransac_score_kernel, dim3((H + 63) / 64), dim3(64), 0, s, F, H,
+    hipLaunchKernelGGL(ransac_score_kernel, dim3((H + SCORE_BLOCK - 1) / SCORE_BLOCK), dim3(SCORE_BLOCK), 0, s, F, H,
                        reinterpret_cast<const uint4 *>(matches), N, t, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u,
                        (const RansacBest *)nullptr, out_count, out_err_sum);
 }
@@ -448,7 +449,7 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     hipLaunchKernelGGL(ransac_live_count_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, block_counts);
     launch_scan_u32(block_counts, nblocks, n_live, s);
     hipLaunchKernelGGL(ransac_live_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, (const uint32_t *)block_counts, live);
-    hipLaunchKernelGGL(ransac_score_kernel, dim3((H + 63) / 64), dim3(64), 0, s, F, H,
+    hipLaunchKernelGGL(ransac_score_kernel, dim3((H + SCORE_BLOCK - 1) / SCORE_BLOCK), dim3(SCORE_BLOCK), 0, s, F, H,
                        reinterpret_cast<const uint4 *>(matches), N, t, (const uint32_t *)live, (const uint32_t *)n_live, min_count,
                        best, out_count, out_err_sum);
 }

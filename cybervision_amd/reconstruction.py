@@ -59,6 +59,15 @@ class ImageReconstruction:
         steps = correlation.optimal_scale_steps(*dims(pyr1[0]))
         mode = correlation.ProjectionMode(int(self.projection_mode))
 
+        if out_xy is None and hasattr(pyr1[0], "data_ptr"):
+            # device-resident pyramids: the grid stays in HBM too (the next stage - triangulation, track extension -
+            # reads it there); a host copy is the caller's explicit choice (pass numpy outputs)
+            import torch
+
+            w, h = dims(pyr1[0])
+            out_xy = torch.empty((h, w, 2), dtype=torch.int32, device=pyr1[0].device)
+            out_corr = torch.empty((h, w), dtype=torch.float32, device=pyr1[0].device)
+
         def run():
             pc = correlation.PointCorrelations(self.device, dims(pyr1[0]), dims(pyr2[0]), f, mode)
             try:

@@ -451,6 +451,82 @@ def test_sharded_level_call_with_gather_hook(gpu_device, oracle):
         pc.close()
 
 
+def test_progress_callback_and_wide_sharding(gpu_device, oracle):
+    """(1) The progress hook (ProgressListener::report_status, gpu/mod.rs:241-249) is invoked synchronously with
+    values in [0, 1] that follow the reference's mapping (forward pass in the lower half, reverse in the upper), for
+    the per-pass calls and for the fused level call, and it does not change the result.  (2) Row sharding with more
+    shards than any test so far (den = 5, ragged bands) through the host hook on a private-stream device: the
+    library fences both sides of the hook itself."""
+    from cybervision_amd import sharding
+
+    c = cases.make_case("sem320x200")
+    p1, p2 = cases.pyramids(c)
+    want = run_oracle(oracle, c)
+    F, R = correlation.CorrelationDirection.Forward, correlation.CorrelationDirection.Reverse
+    for fused in (True, False):
+        seen = []
+        pc = correlation.PointCorrelations(gpu_device, (320, 200), (320, 200), c["F"])
+        try:
+            for i in range(c["steps"] + 1):
+                k = c["steps"] - i
+                pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), progress=seen.append, fused=fused)
+            assert_same_grid(pc.complete(F), want, f"progress fused={fused}")
+        finally:
+            pc.close()
+        assert len(seen) >= 3 * (c["steps"] + 1) and all(0.0 <= v <= 1.0 for v in seen)
+        assert any(v < 0.5 for v in seen) and any(v > 0.5 for v in seen) and max(seen) > 0.99
+    # den = 5 through the fused level call and the host hook, on this fixture's PRIVATE-stream device (the library
+    # fences both sides of the hook): rank r of 5 searches only its band; the hook supplies the other four bands from
+    # the level grids of an unsharded run captured after each search pass (what the other ranks would have sent)
+    import torch
+
+    ba, bb_, _ = synth.make_pair(640, 400, seed=13)
+    big = dict(img1=ba, img2=bb_, F=synth.f_tilt(0.5), projection=0, steps=synth.optimal_scale_steps(640, 400))
+    q1, q2 = cases.pyramids(big)
+    captured = {}
+    ref = correlation.PointCorrelations(gpu_device, (640, 400), (640, 400), big["F"])
+    try:
+        for i in range(big["steps"] + 1):
+            k = big["steps"] - i
+            s = 1.0 / float(1 << k)
+            for d, (a, b) in ((F, (q1[k], q2[k])), (R, (q2[k], q1[k]))):
+                ref.correlate_images_step(a, b, s, d)
+                g = ref.level_grid(d)
+                gpu_device.synchronize()
+                captured[(k, int(d))] = sharding.alias_bytes(g["cells"], g["lh"] * g["lw"] * 8, device=True).clone()
+            ref.cross_check_filter(s, F)
+            ref.cross_check_filter(s, R)
+            ref.first_pass = False
+    finally:
+        ref.close()
+    want_big = run_oracle(oracle, big)
+    for rank in (0, 3, 4):
+        pc = correlation.PointCorrelations(gpu_device, (640, 400), (640, 400), big["F"])
+        calls = []
+        try:
+            level = {"k": None}
+
+            def hook(cells_ptr, shard_bytes, n_shards, direction):
+                assert n_shards == 5
+                full = captured[(level["k"], direction)]
+                mine_lo, mine_hi = rank * shard_bytes, min((rank + 1) * shard_bytes, full.numel())
+                dst = sharding.alias_bytes(cells_ptr, full.numel(), device=True)
+                keep = dst[mine_lo:mine_hi].clone()          # this rank's own band stays what IT computed
+                dst.copy_(full)
+                dst[mine_lo:mine_hi].copy_(keep)
+                torch.cuda.synchronize()
+                calls.append((level["k"], direction))
+
+            pc.set_row_shard(rank, 5, hook)
+            for i in range(big["steps"] + 1):
+                level["k"] = big["steps"] - i
+                pc.correlate_images(q1[level["k"]], q2[level["k"]], 1.0 / float(1 << level["k"]))
+            assert_same_grid(pc.complete(F), want_big, f"rank {rank} of 5")
+        finally:
+            pc.close()
+        assert calls == [(0, 0), (0, 1)]  # only the full-resolution level has >= 64 rows per shard (400 // 5 = 80)
+
+
 @pytest.mark.parametrize("case,mode", [("persp_240x180", "gather"), ("tilt3_200x150", "band")])
 def test_two_rank_sharded_level_calls(case, mode):
     """End-to-end N = 2: two processes (sharing this box's one GPU) row-shard every search pass,

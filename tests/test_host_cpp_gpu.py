@@ -65,3 +65,35 @@ def test_cpp_host_pipeline(gpu_device, tmp_path):
     ys, xs = np.nonzero(valid)
     x2, y2 = want_xy[..., 0][valid], want_xy[..., 1][valid]
     assert (np.abs(x2 + d[y2, x2] - xs) <= 1).mean() > 0.95  # the disparity field is recovered
+
+
+def test_cpp_host_perspective_find_ransac(gpu_device, oracle, oracle_fm, tmp_path):
+    """FundamentalMatrix::new(Perspective, max_dimension).find_ransac through the C++ host layer: the planted
+    geometry is recovered, the returned inliers are exactly fits_model of the returned F (oracle arithmetic), and the
+    same seed through the one-call C entry (cvhip_find_ransac, what the Python mirror uses) gives the same F."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    import cases
+    from cybervision_amd import fundamentalmatrix
+
+    exe = tmp_path / "host_perspective"
+    lib_dir = ROOT / "cybervision_amd"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", str(exe), str(ROOT / "tests" / "cpp" / "host_perspective.cpp"),
+                           f"-L{lib_dir}", "-lcvhip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    m, truth, _, _ = cases.perspective_matches(n=4000, outlier_frac=0.3, seed=21)
+    m.tofile(tmp_path / "matches.bin")
+    res = subprocess.run([str(exe), str(tmp_path / "matches.bin"), str(len(m)), "2048", "17", str(tmp_path)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    F = np.fromfile(tmp_path / "f_persp.bin", dtype=np.float64).reshape(3, 3)
+    inl = np.fromfile(tmp_path / "inliers_persp.bin", dtype=np.uint32).reshape(-1, 4)
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+    mask = oracle_fm.fits_model(F, m, t)
+    assert info["inliers"] == len(inl) == int(mask.sum()) and (inl == m[mask]).all()
+    cnt, _ = oracle.ransac_score(F, m, t)
+    assert cnt[0] == len(inl)
+    assert F[2, 2] == 1.0 and (mask & truth).sum() > 0.97 * truth.sum() and (mask & ~truth).sum() < 0.1 * (~truth).sum()
+    F2, inl2, _ = fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Perspective, 2048.0).find_ransac(gpu_device, m, seed=17)
+    assert (F2 == F).all() and (inl2 == inl).all()

@@ -124,9 +124,10 @@ def test_sfm3_full_size_properties_2048(gpu_device, oracle_fm):
         m = e["matches"]
         true_in = oracle_fm.fits_model(F_true, m, t)
         assert true_in.sum() > 5000 and (oracle_fm.fits_model(F, m, t) & true_in).sum() > 0.97 * true_in.sum()
-        xy, corr = e["xy"], e["corr"]
         xy2, corr2 = rec.correlate_dense(dev_pyr[i], dev_pyr[j], F)
-        assert (xy == xy2).all() and (corr.view(np.uint32) == corr2.view(np.uint32)).all(), "dense stage not deterministic"
+        assert e["xy"].is_cuda  # device-resident pyramids -> device-resident grids
+        assert torch.equal(e["xy"], xy2) and torch.equal(e["corr"].view(torch.int32), corr2.view(torch.int32)), "dense stage not deterministic"
+        xy, corr = e["xy"].cpu().numpy(), e["corr"].cpu().numpy()
         valid = xy[..., 0] >= 0
         assert valid.mean() > 0.3, valid.mean()
         assert not valid[:5].any() and not valid[-5:].any() and not valid[:, :5].any() and not valid[:, -5:].any()
