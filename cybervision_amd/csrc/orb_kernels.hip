@@ -49,13 +49,27 @@ struct Taps11 {
 // ---------------------------------------------------------------------------------------------
 // adjust_contrast (orb.rs:455-472)
 // ---------------------------------------------------------------------------------------------
-__global__ void minmax_kernel(const uint8_t *__restrict__ img, size_t n, uint32_t *__restrict__ mm)
+// img is the library's own 4-byte-aligned copy: dword loads, four pixels per lane and load; one pair of atomics per
+// workgroup (a pair per wave from 2048 workgroups - 16 k atomics on two addresses - cost 120 us per image).
+__global__ __launch_bounds__(256) void minmax_kernel(const uint8_t *__restrict__ img, size_t n, uint32_t *__restrict__ mm)
 {
+    __shared__ uint32_t wlo[4], whi[4];
     uint32_t lo = 255, hi = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t v = img[i];
-        lo = min(lo, v);
-        hi = max(hi, v);
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x, gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t *__restrict__ words = reinterpret_cast<const uint32_t *>(img);
+    for (size_t i = gid; i < n4; i += stride) {
+        const uint32_t v = words[i];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t px = (v >> (8 * b)) & 0xFFu;
+            lo = min(lo, px);
+            hi = max(hi, px);
+        }
+    }
+    for (size_t i = (n4 << 2) + gid; i < n; i += stride) {
+        const uint32_t px = img[i];
+        lo = min(lo, px);
+        hi = max(hi, px);
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
@@ -63,8 +77,13 @@ __global__ void minmax_kernel(const uint8_t *__restrict__ img, size_t n, uint32_
         hi = max(hi, (uint32_t)__shfl_down(hi, s, 64));
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&mm[0], lo);
-        atomicMax(&mm[1], hi);
+        wlo[threadIdx.x >> 6] = lo;
+        whi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&mm[0], min(min(wlo[0], wlo[1]), min(wlo[2], wlo[3])));
+        atomicMax(&mm[1], max(max(whi[0], whi[1]), max(whi[2], whi[3])));
     }
 }
 
@@ -673,7 +692,7 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
 
     // 1. contrast stretch, FAST score, NMS, scan-ordered corner list
     const unsigned rblocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
-    hipLaunchKernelGGL(minmax_kernel, dim3(rblocks), dim3(256), 0, s, d_img, n, d_mm);
+    hipLaunchKernelGGL(minmax_kernel, dim3(std::min(rblocks, 512u)), dim3(256), 0, s, d_img, n, d_mm);
     hipLaunchKernelGGL(contrast_kernel, dim3(rblocks), dim3(256), 0, s, d_img, n, d_mm, d_adj);
     dim3 grid2d((w + 63) / 64, (h + 3) / 4);
     hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, d_adj, w, h, d_score);
