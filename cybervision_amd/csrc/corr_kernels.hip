@@ -1425,7 +1425,7 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 // waves along x, the packed 11-byte vectors are image ROWS - for column-major lines.  Below, u is the lane axis
 // and v the other one; S12 is the same integer either way.
 template <bool COUNT, bool STEP, bool TR>
-__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(SearchJob ja, SearchJob jb)
+__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 7) void search3_box_kernel(SearchJob ja, SearchJob jb)
 {
     const SearchJob &j = this_job(); // both directions of a level in one launch (see search_range_kernel)
     const CorrParams &p = j.p;
