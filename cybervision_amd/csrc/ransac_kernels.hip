@@ -37,29 +37,39 @@ constexpr int RANSAC_TILE = 1024; // matches per LDS tile (16 KiB as 4 x u32)
 // ---------------------------------------------------------------------------------------------------------
 namespace lm {
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CVHIP_LM_INLINE __attribute__((always_inline)) inline
+#else
+#define CVHIP_LM_INLINE inline
+#endif
+
 struct Obs { // one match as the two homogeneous points
     double p1[3], p2[3];
 };
 
-__host__ __device__ inline Obs make_obs(uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2)
+__host__ __device__ CVHIP_LM_INLINE Obs make_obs(uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2)
 {
     return Obs{{(double)x1, (double)y1, 1.0}, {(double)x2, (double)y2, 1.0}};
 }
 
 // dot product of two strided vectors (a column of the n x 7 Jacobian, or a plain vector)
-__host__ __device__ inline double long_dot(const double *a, uint32_t sa, const double *b, uint32_t sb, uint32_t n)
+__host__ __device__ CVHIP_LM_INLINE double long_dot(const double *a, uint32_t sa, const double *b, uint32_t sb, uint32_t n)
 {
     double part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     uint32_t i = 0;
-    for (; n - i >= 8; i += 8)
+    for (; n - i >= 8; i += 8) {
+#pragma unroll
         for (uint32_t k = 0; k < 8; k++) part[k] += a[(size_t)(i + k) * sa] * b[(size_t)(i + k) * sb];
+    }
     double total = 0.0;
+#pragma unroll
     for (uint32_t k = 0; k < 4; k++) total += part[k] + part[k + 4];
+#pragma unroll
     for (; i < n; i++) total += a[(size_t)i * sa] * b[(size_t)i * sb];
     return total;
 }
 
-__host__ __device__ inline void matrix_of(const double (&q)[7], double (&M)[9]) // f_from_perspective_params, :442-449
+__host__ __device__ CVHIP_LM_INLINE void matrix_of(const double (&q)[7], double (&M)[9]) // f_from_perspective_params, :442-449
 {
     const double last = -(-q[0] * q[4] + q[6] * q[2] * q[4] + q[3] * q[1] - q[6] * q[1] * q[5]) / (-q[3] * q[2] + q[0] * q[5]);
     for (int i = 0; i < 7; i++) M[i] = q[i];
@@ -68,18 +78,18 @@ __host__ __device__ inline void matrix_of(const double (&q)[7], double (&M)[9]) 
 }
 
 // row vector v' M and the chained product r . v, in nalgebra's orders
-__host__ __device__ inline void row_times(const double (&v)[3], const double (&M)[9], double (&out)[3])
+__host__ __device__ CVHIP_LM_INLINE void row_times(const double (&v)[3], const double (&M)[9], double (&out)[3])
 {
     for (int j = 0; j < 3; j++) out[j] = (v[0] * M[j] + v[1] * M[3 + j]) + v[2] * M[6 + j];
 }
-__host__ __device__ inline double chain3(const double (&r)[3], const double (&v)[3])
+__host__ __device__ CVHIP_LM_INLINE double chain3(const double (&r)[3], const double (&v)[3])
 {
     double acc = r[0] * v[0];
     acc = r[1] * v[1] + acc;
     return r[2] * v[2] + acc;
 }
 
-__host__ __device__ inline double residual_of(const double (&M)[9], const Obs &o) // reprojection_error, :461-471
+__host__ __device__ CVHIP_LM_INLINE double residual_of(const double (&M)[9], const Obs &o) // reprojection_error, :461-471
 {
     double r[3], mp1[3], mtp2[3];
     row_times(o.p2, M, r);
@@ -92,7 +102,7 @@ __host__ __device__ inline double residual_of(const double (&M)[9], const Obs &o
     return top * top / (mp1[0] * mp1[0] + mp1[1] * mp1[1] + mtp2[0] * mtp2[0] + mtp2[1] * mtp2[1]);
 }
 
-__host__ __device__ inline void gradient_of(const double (&M)[9], const Obs &o, double *out7) // f_jacobian, :473-512
+__host__ __device__ CVHIP_LM_INLINE void gradient_of(const double (&M)[9], const Obs &o, double *out7) // f_jacobian, :473-512
 {
     double mp1[3], mtp2[3];
     for (int i = 0; i < 3; i++) {
@@ -114,50 +124,78 @@ __host__ __device__ inline void gradient_of(const double (&M)[9], const Obs &o, 
     }
 }
 
-// (J'J + mu I) x = g, nalgebra's LU::new + LU::solve; false = "Failed to compute delta vector"
-__host__ __device__ inline bool solve7(double (&A)[49], double (&x)[7])
+// (J'J + mu I) x = g, nalgebra's LU::new + LU::solve; false = "Failed to compute delta vector".  Every index below
+// is a compile-time constant after unrolling (the pivot row is applied through per-row selects, not A[p]), so on the
+// device the whole system stays in registers.
+__host__ __device__ CVHIP_LM_INLINE bool solve7(double (&A)[49], double (&x)[7])
 {
     constexpr int n = 7;
-    int swap_a[n], swap_b[n], n_swaps = 0;
+    int perm[n]; // row exchanged with row c while eliminating column c (c itself = none), applied to x in that order
+#pragma unroll
     for (int c = 0; c < n; c++) {
         int p = c;
-        for (int r = c + 1; r < n; r++)
-            if (fabs(A[r * n + c]) > fabs(A[p * n + c])) p = r;
-        const double pivot = A[p * n + c];
-        if (pivot == 0.0) continue;
-        if (p != c) {
-            swap_a[n_swaps] = c;
-            swap_b[n_swaps++] = p;
-            for (int k = 0; k < n; k++) {
-                const double tmp = A[c * n + k];
-                A[c * n + k] = A[p * n + k];
-                A[p * n + k] = tmp;
+        double pivot = A[c * n + c], largest = fabs(pivot);
+#pragma unroll
+        for (int r = c + 1; r < n; r++) {
+            const double v = A[r * n + c];
+            if (fabs(v) > largest) {
+                largest = fabs(v);
+                pivot = v;
+                p = r;
             }
         }
+        perm[c] = c;
+        if (pivot == 0.0) continue;
+        perm[c] = p;
+#pragma unroll
+        for (int r = c + 1; r < n; r++)
+            if (r == p) {
+#pragma unroll
+                for (int k = 0; k < n; k++) {
+                    const double tmp = A[c * n + k];
+                    A[c * n + k] = A[r * n + k];
+                    A[r * n + k] = tmp;
+                }
+            }
         const double rp = 1.0 / pivot;
+#pragma unroll
         for (int r = c + 1; r < n; r++) A[r * n + c] *= rp;
+#pragma unroll
         for (int k = c + 1; k < n; k++) {
             const double top = A[c * n + k];
+#pragma unroll
             for (int r = c + 1; r < n; r++) A[r * n + k] = -top * A[r * n + c] + A[r * n + k];
         }
     }
-    for (int i = 0; i < n_swaps; i++) {
-        const double tmp = x[swap_a[i]];
-        x[swap_a[i]] = x[swap_b[i]];
-        x[swap_b[i]] = tmp;
+#pragma unroll
+    for (int c = 0; c < n; c++) {
+#pragma unroll
+        for (int r = c + 1; r < n; r++)
+            if (perm[c] == r) {
+                const double tmp = x[c];
+                x[c] = x[r];
+                x[r] = tmp;
+            }
     }
+#pragma unroll
     for (int c = 0; c < n; c++) {
         const double v = x[c];
+#pragma unroll
         for (int r = c + 1; r < n; r++) x[r] = -v * A[r * n + c] + x[r];
     }
+    bool regular = true;
+#pragma unroll
     for (int c = n - 1; c >= 0; c--) {
         const double pivot = A[c * n + c];
-        if (pivot == 0.0) return false;
-        const double v = x[c] / pivot;
-        x[c] = v;
-        for (int r = 0; r < c; r++) x[r] = -v * A[r * n + c] + x[r];
+        if (pivot == 0.0) regular = false;
+        if (regular) {
+            const double v = x[c] / pivot;
+            x[c] = v;
+#pragma unroll
+            for (int r = 0; r < c; r++) x[r] = -v * A[r * n + c] + x[r];
+        }
     }
-    return true;
+    return regular;
 }
 
 // descending singular values of a 3x3 matrix from the eigenvalues of M'M (Jacobi rotations); they are only
@@ -167,7 +205,12 @@ __host__ __device__ inline void singular3(const double (&M)[9], double (&sv)[3])
     double g[3][3];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) g[i][j] = M[i] * M[j] + M[3 + i] * M[3 + j] + M[6 + i] * M[6 + j];
-    for (int sweep = 0; sweep < 32 && (g[0][1] != 0.0 || g[0][2] != 0.0 || g[1][2] != 0.0); sweep++)
+    // cyclic Jacobi converges quadratically: a handful of sweeps take the off-diagonal part below 1e-20 of the diagonal,
+    // far beyond what a comparison with 1e-3 can see (waiting for EXACT zeros made every lane of a wave sit through
+    // up to 32 sweeps of two square roots and two divisions per rotation)
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = fabs(g[0][1]) + fabs(g[0][2]) + fabs(g[1][2]);
+        if (!(off > 1e-20 * (fabs(g[0][0]) + fabs(g[1][1]) + fabs(g[2][2])))) break;
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 if (g[p][q] == 0.0) continue;
@@ -185,6 +228,7 @@ __host__ __device__ inline void singular3(const double (&M)[9], double (&sv)[3])
                     g[q][k] = sn * u + cs * v;
                 }
             }
+    }
     double a = g[0][0], b = g[1][1], c = g[2][2];
     if (a < b) { const double t = a; a = b; b = t; }
     if (b < c) { const double t = b; b = c; c = t; }
@@ -194,22 +238,32 @@ __host__ __device__ inline void singular3(const double (&M)[9], double (&sv)[3])
     sv[2] = sqrt(c > 0.0 ? c : 0.0);
 }
 
-// least_squares (:515-621) on this problem; false = Err.  Workspace: r, r_new [n], J [n x 7].
-__host__ __device__ inline bool levenberg_marquardt(double (&q)[7], const Obs *obs, uint32_t n, double *r, double *r_new,
-                                                    double *J)
+// least_squares (:515-621) on this problem; false = Err.  Workspace: r, r_new [n], J [n x 7].  N = the number of
+// observations when it is known at compile time (validate_f's 7: every loop unrolls, every index is a constant and
+// the workspace lives in registers), 0 = n_obs at run time (the refit over the inliers).  Same statements either way.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed" // (the unroll requests are for N = 7; N = 0 has run-time trip counts)
+template <int N>
+__host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt(double (&q)[7], const Obs *obs, uint32_t n_obs, double *r,
+                                                             double *r_new, double *J)
 {
+    const uint32_t n = N > 0 ? (uint32_t)N : n_obs;
     double M[9], g[7];
     const auto evaluate = [&](const double (&at)[7], double *into) {
         matrix_of(at, M);
+#pragma unroll
         for (uint32_t i = 0; i < n; i++) into[i] = residual_of(M, obs[i]);
     };
     const auto linearise = [&](const double (&at)[7], const double *res) { // Jacobian and J'r at `at`
         matrix_of(at, M);
+#pragma unroll
         for (uint32_t i = 0; i < n; i++) gradient_of(M, obs[i], &J[(size_t)i * 7]);
+#pragma unroll
         for (int j = 0; j < 7; j++) g[j] = long_dot(J + j, 7, res, 1, n);
     };
     const auto largest = [](const double (&v)[7]) {
         double m = v[0];
+#pragma unroll
         for (int j = 1; j < 7; j++)
             if (m < v[j]) m = v[j];
         return m;
@@ -220,6 +274,7 @@ __host__ __device__ inline bool levenberg_marquardt(double (&q)[7], const Obs *o
     linearise(q, r);
     if (fabs(largest(g)) <= 1e-12) return true;
     double mu = 0.0;
+#pragma unroll
     for (int j = 0; j < 7; j++) {
         const double djj = long_dot(J + j, 7, J + j, 7, n);
         if (j == 0 || djj >= mu) mu = djj;
@@ -228,23 +283,32 @@ __host__ __device__ inline bool levenberg_marquardt(double (&q)[7], const Obs *o
     double nu = 2.0;
     for (int iteration = 0; iteration < 1000; iteration++) {
         double A[49];
-        for (int i = 0; i < 7; i++)
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+#pragma unroll
             for (int j = 0; j < 7; j++) A[i * 7 + j] = long_dot(J + i, 7, J + j, 7, n);
+        }
+#pragma unroll
         for (int i = 0; i < 7; i++) A[i * 7 + i] += mu;
         double step[7];
+#pragma unroll
         for (int j = 0; j < 7; j++) step[j] = g[j];
         if (!solve7(A, step)) return false;
         if (norm7(step) <= 1e-12 * (norm7(q) + 1e-12)) return true;
         double trial[7], damped[7];
+#pragma unroll
         for (int j = 0; j < 7; j++) trial[j] = q[j] + step[j];
         evaluate(trial, r_new);
         const double before = long_dot(r, 1, r, 1, n);
         const double after = long_dot(r_new, 1, r_new, 1, n);
+#pragma unroll
         for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + g[j];
         const double rho = (before - after) / long_dot(step, 1, damped, 1, 7);
         if (rho > 0.0) {
             const bool converged = sqrt(before) - sqrt(after) < 0.0 * sqrt(before);
+#pragma unroll
             for (uint32_t i = 0; i < n; i++) r[i] = r_new[i];
+#pragma unroll
             for (int j = 0; j < 7; j++) q[j] = trial[j];
             linearise(q, r);
             if (converged || fabs(largest(g)) <= 1e-12) return true;
@@ -259,6 +323,39 @@ __host__ __device__ inline bool levenberg_marquardt(double (&q)[7], const Obs *o
     }
     return false; // "Levenberg-Marquardt failed to converge"
 }
+#pragma clang diagnostic pop
+
+// The first thing least_squares does (:542-550) is test the gradient at the start: max(J'r) <= 1e-12 returns the
+// parameters unchanged.  For the 7 observations of validate_f this evaluates that test with the SAME operations in
+// the same order as levenberg_marquardt (r_i, row i of J, g_j = 0 + J_0j r_0 + J_1j r_1 + ... - long_dot's order for
+// n < 8) but without the r / J arrays: a 7-point solution has (nearly) zero residuals on its own sample, so on the
+// device this is all the LM ever does for ~all hypotheses, and it stays in registers.
+__host__ __device__ inline bool converged_at_start7(const double (&q)[7], const Obs *obs)
+{
+    double M[9], g[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    matrix_of(q, M);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const double ri = residual_of(M, obs[i]);
+        double row[7];
+        gradient_of(M, obs[i], row);
+#pragma unroll
+        for (int j = 0; j < 7; j++) g[j] += row[j] * ri;
+    }
+    double m = g[0];
+#pragma unroll
+    for (int j = 1; j < 7; j++)
+        if (m < g[j]) m = g[j];
+    return fabs(m) <= 1e-12;
+}
+
+// validate_f's call (n = 7), run by the device's LM kernel for the roots that fail the start test (it re-evaluates
+// the start: same values)
+__host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt7(double (&q)[7], const Obs *obs)
+{
+    double r[7], r_new[7], J[49];
+    return levenberg_marquardt<7>(q, obs, 7, r, r_new, J);
+}
 
 // optimize_perspective_f (:391-426): F (normalised by F[2][2]) -> out, false = None
 __host__ __device__ inline bool optimize_perspective_f(const double (&F)[9], const Obs *obs, uint32_t n, double *r,
@@ -266,7 +363,7 @@ __host__ __device__ inline bool optimize_perspective_f(const double (&F)[9], con
 {
     double q[7];
     for (int i = 0; i < 7; i++) q[i] = F[i]; // params_from_perspective_f, :429-440
-    if (!levenberg_marquardt(q, obs, n, r, r_new, J)) return false;
+    if (!levenberg_marquardt<0>(q, obs, n, r, r_new, J)) return false;
     matrix_of(q, out);
     const double Mt[9] = {out[0], out[3], out[6], out[1], out[4], out[7], out[2], out[5], out[8]};
     double s[3];
@@ -437,21 +534,174 @@ void launch_ransac_score(const double *F, uint32_t H, const uint32_t *matches, u
                        (const RansacBest *)nullptr, out_count, out_err_sum);
 }
 
-// one RANSAC round's scoring: only the live slots, abandoning what cannot reach the best of the previous rounds
+// ---------------------------------------------------------------------------------------------
+// One RANSAC round's scoring, parallel over hypotheses AND matches.  A round holds ~25 000 live hypotheses; one lane
+// per hypothesis folding 29 000 matches serially (ransac_score_kernel above, kept for cvhip_ransac_score, whose
+// contract is the ordered error sum of EVERY hypothesis) leaves the GPU at ~100 workgroups and bound by the latency
+// of one thread's loop.  The round needs less than that contract: Ord (:623-649) looks at the inlier COUNT first and
+// at the mean error only between hypotheses of equal count.  So:
+//   1. ransac_count_kernel - one WAVE per live hypothesis, its lanes striding over the matches; the inlier predicate
+//      is the same f64 expression as in the fold (order-free), the count a sum of ballots; a hypothesis that can no
+//      longer reach min_count or the best count of the previous rounds is abandoned (count 0).
+//   2. ransac_round_max_kernel - the largest count of the round and the list of hypotheses that have it.
+//   3. ransac_tied_sum_kernel - only for the hypotheses AT that maximum (usually one): the reference's fold, errors
+//      computed in parallel, added serially in match order - bit-equal to the serial kernel's sum.
+// Every other hypothesis loses on its count, so its error sum is never looked at (it is reported as 0).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool match_fits(const double (&f)[9], uint4 m, double t, double t_hi, double &err)
+{
+    const double p1x = (double)m.x, p1y = (double)m.y, p2x = (double)m.z, p2y = (double)m.w;
+    const double r0 = (p2x * f[0] + p2y * f[3]) + f[6];
+    const double r1 = (p2x * f[1] + p2y * f[4]) + f[7];
+    const double r2 = (p2x * f[2] + p2y * f[5]) + f[8];
+    double nn = r0 * p1x;
+    nn = r1 * p1y + nn;
+    nn = r2 + nn;
+    double a0 = f[0] * p1x;
+    a0 = f[1] * p1y + a0;
+    a0 = f[2] + a0;
+    double a1 = f[3] * p1x;
+    a1 = f[4] * p1y + a1;
+    a1 = f[5] + a1;
+    const double nominator = nn * nn;
+    const double denominator = a0 * a0 + a1 * a1 + r0 * r0 + r1 * r1;
+    err = 0.0;
+    if (nominator > t_hi * denominator) return false; // certainly err > t (see ransac_score_kernel)
+    err = nominator / denominator;
+    return fabs(err) < __builtin_inf() && !(fabs(err) > t); // fits_model, :452-458
+}
+
+__global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                            uint32_t N, double t, const uint32_t *__restrict__ live,
+                                                            const uint32_t *__restrict__ n_live, uint32_t min_count,
+                                                            const RansacBest *__restrict__ best,
+                                                            uint32_t *__restrict__ out_count,
+                                                            double *__restrict__ out_err_sum)
+{
+    const uint32_t n_hyp = *n_live, lane = threadIdx.x & 63;
+    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); // one wave per live hypothesis
+    if (j >= n_hyp) return;
+    const uint32_t h = live[j];
+    double f[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) f[i] = F[(size_t)h * 9 + i];
+    const uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
+    const double t_hi = t * (1.0 + 0x1p-40);
+    uint32_t count = 0;
+    bool alive = true;
+    for (uint32_t base = 0; base < N; base += 64) {
+        if (count + (N - base) < bound) { // this hypothesis is out, whatever the remaining matches do
+            alive = false;
+            break;
+        }
+        const uint32_t i = base + lane;
+        double err;
+        const bool in = i < N && match_fits(f, matches[i], t, t_hi, err);
+        count += (uint32_t)__popcll(__ballot(in));
+    }
+    if (lane == 0) {
+        out_count[h] = alive ? count : 0u;
+        out_err_sum[h] = 0.0;
+    }
+}
+
+constexpr uint32_t TIED_CAP = 4096; // hypotheses at the round's maximum count that get an ordered error sum (usually 1)
+
+// the round's largest count, and the list of the live hypotheses that have it: tied[0] = their number, then the slots
+__global__ __launch_bounds__(1024) void ransac_round_max_kernel(const uint32_t *__restrict__ counts,
+                                                                 const uint32_t *__restrict__ live,
+                                                                 const uint32_t *__restrict__ n_live, uint32_t min_count,
+                                                                 uint32_t *__restrict__ tied)
+{
+    __shared__ uint32_t wmax[16];
+    __shared__ uint32_t s_max, s_n;
+    uint32_t m = 0;
+    const uint32_t n_hyp = *n_live;
+    for (uint32_t j = threadIdx.x; j < n_hyp; j += 1024) m = max(m, counts[live[j]]);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_down(m, sft, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) m = max(m, wmax[w]);
+        s_max = m;
+        s_n = 0;
+    }
+    __syncthreads();
+    const uint32_t top = s_max;
+    if (top >= min_count && top > 0)
+        for (uint32_t j = threadIdx.x; j < n_hyp; j += 1024) {
+            const uint32_t h = live[j];
+            if (counts[h] == top) {
+                const uint32_t k = atomicAdd(&s_n, 1u);
+                if (k < TIED_CAP) tied[1 + k] = h;
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tied[0] = s_n; // > TIED_CAP (never seen): the sum kernel then scans the live list for counts == top itself
+        tied[1 + TIED_CAP] = top;
+    }
+}
+
+// The reference's fold for the hypotheses at the round's maximum: errors in parallel, added serially in match order
+// (an outlier contributes +0.0, which leaves the sum's bits unchanged: the sum is a sum of non-negative terms).
+__global__ __launch_bounds__(1024) void ransac_tied_sum_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                                uint32_t N, double t, const uint32_t *__restrict__ tied,
+                                                                const uint32_t *__restrict__ counts,
+                                                                const uint32_t *__restrict__ live,
+                                                                const uint32_t *__restrict__ n_live,
+                                                                double *__restrict__ out_err_sum)
+{
+    __shared__ double errs[1024];
+    const bool listed = tied[0] <= TIED_CAP;
+    const uint32_t n_items = listed ? tied[0] : *n_live, top = tied[1 + TIED_CAP];
+    for (uint32_t b = blockIdx.x; b < n_items; b += gridDim.x) {
+        const uint32_t h = listed ? tied[1 + b] : live[b];
+        if (!listed && counts[h] != top) continue; // (uniform per workgroup)
+        double f[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) f[i] = F[(size_t)h * 9 + i];
+        const double t_hi = t * (1.0 + 0x1p-40);
+        double sum = 0.0;
+        for (uint32_t base = 0; base < N; base += 1024) {
+            const uint32_t i = base + threadIdx.x;
+            double err = 0.0;
+            const bool in = i < N && match_fits(f, matches[i], t, t_hi, err);
+            __syncthreads();
+            errs[threadIdx.x] = in ? err : 0.0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+#pragma unroll 8
+                for (uint32_t q = 0; q < 1024; q++) sum += errs[q];
+            }
+        }
+        if (threadIdx.x == 0) out_err_sum[h] = sum;
+        __syncthreads();
+    }
+}
+
 static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
                                       uint32_t *live, uint32_t *n_live, uint32_t min_count, const RansacBest *best,
                                       uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
-    // scratch: the per-block counts live in out_err_sum's first words until the score kernel overwrites them
+    // scratch: the per-block counts live in out_err_sum's first words until the count kernel overwrites them; the
+    // round maximum sits behind the live count
     uint32_t *block_counts = reinterpret_cast<uint32_t *>(out_err_sum);
+    uint32_t *tied = n_live + 1; // [2 + TIED_CAP]: number, slots, the maximum itself
     const uint32_t nblocks = (H + 1023) / 1024;
+    const uint4 *m4 = reinterpret_cast<const uint4 *>(matches);
     (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
     hipLaunchKernelGGL(ransac_live_count_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, block_counts);
     launch_scan_u32(block_counts, nblocks, n_live, s);
     hipLaunchKernelGGL(ransac_live_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, (const uint32_t *)block_counts, live);
-    hipLaunchKernelGGL(ransac_score_kernel, dim3((H + SCORE_BLOCK - 1) / SCORE_BLOCK), dim3(SCORE_BLOCK), 0, s, F, H,
-                       reinterpret_cast<const uint4 *>(matches), N, t, (const uint32_t *)live, (const uint32_t *)n_live, min_count,
-                       best, out_count, out_err_sum);
+    // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 3) / 4), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
+                       (const uint32_t *)n_live, min_count, best, out_count, out_err_sum);
+    hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
+                       (const uint32_t *)n_live, min_count, tied);
+    hipLaunchKernelGGL(ransac_tied_sum_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied,
+                       (const uint32_t *)out_count, (const uint32_t *)live, (const uint32_t *)n_live, out_err_sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -656,7 +906,9 @@ __device__ int cubic_real_roots(double c0, double c1, double c2, double c3, doub
 }
 
 // -> number of candidate F's written (each normalised by F[2][2]); ok[k] tells which survived the checks
-__device__ int perspective_models_from_sample(const uint4 (&sm)[7], double t, double (&fout)[3][9], bool (&ok)[3])
+// The pencil of a sample: the two null vectors of the 7x9 system and the real roots of det(a n1 + (1 - a) n2) = 0
+// (:293-358); returns the number of roots.
+__device__ int perspective_pencil(const uint4 (&sm)[7], double (&n1)[9], double (&n2)[9], double (&roots)[3])
 {
     // M = A^T (9 x 7), fundamentalmatrix.rs:293-309; Householder QR, reflectors kept in place
     double M[9][7], beta[7];
@@ -696,7 +948,6 @@ __device__ int perspective_models_from_sample(const uint4 (&sm)[7], double t, do
         }
     }
     // null space of A = last two columns of Q = H0 H1 ... H6 applied to e7, e8
-    double n1[9], n2[9];
 #pragma unroll
     for (int r = 0; r < 9; r++) {
         n1[r] = r == 7 ? 1.0 : 0.0;
@@ -739,85 +990,91 @@ __device__ int perspective_models_from_sample(const uint4 (&sm)[7], double t, do
     const double c1 = d[0][0][1] - 2.0 * d[0][1][1] - 2.0 * d[1][0][1] + d[1][0][0] - 2.0 * d[1][1][0] + d[0][1][0] + 3.0 * d[1][1][1];
     const double c2 = d[1][1][0] + d[0][1][1] + d[1][0][1] - 3.0 * d[1][1][1];
     const double c3 = d[1][1][1];
-    ok[0] = ok[1] = ok[2] = false;
     if (!(fabs(c0) > 1e-300) || !(fabs(c0) < __builtin_inf())) return 0;
-    lm::Obs obs[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) obs[i] = lm::make_obs(sm[i].x, sm[i].y, sm[i].z, sm[i].w);
-    double roots[3];
-    const int nr = cubic_real_roots(c0, c1, c2, c3, roots);
-    for (int k = 0; k < nr; k++) {
-        const double a = roots[k];
-        double f[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) f[i] = a * n1[i] + (1.0 - a) * n2[i]; // :359
-        double sv[3];
-        {
-            const double ft[9] = {f[0], f[3], f[6], f[1], f[4], f[7], f[2], f[5], f[8]};
-            lm::singular3(ft, sv); // f.transpose().svd, :361
-        }
-        bool good = !(sv[1] < 0.001) && !(sv[2] > 0.001); // :362-366
-        // e1: null vector of F^T (last right singular vector of svd(F^T), :372-373) = normal of F's columns
-        double e1[3], best = -1.0;
-#pragma unroll
-        for (int pr = 0; pr < 3; pr++) {
-            const int ca = pr == 2 ? 1 : 0, cb = pr == 0 ? 1 : 2;
-            const double ax = f[0 + ca], ay = f[3 + ca], az = f[6 + ca], bx = f[0 + cb], by = f[3 + cb], bz = f[6 + cb];
-            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-            const double nn = cx * cx + cy * cy + cz * cz;
-            if (nn > best) {
-                best = nn;
-                e1[0] = cx;
-                e1[1] = cy;
-                e1[2] = cz;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 9; i++) fout[k][i] = f[i] / f[8]; // :369
-        // sign consistency (:374-383): s = sum over the seven points of (F x2) .* (e1 x x1), per component
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const double x1 = (double)sm[i].x, y1 = (double)sm[i].y, x2 = (double)sm[i].z, y2 = (double)sm[i].w;
-            const double l0 = e1[1] * 1.0 - e1[2] * y1, l1 = e1[2] * x1 - e1[0] * 1.0, l2 = e1[0] * y1 - e1[1] * x1;
-            const double g0 = fout[k][0] * x2 + fout[k][1] * y2 + fout[k][2], g1 = fout[k][3] * x2 + fout[k][4] * y2 + fout[k][5],
-                         g2 = fout[k][6] * x2 + fout[k][7] * y2 + fout[k][8];
-            s0 += g0 * l0;
-            s1 += g1 * l1;
-            s2 += g2 * l2;
-        }
-        good = good && ((s0 > 0.0 && s1 > 0.0 && s2 > 0.0) || (s0 < 0.0 && s1 < 0.0 && s2 < 0.0));
-#pragma unroll
-        for (int i = 0; i < 9; i++) good = good && fabs(fout[k][i]) < __builtin_inf(); // validate_f, :197-199
-        if (good) {
-            // validate_f, :201-205: optimize_perspective_f over the sample itself.  A 7-point solution has (nearly)
-            // zero reprojection error on its sample, so the LM loop almost always returns at its gradient test -
-            // but the hypothesis that goes on is f_from_perspective_params(params) (F[2][1] rebuilt from det = 0,
-            // F[2][2] = 1 exactly) and it has to pass the rank test on THAT matrix (:418-423).
-            double r[7], r_new[7], J[49], opt[9];
-            good = lm::optimize_perspective_f(fout[k], obs, 7, r, r_new, J, opt);
-#pragma unroll
-            for (int i = 0; i < 9; i++) fout[k][i] = opt[i];
-        }
-        if (good) {
-#pragma unroll
-            for (int i = 0; i < 7; i++) { // all sample points must fit, :206-209
-                const double err = reprojection_error(fout[k], (double)sm[i].x, (double)sm[i].y, (double)sm[i].z, (double)sm[i].w);
-                good = good && fabs(err) < __builtin_inf() && !(fabs(err) > t);
-            }
-        }
-        ok[k] = good;
-    }
-    return nr;
+    return cubic_real_roots(c0, c1, c2, c3, roots);
 }
 
-// three hypothesis slots per sample; slots without a surviving root hold NaN (they score 0 inliers).
+// One root of the pencil -> the normalised matrix validate_f receives, or false (:359-389 and validate_f :197-199):
+// rank test, normalisation, sign consistency, finiteness.
+__device__ bool perspective_root_matrix(const uint4 (&sm)[7], const double (&n1)[9], const double (&n2)[9], double a,
+                                        double (&fo)[9])
+{
+    double f[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) f[i] = a * n1[i] + (1.0 - a) * n2[i]; // :359
+    double sv[3];
+    {
+        const double ft[9] = {f[0], f[3], f[6], f[1], f[4], f[7], f[2], f[5], f[8]};
+        lm::singular3(ft, sv); // f.transpose().svd, :361
+    }
+    bool good = !(sv[1] < 0.001) && !(sv[2] > 0.001); // :362-366
+    // e1: null vector of F^T (last right singular vector of svd(F^T), :372-373) = normal of F's columns
+    double e1[3], best = -1.0;
+#pragma unroll
+    for (int pr = 0; pr < 3; pr++) {
+        const int ca = pr == 2 ? 1 : 0, cb = pr == 0 ? 1 : 2;
+        const double ax = f[0 + ca], ay = f[3 + ca], az = f[6 + ca], bx = f[0 + cb], by = f[3 + cb], bz = f[6 + cb];
+        const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+        const double nn = cx * cx + cy * cy + cz * cz;
+        if (nn > best) {
+            best = nn;
+            e1[0] = cx;
+            e1[1] = cy;
+            e1[2] = cz;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) fo[i] = f[i] / f[8]; // :369
+    // sign consistency (:374-383): s = sum over the seven points of (F x2) .* (e1 x x1), per component
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const double x1 = (double)sm[i].x, y1 = (double)sm[i].y, x2 = (double)sm[i].z, y2 = (double)sm[i].w;
+        const double l0 = e1[1] * 1.0 - e1[2] * y1, l1 = e1[2] * x1 - e1[0] * 1.0, l2 = e1[0] * y1 - e1[1] * x1;
+        const double g0 = fo[0] * x2 + fo[1] * y2 + fo[2], g1 = fo[3] * x2 + fo[4] * y2 + fo[5], g2 = fo[6] * x2 + fo[7] * y2 + fo[8];
+        s0 += g0 * l0;
+        s1 += g1 * l1;
+        s2 += g2 * l2;
+    }
+    good = good && ((s0 > 0.0 && s1 > 0.0 && s2 > 0.0) || (s0 < 0.0 && s1 < 0.0 && s2 < 0.0));
+#pragma unroll
+    for (int i = 0; i < 9; i++) good = good && fabs(fo[i]) < __builtin_inf(); // validate_f, :197-199
+    return good;
+}
+
+// The tail of validate_f once optimize_perspective_f's LM has returned parameters q (:412-423, :206-209): the hypothesis
+// that goes on is f_from_perspective_params(q) (F[2][1] rebuilt from det = 0, F[2][2] = 1 exactly); it has to pass the
+// rank test on THAT matrix, and all seven sample points must fit it.
+__device__ bool perspective_root_accept(const double (&q)[7], const uint4 (&sm)[7], double t, double (&fo)[9])
+{
+    lm::matrix_of(q, fo);
+    const double Mt[9] = {fo[0], fo[3], fo[6], fo[1], fo[4], fo[7], fo[2], fo[5], fo[8]};
+    double s[3];
+    lm::singular3(Mt, s);
+    bool good = !(fabs(s[1]) < 1e-3 || fabs(s[2]) > 1e-3); // :418-423
+#pragma unroll
+    for (int i = 0; i < 7; i++) { // all sample points must fit, :206-209
+        const double err = reprojection_error(fo, (double)sm[i].x, (double)sm[i].y, (double)sm[i].z, (double)sm[i].w);
+        good = good && fabs(err) < __builtin_inf() && !(fabs(err) > t);
+    }
+    return good;
+}
+
+// Hypothesis generation in two kernels: one thread per SAMPLE draws it and solves for the pencil (QR, cubic), one
+// thread per ROOT turns a root into a validated hypothesis - three times the parallelism for the expensive half, and
+// neither kernel has to hold the other's registers (as one kernel this was 512 VGPRs + 1 KB of scratch per thread at
+// one wave per SIMD: 1.4 ms per round).  Three hypothesis slots per sample; slots without a surviving root hold NaN.
 // sample_idx != nullptr: the caller's samples (7 match indices each) instead of choose_inliers (test hook).
-__global__ __launch_bounds__(64) void ransac_generate_perspective_kernel(const uint4 *__restrict__ matches, uint32_t limit,
-                                                                          double t, unsigned long long seed,
-                                                                          uint32_t round, uint32_t H,
-                                                                          const uint32_t *__restrict__ sample_idx,
-                                                                          double *__restrict__ F)
+struct PerspPencil {
+    uint4 sm[7];
+    double n1[9], n2[9], roots[3];
+    int nr, pad;
+};
+
+__global__ __launch_bounds__(64) void ransac_perspective_pencil_kernel(const uint4 *__restrict__ matches, uint32_t limit,
+                                                                        unsigned long long seed, uint32_t round, uint32_t H,
+                                                                        const uint32_t *__restrict__ sample_idx,
+                                                                        PerspPencil *__restrict__ pencils)
 {
     const uint32_t h = blockIdx.x * 64 + threadIdx.x;
     if (h >= H) return;
@@ -848,14 +1105,110 @@ __global__ __launch_bounds__(64) void ransac_generate_perspective_kernel(const u
             }
         }
     }
-    double f[3][9];
-    bool ok[3] = {false, false, false};
-    if (have == 7) perspective_models_from_sample(sm, t, f, ok);
+    PerspPencil &out = pencils[h];
+    double n1[9], n2[9], roots[3] = {0.0, 0.0, 0.0};
+    int nr = 0;
+    if (have == 7) nr = perspective_pencil(sm, n1, n2, roots);
+    out.nr = nr;
+    if (nr > 0) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) out.sm[i] = sm[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            out.n1[i] = n1[i];
+            out.n2[i] = n2[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) out.roots[i] = roots[i];
+    }
+}
+
+// validate_f's optimize_perspective_f over the sample itself (:201-205).  A 7-point solution has (nearly) zero
+// reprojection error on its own sample, so for ~92 % of the roots least_squares returns at its first test (the gradient
+// at the start) - those finish here.  The others (degenerate samples: gradients up to 1e11) run the full loop; a few
+// such lanes per wave used to hold every wave of this kernel for the whole loop, so they are queued instead and the
+// loop runs densely packed in ransac_perspective_lm_kernel.  queue[0] = count, queue[1 + i] = slot.
+__global__ __launch_bounds__(64) void ransac_perspective_root_kernel(const PerspPencil *__restrict__ pencils, uint32_t H,
+                                                                      double t, double *__restrict__ F,
+                                                                      uint32_t *__restrict__ queue)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x; // slot = sample * 3 + root
+    if (g >= 3u * H) return;
+    const uint32_t h = g / 3u, k = g - 3u * h;
+    const PerspPencil &pc = pencils[h];
+    double f[9];
+    bool ok = false, queued = false;
+    if ((int)k < pc.nr) {
+        uint4 sm[7];
+        double n1[9], n2[9];
+#pragma unroll
+        for (int i = 0; i < 7; i++) sm[i] = pc.sm[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            n1[i] = pc.n1[i];
+            n2[i] = pc.n2[i];
+        }
+        double fo[9];
+        if (perspective_root_matrix(sm, n1, n2, pc.roots[k], fo)) {
+            lm::Obs obs[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) obs[i] = lm::make_obs(sm[i].x, sm[i].y, sm[i].z, sm[i].w);
+            double q[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) q[i] = fo[i]; // params_from_perspective_f, :429-440
+            if (lm::converged_at_start7(q, obs)) {
+                ok = perspective_root_accept(q, sm, t, f);
+            } else {
+                queued = true;
+#pragma unroll
+                for (int i = 0; i < 7; i++) f[i] = q[i];
+                f[7] = f[8] = 0.0;
+            }
+        }
+    }
+    if (queued) queue[1u + atomicAdd(&queue[0], 1u)] = g;
     const double nan = __builtin_nan("");
 #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = (ok || queued) ? f[i] : nan;
+}
+
+// The queued roots: least_squares in full (lm::levenberg_marquardt, the same code the host refit runs), then the
+// same acceptance tail.  One thread per queued root; the slot's first seven doubles hold the start parameters.
+__global__ __launch_bounds__(64) void ransac_perspective_lm_kernel(const PerspPencil *__restrict__ pencils, double t,
+                                                                    double *__restrict__ F, const uint32_t *__restrict__ queue)
+{
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= queue[0]) return;
+    const uint32_t g = queue[1u + i];
+    const PerspPencil &pc = pencils[g / 3u];
+    uint4 sm[7];
+    lm::Obs obs[7];
+    double q[7], f[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) F[((size_t)h * 3 + k) * 9 + i] = ok[k] ? f[k][i] : nan;
+    for (int k = 0; k < 7; k++) {
+        sm[k] = pc.sm[k];
+        obs[k] = lm::make_obs(sm[k].x, sm[k].y, sm[k].z, sm[k].w);
+        q[k] = F[(size_t)g * 9 + k];
+    }
+    const bool ok = lm::levenberg_marquardt7(q, obs) && perspective_root_accept(q, sm, t, f);
+    const double nan = __builtin_nan("");
+#pragma unroll
+    for (int k = 0; k < 9; k++) F[(size_t)g * 9 + k] = ok ? f[k] : nan;
+}
+
+// queue: 1 + 3 H words
+static void launch_generate_perspective(const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round,
+                                        uint32_t H, const uint32_t *sample_idx, PerspPencil *pencils, uint32_t *queue, double *d_F,
+                                        hipStream_t s)
+{
+    (void)hipMemsetAsync(queue, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(ransac_perspective_pencil_kernel, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round, H, sample_idx,
+                       pencils);
+    hipLaunchKernelGGL(ransac_perspective_root_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, H, t,
+                       d_F, queue);
+    // sized for the worst case (every root queued); blocks beyond the count return at once
+    hipLaunchKernelGGL(ransac_perspective_lm_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, t, d_F,
+                       (const uint32_t *)queue);
 }
 
 // Ord for RansacIterationResult (fundamentalmatrix.rs:623-649)
@@ -1010,7 +1363,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     if (e == hipSuccess) e = hipMalloc(&d_best, sizeof(RansacBest));
     if (e == hipSuccess) e = hipMalloc(&d_mask, N);
     uint32_t *d_live = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)CHECK_INTERVAL + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)CHECK_INTERVAL + 4 + TIED_CAP) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     RansacBest h_best;
@@ -1071,28 +1424,50 @@ int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32
     RansacBest *d_best = nullptr;
     uint8_t *d_mask = nullptr;
     hipError_t e = hipMalloc(&d_m, (size_t)N * 16);
-    if (e == hipSuccess) e = hipMalloc(&d_F, (size_t)H * 9 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_F, 2 * (size_t)H * 9 * sizeof(double)); // two rounds' hypotheses
     if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)H * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&d_err, (size_t)H * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&d_best, sizeof(RansacBest));
     if (e == hipSuccess) e = hipMalloc(&d_mask, N);
     uint32_t *d_live = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)H + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)H + 4 + TIED_CAP) * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
+    // Two streams, two hypothesis buffers: round r + 1 is GENERATED (stream g; its samples depend on the seed and the
+    // round number only) while round r is SCORED (the handle's stream; the best-so-far chain lives there).  The
+    // generator's tail - a few long Levenberg-Marquardt loops on a handful of waves - then runs under the scoring
+    // kernels, which fill the rest of the chip.  An early exit discards at most one generated round.
+    hipStream_t g = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, uploaded = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&uploaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(uploaded, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(g, uploaded, 0);
+    if (e == hipSuccess && rounds > 0) {
+        generate(m4, 0u, 0, d_F, g);
+        e = hipEventRecord(ready[0], g);
+    }
     for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
-        generate(m4, round, d_F, s);
-        launch_ransac_score_round(d_F, H, d_m, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
-        hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, H, min_count, d_best);
-        e = hipGetLastError();
+        const int b = (int)(round & 1u);
+        double *F_round = d_F + (size_t)b * H * 9;
+        if (round + 1 < rounds) { // (round - 1, the last reader of the other buffer, was synchronised below)
+            generate(m4, round + 1, b ^ 1, d_F + (size_t)(b ^ 1) * H * 9, g);
+            e = hipEventRecord(ready[b ^ 1], g);
+        }
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
+        launch_ransac_score_round(F_round, H, d_m, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
+        hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, F_round, d_cnt, d_err, H, min_count, d_best);
+        if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (h_best.valid && h_best.matches_count > early_exit) break; // :135-141
     }
+    if (g) (void)hipStreamSynchronize(g); // a round generated ahead of an early exit, or of an error
     int rc = CVHIP_OK;
     if (e == hipSuccess && !h_best.valid) rc = fail(CVHIP_ERR_NO_MODEL, "No reliable matches found"); // :145
     if (e == hipSuccess && rc == CVHIP_OK) {
@@ -1116,6 +1491,10 @@ int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32
     (void)hipFree(d_best);
     (void)hipFree(d_mask);
     (void)hipFree(d_live);
+    for (int b = 0; b < 2; b++)
+        if (ready[b]) (void)hipEventDestroy(ready[b]);
+    if (uploaded) (void)hipEventDestroy(uploaded);
+    if (g) (void)hipStreamDestroy(g);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
     return rc;
 }
@@ -1135,13 +1514,19 @@ extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *match
     const double t = 10.0 / 1000.0 * max_dimension; // :23, :85
     const uint32_t limit = std::min(N, TOP_INLIERS);
     if (rounds == 0 || rounds > RANSAC_K / CHECK_INTERVAL) rounds = RANSAC_K / CHECK_INTERVAL;
-    return ransac_rounds(dev, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
-                         out_inlier_count, out_inlier_mask, "ransac_perspective",
-                         [&](const uint4 *m4, uint32_t round, double *d_F, hipStream_t s) {
-                             hipLaunchKernelGGL(ransac_generate_perspective_kernel, dim3((CHECK_INTERVAL + 63) / 64), dim3(64),
-                                                0, s, m4, limit, t, (unsigned long long)seed, round, CHECK_INTERVAL,
-                                                (const uint32_t *)nullptr, d_F);
-                         });
+    // per generated round (two are in flight, see ransac_rounds): the pencils, then the LM queue
+    const size_t gen_bytes = (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + ((1 + 3 * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256;
+    char *d_gen = nullptr;
+    CVHIP_TRY_HIP(hipMalloc(&d_gen, 2 * gen_bytes));
+    const int rc = ransac_rounds(dev, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
+                                 out_inlier_count, out_inlier_mask, "ransac_perspective",
+                                 [&](const uint4 *m4, uint32_t round, int buffer, double *d_F, hipStream_t s) {
+                                     PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
+                                     launch_generate_perspective(m4, limit, t, (unsigned long long)seed, round, CHECK_INTERVAL,
+                                                                 nullptr, pencils, (uint32_t *)(pencils + CHECK_INTERVAL), d_F, s);
+                                 });
+    (void)hipFree(d_gen); // (ransac_rounds has synchronised both streams)
+    return rc;
 }
 
 // Test hooks of the two generators: the models of B caller-chosen samples (`per` match indices each).
@@ -1181,11 +1566,18 @@ int models_of_samples(cvhip_device *dev, const uint32_t *matches, uint32_t N, co
 extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t *matches, uint32_t N,
                                                const uint32_t *sample_idx, uint32_t B, double t, double *out_F)
 {
-    return models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
-                             [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
-                                 hipLaunchKernelGGL(ransac_generate_perspective_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m4,
-                                                    N, t, 0ull, 0u, B, idx, d_F);
-                             });
+    if (!dev || B == 0) return models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
+                                                 [](const uint4 *, const uint32_t *, double *, hipStream_t) {});
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    PerspPencil *d_pencils = nullptr;
+    CVHIP_TRY_HIP(hipMalloc(&d_pencils, (size_t)B * sizeof(PerspPencil) + (1 + 3 * (size_t)B) * sizeof(uint32_t)));
+    uint32_t *d_queue = (uint32_t *)(d_pencils + B);
+    const int rc = models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
+                                     [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
+                                         launch_generate_perspective(m4, N, t, 0ull, 0u, B, idx, d_pencils, d_queue, d_F, s);
+                                     });
+    (void)hipFree(d_pencils); // (models_of_samples has synchronised the stream)
+    return rc;
 }
 
 extern "C" int cvhip_ransac_affine_models(cvhip_device *dev, const uint32_t *matches, uint32_t N,
