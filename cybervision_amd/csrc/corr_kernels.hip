@@ -1424,8 +1424,11 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 // of the displacement box is dx);  TR = true: the same kernel with the two image axes exchanged - lanes along y,
 // waves along x, the packed 11-byte vectors are image ROWS - for column-major lines.  Below, u is the lane axis
 // and v the other one; S12 is the same integer either way.
+// Launch bound of the lean instantiation: 6 waves/SIMD (76 VGPRs, no spill).  7 waves - what its 22.5 KB of LDS would
+// admit - was measured 1.8 % faster (5.89 vs 6.00 ms per 4096^2 pair) but only with 10 VGPRs spilled: 28 B of scratch
+// per lane x 54 M threads put +1.17 GB per step on the L2 write-back counter (whole step 3.0 -> 4.2 GB).  Not taken.
 template <bool COUNT, bool STEP, bool TR>
-__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 7) void search3_box_kernel(SearchJob ja, SearchJob jb)
+__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(SearchJob ja, SearchJob jb)
 {
     const SearchJob &j = this_job(); // both directions of a level in one launch (see search_range_kernel)
     const CorrParams &p = j.p;

@@ -502,6 +502,7 @@ void cvhip_device_destroy(cvhip_device *dev)
     }
     for (auto &b : dev->d.parked) free_buffer_set(b);
     dev->d.parked.clear();
+    if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
     delete dev;
 }
 

@@ -608,23 +608,6 @@ static bool dev_ptr(const void *p)
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
-// RAII bag of device allocations so every error path frees them
-struct DevAllocs {
-    std::vector<void *> ptrs;
-    ~DevAllocs()
-    {
-        for (void *p : ptrs) (void)hipFree(p);
-    }
-    template <typename T> hipError_t alloc(T **out, size_t count)
-    {
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
-        if (e == hipSuccess) ptrs.push_back(p);
-        *out = static_cast<T *>(p);
-        return e;
-    }
-};
-
 } // namespace cvhip
 
 using namespace cvhip;
@@ -647,7 +630,7 @@ extern "C" int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint3
     if (dw == 0 || dh == 0) return fail(CVHIP_ERR_INVALID, "image too small to halve");
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     hipStream_t s = dev->d.stream;
-    DevAllocs mem;
+    DevAllocs mem(dev->d);
     const bool s_dev = dev_ptr(src), d_dev = dev_ptr(dst);
     const uint8_t *d_src = src;
     uint8_t *d_dst = dst, *tmp = nullptr;
@@ -675,7 +658,7 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     hipStream_t s = dev->d.stream;
     const size_t n = (size_t)w * h;
-    DevAllocs mem;
+    DevAllocs mem(dev->d);
 
     uint8_t *d_img = nullptr, *d_adj = nullptr, *d_score = nullptr;
     uint32_t *d_mm = nullptr, *d_counts = nullptr, *d_total = nullptr;
@@ -805,7 +788,7 @@ extern "C" int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const 
     if (!xy1 || !desc1 || !xy2 || !desc2) return fail(CVHIP_ERR_INVALID, "null argument");
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     hipStream_t s = dev->d.stream;
-    DevAllocs mem;
+    DevAllocs mem(dev->d);
     uint32_t *d_xy1, *d_xy2, *d_desc1, *d_desc2, *d_bj, *d_bd, *d_bd_sorted, *d_q, *d_q_sorted, *d_om, *d_od, *d_n;
     CVHIP_TRY_HIP(mem.alloc(&d_xy1, (size_t)n1 * 2));
     CVHIP_TRY_HIP(mem.alloc(&d_xy2, (size_t)n2 * 2));

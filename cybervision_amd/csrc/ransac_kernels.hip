@@ -1413,7 +1413,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
 // Shared driver of the two RANSAC models: rounds of `per_round` samples x `slots` hypotheses each.
 namespace {
 template <typename Generate>
-int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
+int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
                   double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
                   uint8_t *out_inlier_mask, const char *what, Generate generate)
 {
@@ -1423,14 +1423,14 @@ int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32
     double *d_F = nullptr, *d_err = nullptr;
     RansacBest *d_best = nullptr;
     uint8_t *d_mask = nullptr;
-    hipError_t e = hipMalloc(&d_m, (size_t)N * 16);
-    if (e == hipSuccess) e = hipMalloc(&d_F, 2 * (size_t)H * 9 * sizeof(double)); // two rounds' hypotheses
-    if (e == hipSuccess) e = hipMalloc(&d_cnt, (size_t)H * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_err, (size_t)H * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&d_best, sizeof(RansacBest));
-    if (e == hipSuccess) e = hipMalloc(&d_mask, N);
+    hipError_t e = mem.alloc(&d_m, (size_t)N * 4);
+    if (e == hipSuccess) e = mem.alloc(&d_F, 2 * (size_t)H * 9); // two rounds' hypotheses
+    if (e == hipSuccess) e = mem.alloc(&d_cnt, (size_t)H);
+    if (e == hipSuccess) e = mem.alloc(&d_err, (size_t)H);
+    if (e == hipSuccess) e = mem.alloc(&d_best, 1);
+    if (e == hipSuccess) e = mem.alloc(&d_mask, N);
     uint32_t *d_live = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)H + 4 + TIED_CAP) * sizeof(uint32_t));
+    if (e == hipSuccess) e = mem.alloc(&d_live, (size_t)H + 4 + TIED_CAP);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
@@ -1484,13 +1484,6 @@ int ransac_rounds(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint32
             if (out_inlier_mask) std::memcpy(out_inlier_mask, h_mask.data(), N);
         }
     }
-    (void)hipFree(d_m);
-    (void)hipFree(d_F);
-    (void)hipFree(d_cnt);
-    (void)hipFree(d_err);
-    (void)hipFree(d_best);
-    (void)hipFree(d_mask);
-    (void)hipFree(d_live);
     for (int b = 0; b < 2; b++)
         if (ready[b]) (void)hipEventDestroy(ready[b]);
     if (uploaded) (void)hipEventDestroy(uploaded);
@@ -1516,16 +1509,16 @@ extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *match
     if (rounds == 0 || rounds > RANSAC_K / CHECK_INTERVAL) rounds = RANSAC_K / CHECK_INTERVAL;
     // per generated round (two are in flight, see ransac_rounds): the pencils, then the LM queue
     const size_t gen_bytes = (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + ((1 + 3 * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256;
+    DevAllocs mem(dev->d);
     char *d_gen = nullptr;
-    CVHIP_TRY_HIP(hipMalloc(&d_gen, 2 * gen_bytes));
-    const int rc = ransac_rounds(dev, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
+    CVHIP_TRY_HIP(mem.alloc(&d_gen, 2 * gen_bytes));
+    const int rc = ransac_rounds(dev, mem, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
                                  out_inlier_count, out_inlier_mask, "ransac_perspective",
                                  [&](const uint4 *m4, uint32_t round, int buffer, double *d_F, hipStream_t s) {
                                      PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
                                      launch_generate_perspective(m4, limit, t, (unsigned long long)seed, round, CHECK_INTERVAL,
                                                                  nullptr, pencils, (uint32_t *)(pencils + CHECK_INTERVAL), d_F, s);
                                  });
-    (void)hipFree(d_gen); // (ransac_rounds has synchronised both streams)
     return rc;
 }
 
