@@ -404,6 +404,8 @@ struct RansacBest {
     double best_error;
     uint32_t matches_count;
     uint32_t valid;
+    uint32_t err_known; // best_error has been computed (it is only ever needed to break a tie in matches_count)
+    uint32_t pad;
 };
 
 // The fold of validate_f (:210-216) for a batch of hypotheses, one lane per hypothesis.
@@ -646,22 +648,35 @@ __global__ __launch_bounds__(1024) void ransac_round_max_kernel(const uint32_t *
 
 // The reference's fold for the hypotheses at the round's maximum: errors in parallel, added serially in match order
 // (an outlier contributes +0.0, which leaves the sum's bits unchanged: the sum is a sum of non-negative terms).
+// Ord (:623-649) looks at the error only between hypotheses of EQUAL count, so the fold - 29 000 dependent f64
+// additions, ~0.25 ms - runs only when it can decide something: several hypotheses share the round's maximum, or the
+// maximum equals the count of the best hypothesis of the earlier rounds (whose own sum is then computed too, from
+// best->f, if it never was).  In every other round the kernel returns at once and the winner's error stays unknown.
+__device__ __forceinline__ bool ransac_round_needs_errors(const uint32_t *__restrict__ tied, const RansacBest *best)
+{
+    return tied[0] > 1u || (best->valid && tied[1 + TIED_CAP] == best->matches_count);
+}
 __global__ __launch_bounds__(1024) void ransac_tied_sum_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
                                                                 uint32_t N, double t, const uint32_t *__restrict__ tied,
                                                                 const uint32_t *__restrict__ counts,
                                                                 const uint32_t *__restrict__ live,
-                                                                const uint32_t *__restrict__ n_live,
+                                                                const uint32_t *__restrict__ n_live, RansacBest *best,
                                                                 double *__restrict__ out_err_sum)
 {
     __shared__ double errs[1024];
+    if (tied[0] == 0u || !ransac_round_needs_errors(tied, best)) return;
     const bool listed = tied[0] <= TIED_CAP;
     const uint32_t n_items = listed ? tied[0] : *n_live, top = tied[1 + TIED_CAP];
-    for (uint32_t b = blockIdx.x; b < n_items; b += gridDim.x) {
-        const uint32_t h = listed ? tied[1 + b] : live[b];
-        if (!listed && counts[h] != top) continue; // (uniform per workgroup)
+    // item n_items: the best hypothesis of the earlier rounds, when it ties with this round's maximum
+    const uint32_t n_all = n_items + ((best->valid && top == best->matches_count) ? 1u : 0u);
+    for (uint32_t b = blockIdx.x; b < n_all; b += gridDim.x) {
+        const bool carried = b == n_items;
+        if (carried && best->err_known) continue; // (only this workgroup writes err_known)
+        const uint32_t h = carried ? 0u : (listed ? tied[1 + b] : live[b]);
+        if (!carried && !listed && counts[h] != top) continue; // (uniform per workgroup)
         double f[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) f[i] = F[(size_t)h * 9 + i];
+        for (int i = 0; i < 9; i++) f[i] = carried ? best->f[i] : F[(size_t)h * 9 + i];
         const double t_hi = t * (1.0 + 0x1p-40);
         double sum = 0.0;
         for (uint32_t base = 0; base < N; base += 1024) {
@@ -676,13 +691,20 @@ __global__ __launch_bounds__(1024) void ransac_tied_sum_kernel(const double *__r
                 for (uint32_t q = 0; q < 1024; q++) sum += errs[q];
             }
         }
-        if (threadIdx.x == 0) out_err_sum[h] = sum;
+        if (threadIdx.x == 0) {
+            if (carried) {
+                best->best_error = sum / (double)best->matches_count;
+                best->err_known = 1u;
+            } else {
+                out_err_sum[h] = sum;
+            }
+        }
         __syncthreads();
     }
 }
 
 static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
-                                      uint32_t *live, uint32_t *n_live, uint32_t min_count, const RansacBest *best,
+                                      uint32_t *live, uint32_t *n_live, uint32_t min_count, RansacBest *best,
                                       uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
     // scratch: the per-block counts live in out_err_sum's first words until the count kernel overwrites them; the
@@ -697,11 +719,11 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     hipLaunchKernelGGL(ransac_live_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, (const uint32_t *)block_counts, live);
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
     hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 3) / 4), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
-                       (const uint32_t *)n_live, min_count, best, out_count, out_err_sum);
+                       (const uint32_t *)n_live, min_count, (const RansacBest *)best, out_count, out_err_sum);
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
     hipLaunchKernelGGL(ransac_tied_sum_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied,
-                       (const uint32_t *)out_count, (const uint32_t *)live, (const uint32_t *)n_live, out_err_sum);
+                       (const uint32_t *)out_count, (const uint32_t *)live, (const uint32_t *)n_live, best, out_err_sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1221,11 +1243,17 @@ __device__ __forceinline__ bool ransac_better(uint32_t ca, double ea, uint32_t c
     return ea < eb;
 }
 
+// `tied` (optional): the round's maximum list of ransac_round_max_kernel - tells whether this round's error sums were
+// computed (ransac_round_needs_errors); without it they are taken as given (cvhip_ransac_score-style full sums).
 __global__ __launch_bounds__(1024) void ransac_pick_best_kernel(const double *__restrict__ F,
                                                                  const uint32_t *__restrict__ counts,
                                                                  const double *__restrict__ err_sums, uint32_t H,
-                                                                 uint32_t min_count, RansacBest *__restrict__ best)
+                                                                 uint32_t min_count, const uint32_t *__restrict__ tied,
+                                                                 RansacBest *best)
 {
+    // (read before thread 0 updates *best below; every thread evaluates the same values)
+    const uint32_t errors_known = tied == nullptr || (tied[0] != 0u && ransac_round_needs_errors(tied, best)) ? 1u : 0u;
+    __syncthreads();
     __shared__ uint32_t s_cnt[1024];
     __shared__ double s_err[1024];
     __shared__ uint32_t s_idx[1024];
@@ -1263,6 +1291,7 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_kernel(const double *__
             best->matches_count = s_cnt[0];
             best->best_error = s_err[0];
             best->valid = 1;
+            best->err_known = errors_known;
         }
     }
 }
@@ -1376,7 +1405,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
         launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL, RANSAC_D + RANSAC_N, d_best,
                                   d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, CHECK_INTERVAL,
-                           RANSAC_D + RANSAC_N, d_best);
+                           RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1412,6 +1441,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
 
 // Shared driver of the two RANSAC models: rounds of `per_round` samples x `slots` hypotheses each.
 namespace {
+constexpr uint32_t GEN_DEPTH = 3; // hypothesis buffers: the round being scored + the two being generated
 template <typename Generate>
 int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
                   double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
@@ -1424,7 +1454,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     RansacBest *d_best = nullptr;
     uint8_t *d_mask = nullptr;
     hipError_t e = mem.alloc(&d_m, (size_t)N * 4);
-    if (e == hipSuccess) e = mem.alloc(&d_F, 2 * (size_t)H * 9); // two rounds' hypotheses
+    if (e == hipSuccess) e = mem.alloc(&d_F, GEN_DEPTH * (size_t)H * 9); // the hypotheses of the rounds in flight
     if (e == hipSuccess) e = mem.alloc(&d_cnt, (size_t)H);
     if (e == hipSuccess) e = mem.alloc(&d_err, (size_t)H);
     if (e == hipSuccess) e = mem.alloc(&d_best, 1);
@@ -1437,31 +1467,33 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
-    // Two streams, two hypothesis buffers: round r + 1 is GENERATED (stream g; its samples depend on the seed and the
-    // round number only) while round r is SCORED (the handle's stream; the best-so-far chain lives there).  The
-    // generator's tail - a few long Levenberg-Marquardt loops on a handful of waves - then runs under the scoring
-    // kernels, which fill the rest of the chip.  An early exit discards at most one generated round.
+    // Two streams, GEN_DEPTH hypothesis buffers: rounds r + 1 and r + 2 are GENERATED (stream g; samples depend on the
+    // seed and the round number only) while round r is SCORED (the handle's stream; the best-so-far chain lives
+    // there).  The generator's tail - a few long Levenberg-Marquardt loops on ~190 waves that need a whole SIMD's
+    // registers each - cannot get onto the chip while the counting kernel fills it; generated two rounds ahead, it is
+    // already queued when a counting kernel drains, starts in the gap that follows (ordered sums, best pick, the host's
+    // early-exit read) and finishes under the next counting kernel.  An early exit discards at most two generated rounds.
     hipStream_t g = nullptr;
-    hipEvent_t ready[2] = {nullptr, nullptr}, uploaded = nullptr;
+    hipEvent_t ready[GEN_DEPTH] = {}, uploaded = nullptr;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g, hipStreamNonBlocking);
-    for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming);
+    for (uint32_t b = 0; b < GEN_DEPTH && e == hipSuccess; b++) e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&uploaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(uploaded, s);
     if (e == hipSuccess) e = hipStreamWaitEvent(g, uploaded, 0);
-    if (e == hipSuccess && rounds > 0) {
-        generate(m4, 0u, 0, d_F, g);
-        e = hipEventRecord(ready[0], g);
-    }
+    const auto generate_round = [&](uint32_t r) { // into buffer r % GEN_DEPTH, whose last reader (round r - GEN_DEPTH) is done
+        const uint32_t b = r % GEN_DEPTH;
+        generate(m4, r, (int)b, d_F + (size_t)b * H * 9, g);
+        return hipEventRecord(ready[b], g);
+    };
+    for (uint32_t r = 0; r + 1 < GEN_DEPTH && r < rounds && e == hipSuccess; r++) e = generate_round(r);
     for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
-        const int b = (int)(round & 1u);
+        const uint32_t b = round % GEN_DEPTH;
         double *F_round = d_F + (size_t)b * H * 9;
-        if (round + 1 < rounds) { // (round - 1, the last reader of the other buffer, was synchronised below)
-            generate(m4, round + 1, b ^ 1, d_F + (size_t)(b ^ 1) * H * 9, g);
-            e = hipEventRecord(ready[b ^ 1], g);
-        }
+        if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1); // (round - 1 was synchronised below)
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
         launch_ransac_score_round(F_round, H, d_m, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
-        hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, F_round, d_cnt, d_err, H, min_count, d_best);
+        hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, F_round, d_cnt, d_err, H, min_count,
+                           (const uint32_t *)(d_live + H + 1), d_best);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1484,7 +1516,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
             if (out_inlier_mask) std::memcpy(out_inlier_mask, h_mask.data(), N);
         }
     }
-    for (int b = 0; b < 2; b++)
+    for (uint32_t b = 0; b < GEN_DEPTH; b++)
         if (ready[b]) (void)hipEventDestroy(ready[b]);
     if (uploaded) (void)hipEventDestroy(uploaded);
     if (g) (void)hipStreamDestroy(g);
@@ -1507,11 +1539,11 @@ extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *match
     const double t = 10.0 / 1000.0 * max_dimension; // :23, :85
     const uint32_t limit = std::min(N, TOP_INLIERS);
     if (rounds == 0 || rounds > RANSAC_K / CHECK_INTERVAL) rounds = RANSAC_K / CHECK_INTERVAL;
-    // per generated round (two are in flight, see ransac_rounds): the pencils, then the LM queue
+    // per generated round (GEN_DEPTH buffers, see ransac_rounds): the pencils, then the LM queue
     const size_t gen_bytes = (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + ((1 + 3 * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256;
     DevAllocs mem(dev->d);
     char *d_gen = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_gen, 2 * gen_bytes));
+    CVHIP_TRY_HIP(mem.alloc(&d_gen, GEN_DEPTH * gen_bytes));
     const int rc = ransac_rounds(dev, mem, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
                                  out_inlier_count, out_inlier_mask, "ransac_perspective",
                                  [&](const uint4 *m4, uint32_t round, int buffer, double *d_F, hipStream_t s) {
@@ -1603,6 +1635,262 @@ extern "C" int cvhip_optimize_perspective_f(const double *F, const uint32_t *mat
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// optimize_result's refit (:246) on the device.  lm::levenberg_marquardt above is one thread's loop; on ~19 000
+// inliers it costs the host 12 ms per pair (a third of config 5's RANSAC stage).  Here ONE workgroup runs the same
+// statements with the work inside each statement spread over its 1024 threads:
+//  * residuals and Jacobian rows are per observation (lm::residual_of / lm::gradient_of, unchanged);
+//  * every long_dot is evaluated by eight threads, one per partial sum of blas `dot` (indices k, k + 8, ... in
+//    order), then combined and given its tail by one thread exactly as long_dot does - the additions and their order
+//    are the serial function's, so the values are too;
+//  * the 7x7 system, norms, rho and the control flow are thread 0's (lm::solve7, same code), broadcast through LDS.
+// J'J is recomputed only when J changed (a rejected step leaves J, hence J'J before the damping term, as it was), and
+// the closing test's r.r is the `after` (accepted step) or `before` (rejected) that was just computed from the same
+// vector.  tests/test_orb_ransac_gpu.py compares the result with the host function bit for bit.
+// ---------------------------------------------------------------------------------------------------------
+namespace refit {
+constexpr int THREADS = 1024;
+constexpr int MAX_DOTS = 49;
+struct DotJob {
+    const double *a, *b;
+    uint32_t sa, sb;
+};
+struct Shared {
+    double q[7], g[7], A0[49], step[7], trial[7];
+    double parts[MAX_DOTS * 8], dotv[MAX_DOTS];
+    DotJob jobs[MAX_DOTS];
+    double mu, nu, rho;
+    int action;
+};
+enum { CONTINUE = 0, DONE_TRUE = 1, DONE_FALSE = 2, ACCEPT = 3, ACCEPT_CONVERGED = 4, REJECT = 5 };
+
+// sh.dotv[d] = lm::long_dot(jobs[d].a, sa, jobs[d].b, sb, n) for d < nd
+__device__ void dots(Shared &sh, int nd, uint32_t n)
+{
+    __syncthreads(); // jobs written, operands complete
+    const uint32_t n8 = n & ~7u;
+    for (int c = (int)threadIdx.x; c < nd * 8; c += THREADS) {
+        const DotJob jb = sh.jobs[c >> 3];
+        double part = 0.0;
+        uint32_t i = (uint32_t)(c & 7);
+        // (the chain of additions is serial; its operands are not - sixteen products' loads in flight at a time)
+        for (; i + 8u * 15u < n8; i += 8u * 16u) {
+            double prod[16];
+#pragma unroll
+            for (uint32_t u = 0; u < 16; u++) prod[u] = jb.a[(size_t)(i + 8u * u) * jb.sa] * jb.b[(size_t)(i + 8u * u) * jb.sb];
+#pragma unroll
+            for (uint32_t u = 0; u < 16; u++) part += prod[u];
+        }
+        for (; i < n8; i += 8) part += jb.a[(size_t)i * jb.sa] * jb.b[(size_t)i * jb.sb];
+        sh.parts[c] = part;
+    }
+    __syncthreads();
+    for (int d = (int)threadIdx.x; d < nd; d += THREADS) {
+        const DotJob jb = sh.jobs[d];
+        double total = 0.0;
+        for (uint32_t k = 0; k < 4; k++) total += sh.parts[d * 8 + k] + sh.parts[d * 8 + k + 4];
+        for (uint32_t i = n8; i < n; i++) total += jb.a[(size_t)i * jb.sa] * jb.b[(size_t)i * jb.sb];
+        sh.dotv[d] = total;
+    }
+    __syncthreads();
+}
+__device__ void evaluate(const double *at_lds, const uint4 *__restrict__ inl, uint32_t n, double *into)
+{
+    double at[7], M[9];
+    for (int i = 0; i < 7; i++) at[i] = at_lds[i];
+    lm::matrix_of(at, M);
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+        const uint4 m = inl[i];
+        into[i] = lm::residual_of(M, lm::make_obs(m.x, m.y, m.z, m.w));
+    }
+}
+// Jacobian at sh.q and g = J'res -> sh.g
+__device__ void linearise(Shared &sh, const uint4 *__restrict__ inl, uint32_t n, const double *res, double *J)
+{
+    double at[7], M[9];
+    for (int i = 0; i < 7; i++) at[i] = sh.q[i];
+    lm::matrix_of(at, M);
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+        const uint4 m = inl[i];
+        double row[7];
+        lm::gradient_of(M, lm::make_obs(m.x, m.y, m.z, m.w), row);
+        for (int j = 0; j < 7; j++) J[(size_t)i * 7 + j] = row[j];
+    }
+    if (threadIdx.x < 7) sh.jobs[threadIdx.x] = DotJob{J + threadIdx.x, res, 7u, 1u};
+    dots(sh, 7, n);
+    if (threadIdx.x < 7) sh.g[threadIdx.x] = sh.dotv[threadIdx.x];
+    __syncthreads();
+}
+__device__ void normal_matrix(Shared &sh, uint32_t n, const double *J)
+{
+    if (threadIdx.x < 49) sh.jobs[threadIdx.x] = DotJob{J + threadIdx.x / 7, J + threadIdx.x % 7, 7u, 7u};
+    dots(sh, 49, n);
+    if (threadIdx.x < 49) sh.A0[threadIdx.x] = sh.dotv[threadIdx.x];
+    __syncthreads();
+}
+__device__ double largest7(const double *v)
+{
+    double m = v[0];
+    for (int j = 1; j < 7; j++)
+        if (m < v[j]) m = v[j];
+    return m;
+}
+} // namespace refit
+
+// inl: the n inliers; r, r_new [n], J [n x 7]: workspace; F_in: the winner (F[8] = 1); F_out / refined as
+// cvhip_optimize_perspective_f
+__global__ __launch_bounds__(refit::THREADS) void ransac_refit_kernel(const uint4 *__restrict__ inl, uint32_t n, double *r,
+                                                                       double *r_new, double *J, const double *F_in,
+                                                                       double *F_out, int *refined)
+{
+    using namespace refit;
+    __shared__ Shared sh;
+    const bool lead = threadIdx.x == 0;
+    if (threadIdx.x < 7) sh.q[threadIdx.x] = F_in[threadIdx.x]; // params_from_perspective_f, :429-440
+    __syncthreads();
+    evaluate(sh.q, inl, n, r);
+    __syncthreads();
+    linearise(sh, inl, n, r, J);
+    bool found = false, failed = false;
+    if (fabs(largest7(sh.g)) <= 1e-12) found = true; // (every thread reads the same values)
+    if (!found) {
+        normal_matrix(sh, n, J);
+        if (lead) {
+            double mu = 0.0;
+            for (int j = 0; j < 7; j++) {
+                const double djj = sh.A0[j * 7 + j];
+                if (j == 0 || djj >= mu) mu = djj;
+            }
+            sh.mu = mu * 1e-3;
+            sh.nu = 2.0;
+        }
+        __syncthreads();
+        for (int iteration = 0; iteration < 1000 && !found && !failed; iteration++) {
+            if (lead) {
+                double A[49], step[7], q[7];
+                for (int i = 0; i < 49; i++) A[i] = sh.A0[i];
+                for (int i = 0; i < 7; i++) A[i * 7 + i] += sh.mu;
+                for (int j = 0; j < 7; j++) {
+                    step[j] = sh.g[j];
+                    q[j] = sh.q[j];
+                }
+                int action = CONTINUE;
+                if (!lm::solve7(A, step)) {
+                    action = DONE_FALSE;
+                } else if (sqrt(lm::long_dot(step, 1, step, 1, 7)) <= 1e-12 * (sqrt(lm::long_dot(q, 1, q, 1, 7)) + 1e-12)) {
+                    action = DONE_TRUE;
+                } else {
+                    for (int j = 0; j < 7; j++) {
+                        sh.step[j] = step[j];
+                        sh.trial[j] = q[j] + step[j];
+                    }
+                }
+                sh.action = action;
+            }
+            __syncthreads();
+            if (sh.action == DONE_FALSE) {
+                failed = true;
+                break;
+            }
+            if (sh.action == DONE_TRUE) {
+                found = true;
+                break;
+            }
+            evaluate(sh.trial, inl, n, r_new);
+            if (lead) {
+                sh.jobs[0] = DotJob{r, r, 1u, 1u};
+                sh.jobs[1] = DotJob{r_new, r_new, 1u, 1u};
+            }
+            dots(sh, 2, n);
+            if (lead) {
+                const double before = sh.dotv[0], after = sh.dotv[1];
+                double step[7], damped[7];
+                for (int j = 0; j < 7; j++) {
+                    step[j] = sh.step[j];
+                    damped[j] = step[j] * sh.mu + sh.g[j];
+                }
+                const double rho = (before - after) / lm::long_dot(step, 1, damped, 1, 7);
+                sh.rho = rho;
+                if (rho > 0.0) {
+                    const bool converged = sqrt(before) - sqrt(after) < 0.0 * sqrt(before);
+                    sh.action = converged ? ACCEPT_CONVERGED : ACCEPT;
+                    for (int j = 0; j < 7; j++) sh.q[j] = sh.trial[j];
+                } else {
+                    sh.mu *= sh.nu;
+                    sh.nu *= 2.0;
+                    sh.action = REJECT;
+                }
+            }
+            __syncthreads();
+            const int action = sh.action;
+            const double rr = action == REJECT ? sh.dotv[0] : sh.dotv[1]; // r.r of the vector r is NOW
+            if (action != REJECT) {
+                for (uint32_t i = threadIdx.x; i < n; i += THREADS) r[i] = r_new[i];
+                __syncthreads();
+                linearise(sh, inl, n, r, J);
+                if (action == ACCEPT_CONVERGED || fabs(largest7(sh.g)) <= 1e-12) {
+                    found = true;
+                    break;
+                }
+                normal_matrix(sh, n, J); // J changed: J'J for the next iteration
+                if (lead) {
+                    const double w = 2.0 * sh.rho - 1.0, shrink = 1.0 - w * w * w;
+                    sh.mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
+                    sh.nu = 2.0;
+                }
+                __syncthreads();
+            }
+            if (sqrt(rr) <= 1e-12) found = true;
+        }
+    }
+    if (lead) {
+        bool ok = found && !failed;
+        double M[9];
+        if (ok) {
+            double q[7];
+            for (int i = 0; i < 7; i++) q[i] = sh.q[i];
+            lm::matrix_of(q, M);
+            const double Mt[9] = {M[0], M[3], M[6], M[1], M[4], M[7], M[2], M[5], M[8]};
+            double sv[3];
+            lm::singular3(Mt, sv);
+            ok = !(fabs(sv[1]) < 1e-3 || fabs(sv[2]) > 1e-3); // :418-423
+        }
+        *refined = ok ? 1 : 0;
+        for (int k = 0; k < 9; k++) F_out[k] = ok ? M[k] : F_in[k]; // optimize_result: .unwrap_or(res.f), :246
+    }
+}
+
+extern "C" int cvhip_optimize_perspective_f_device(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t n,
+                                                   double *out_F, int *out_refined)
+{
+    if (!dev || !F || !out_F || !out_refined || (n && !matches)) return fail(CVHIP_ERR_INVALID, "cvhip_optimize_perspective_f_device: null argument");
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    DevAllocs mem(dev->d);
+    uint32_t *d_inl = nullptr;
+    double *d_r = nullptr, *d_rn = nullptr, *d_J = nullptr, *d_F = nullptr;
+    int *d_ref = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_inl, (size_t)n * 4));
+    CVHIP_TRY_HIP(mem.alloc(&d_r, n));
+    CVHIP_TRY_HIP(mem.alloc(&d_rn, n));
+    CVHIP_TRY_HIP(mem.alloc(&d_J, (size_t)n * 7));
+    CVHIP_TRY_HIP(mem.alloc(&d_F, 18));
+    CVHIP_TRY_HIP(mem.alloc(&d_ref, 1));
+    if (n) CVHIP_TRY_HIP(hipMemcpyAsync(d_inl, matches, (size_t)n * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_F, F, 9 * sizeof(double), dev_ptr(F) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ransac_refit_kernel, dim3(1), dim3(refit::THREADS), 0, s, reinterpret_cast<const uint4 *>(d_inl), n, d_r, d_rn,
+                       d_J, (const double *)d_F, d_F + 9, d_ref);
+    CVHIP_TRY_HIP(hipGetLastError());
+    double h_F[9];
+    int h_ref = 0;
+    CVHIP_TRY_HIP(hipMemcpyAsync(h_F, d_F + 9, sizeof(h_F), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(&h_ref, d_ref, sizeof(int), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    std::memcpy(out_F, h_F, sizeof(h_F));
+    *out_refined = h_ref;
+    return CVHIP_OK;
+}
+
 // fits_model (:452-458) of one F for every match: the inlier filter of optimize_result (:233-236, 248-254).
 extern "C" int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t N, double t,
                                 uint8_t *out_mask)
@@ -1663,7 +1951,7 @@ extern "C" int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32
         for (uint32_t i = 0; i < N; i++)
             if (mask[i]) inl.insert(inl.end(), hm + 4 * (size_t)i, hm + 4 * (size_t)i + 4);
         int refined = 0;
-        CVHIP_TRY(cvhip_optimize_perspective_f(F0, inl.data(), (uint32_t)(inl.size() / 4), out_F, &refined)); // :246
+        CVHIP_TRY(cvhip_optimize_perspective_f_device(dev, F0, inl.data(), (uint32_t)(inl.size() / 4), out_F, &refined)); // :246
         // :248-254 - the inliers of the refitted matrix (of F0 itself where the refit returned None)
         const double t = 10.0 / 1000.0 * max_dimension;
         uint32_t n_in = 0;

@@ -69,6 +69,18 @@ def optimize_perspective_f(F, inliers):
     return out.reshape(3, 3) if refined.value else None
 
 
+def optimize_perspective_f_device(device, F, inliers):
+    """The same refit on the device (cvhip_optimize_perspective_f_device) - what cvhip_find_ransac uses; equal to
+    optimize_perspective_f bit for bit."""
+    F = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(9))
+    m = _matches(inliers)
+    out = np.zeros(9, dtype=np.float64)
+    refined = C.c_int(0)
+    _lib.check(_lib.lib().cvhip_optimize_perspective_f_device(device.handle, _p(F), _p(m), len(m), _p(out), C.byref(refined)),
+               "cvhip_optimize_perspective_f_device")
+    return out.reshape(3, 3) if refined.value else None
+
+
 def perspective_models_device(device, matches, sample_idx, t: float):
     """cvhip_ransac_perspective_models: the device generator + validate_f's per-hypothesis checks on caller-chosen
     samples [B, 7] -> F [B, 3, 3, 3] (NaN where a root does not exist or is rejected)."""

@@ -332,8 +332,8 @@ int cvhip_ransac_affine_models(cvhip_device *dev, const uint32_t *matches, uint3
 int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t N, double t, uint8_t *out_mask);
 /* FundamentalMatrix::new(projection, max_dimension).find_ransac(matches) in one call (fundamentalmatrix.rs:72-147
  * and optimize_result :231-257): cvhip_ransac_affine for projection 0 (max_dimension unused); for projection 1
- * cvhip_ransac_perspective, then the LM refit of the winner on its inliers (cvhip_optimize_perspective_f, host
- * arithmetic as in the reference) and the inliers of the refitted matrix.  This is what reconstruction.rs:502-526
+ * cvhip_ransac_perspective, then the LM refit of the winner on its inliers (cvhip_optimize_perspective_f_device: the
+ * reference's loop, values equal to the host function's) and the inliers of the refitted matrix.  This is what reconstruction.rs:502-526
  * calls.  out_F: 9 doubles row-major; out_inlier_mask: N bytes (may be NULL). */
 int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32_t *matches, uint32_t N, double max_dimension,
                       uint64_t seed, double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask);
@@ -346,6 +346,13 @@ int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32_t *matches
  * method (see the implementation's header); it is deterministic, so the oracle's restatement is compared
  * value for value. */
 int cvhip_optimize_perspective_f(const double *F, const uint32_t *matches, uint32_t n, double *out_F, int *out_refined);
+/* The same function on the device - what cvhip_find_ransac uses: one workgroup runs the loop's statements with the
+ * per-observation work spread over its threads and every long dot product evaluated by eight threads, one per
+ * partial sum of the reference's `dot`, so additions happen in the serial function's order and the result equals
+ * cvhip_optimize_perspective_f's bit for bit (tested).  ~19 000 inliers: 12 ms on the host, well under 1 ms here.
+ * F, matches: host or device pointers; out_F (9 doubles), out_refined: host. */
+int cvhip_optimize_perspective_f_device(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t n,
+                                        double *out_F, int *out_refined);
 
 #ifdef __cplusplus
 }

@@ -295,6 +295,42 @@ def test_device_perspective_ransac_recovers_planted_geometry(gpu_device, oracle,
     assert ei.value.code == -5 and "Not enough matches" in str(ei.value)
 
 
+def test_device_refit_equals_host_refit_bit_for_bit(gpu_device, oracle):
+    """cvhip_optimize_perspective_f_device (one workgroup, eight threads per long dot product) against
+    cvhip_optimize_perspective_f (one host thread) and the oracle: same loop, same accumulation order -> same bits.
+    Inlier counts around the multiples of 8 (the partial-sum blocks and their tail), a start the loop accepts steps
+    from, a start it returns at once, and a degenerate one (None)."""
+    import cases
+
+    m, truth, _, _ = cases.perspective_matches(n=3000, outlier_frac=0.2)
+    F0, mask0 = fundamentalmatrix.find_ransac_perspective_device(gpu_device, m, 2048.0, seed=9, rounds=1, refit=False)
+    inl = m[mask0]
+    assert len(inl) > 1500
+    rng = np.random.default_rng(4)
+    starts = [F0]
+    for scale in (1e-3, 3e-2):  # perturbed starts: several accepted and rejected steps before the loop ends
+        P = F0 * (1.0 + scale * rng.standard_normal((3, 3)))
+        starts.append(P / P[2, 2])
+    refined_some = False
+    for F in starts:
+        for n in (len(inl), 1024, 1001, 808, 807, 801, 64, 15, 8, 7):
+            host = fundamentalmatrix.optimize_perspective_f(F, inl[:n])
+            dev = fundamentalmatrix.optimize_perspective_f_device(gpu_device, F, inl[:n])
+            assert (host is None) == (dev is None), (n, host, dev)
+            if host is not None:
+                refined_some = True
+                assert (host.view(np.uint64) == dev.view(np.uint64)).all(), (n, host - dev)
+    assert refined_some
+    want = oracle.optimize_perspective_f(F0, inl)
+    got = fundamentalmatrix.optimize_perspective_f_device(gpu_device, F0, inl)
+    assert (want is None) == (got is None) and (want is None or (want == got).all())
+    # degenerate start: rank test / solve failure -> None on both
+    Z = np.zeros((3, 3))
+    Z[2, 2] = 1.0
+    assert fundamentalmatrix.optimize_perspective_f(Z, inl[:50]) is None
+    assert fundamentalmatrix.optimize_perspective_f_device(gpu_device, Z, inl[:50]) is None
+
+
 def test_device_affine_ransac_error_reporting(gpu_device):
     from cybervision_amd._lib import CvhipError
 
