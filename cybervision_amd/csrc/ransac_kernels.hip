@@ -573,10 +573,47 @@ __device__ __forceinline__ bool match_fits(const double (&f)[9], uint4 m, double
     return fabs(err) < __builtin_inf() && !(fabs(err) > t); // fits_model, :452-458
 }
 
+// Largest coordinate of the match list (one word, once per call): the scale of the f32 screen's error bounds.
+__global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__restrict__ matches, uint32_t N,
+                                                                 uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t wmax[16];
+    uint32_t m = 1u;
+    for (uint32_t i = threadIdx.x; i < N; i += 1024) {
+        const uint4 v = matches[i];
+        m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_down(m, sft, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) m = max(m, wmax[w]);
+        *out = m;
+    }
+}
+
+// The counting kernel decides most (hypothesis, match) pairs in PACKED f32 - two matches per lane and instruction,
+// fused multiply-adds allowed because nothing here is a result: the f32 value of n and of the denominator come with
+// rigorous error bounds (below), "certainly an inlier" / "certainly not" are decided against those, and only a pair
+// that falls inside the guard band (~1e-4 of them) is evaluated with the reference's f64 expression (match_fits).
+// The count is therefore exactly the f64 count.
+// Bounds (u = 2^-24; W = largest coordinate; |f| = the f64 coefficients' magnitudes, their f32 copies add one u):
+//   r_j, a_j: three terms, two fmas + the coefficient rounding: |error| <= 4u * T_j,  T_j = (|f|+|f|) W + |f| >= |value|
+//   n = r0 x + r1 y + r2: the operands' errors times W plus three roundings: E_n = 7u (T_r0 W + T_r1 W + T_r2)
+//   den = a0^2 + a1^2 + r0^2 + r1^2 (non-negative terms): |t^2 - t_exact^2| <= E_t (2|t| + E_t) per term,
+//     E_den = 8 E_max T_max + 4 E_max^2 absolute, plus 5u relative (roundings of a positive sum) - the relative part,
+//     the roundings of the comparison itself and the f64 expression's own 2^-53 errors sit inside the 2^-18 shave of t
+//     and the 0.1 % inflation of E_n, E_den.
+// A hypothesis with non-finite, tiny or huge coefficients is not screened at all (its pairs all take the f64 path).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
                                                             uint32_t N, double t, const uint32_t *__restrict__ live,
                                                             const uint32_t *__restrict__ n_live, uint32_t min_count,
                                                             const RansacBest *__restrict__ best,
+                                                            const uint32_t *__restrict__ coord_max,
                                                             uint32_t *__restrict__ out_count,
                                                             double *__restrict__ out_err_sum)
 {
@@ -589,17 +626,66 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     for (int i = 0; i < 9; i++) f[i] = F[(size_t)h * 9 + i];
     const uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
     const double t_hi = t * (1.0 + 0x1p-40);
+    // the screen's constants (wave-uniform)
+    const double W = (double)*coord_max, u = 0x1p-24;
+    double af[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) af[i] = fabs(f[i]);
+    const double Tr0 = (af[0] + af[3]) * W + af[6], Tr1 = (af[1] + af[4]) * W + af[7], Tr2 = (af[2] + af[5]) * W + af[8];
+    const double Ta0 = (af[0] + af[1]) * W + af[2], Ta1 = (af[3] + af[4]) * W + af[5];
+    const double Tmax = fmax(fmax(Tr0, Tr1), fmax(Ta0, Ta1)), Emax = 4.0 * u * Tmax;
+    const double En_d = 1.001 * 7.0 * u * (Tr0 * W + Tr1 * W + Tr2), Eden_d = 1.001 * (8.0 * Emax * Tmax + 4.0 * Emax * Emax);
+    // (as f32, rounded up by one more 2^-20; a bound beyond f32's comfortable range switches the screen off)
+    const float En = (float)(En_d * (1.0 + 0x1p-20)), Eden = (float)(Eden_d * (1.0 + 0x1p-20));
+    // the screen runs only where every bound and every product it is compared with stays a NORMAL f32 number
+    // (E_den >= 32u Tmax^2 >= 2e-18, times t >= 1e-6; squares below 1e31); false for NaN / inf coefficients too
+    const bool screen = Tmax >= 1e-6 && Tmax * W <= 1e12 && Tr2 <= 1e12 && t >= 1e-6 && t <= 1e12;
+    const float T_out = (float)(t * (1.0 + 0x1p-18)), T_in = (float)(t * (1.0 - 0x1p-18));
+    float ff[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) ff[i] = (float)f[i];
+    const auto bc = [](float v) { return v2f{v, v}; };
+
     uint32_t count = 0;
     bool alive = true;
-    for (uint32_t base = 0; base < N; base += 64) {
+    for (uint32_t base = 0; base < N; base += 128) {
         if (count + (N - base) < bound) { // this hypothesis is out, whatever the remaining matches do
             alive = false;
             break;
         }
-        const uint32_t i = base + lane;
-        double err;
-        const bool in = i < N && match_fits(f, matches[i], t, t_hi, err);
-        count += (uint32_t)__popcll(__ballot(in));
+        const uint32_t ia = base + lane, ib = base + 64 + lane;
+        const bool va = ia < N, vb = ib < N;
+        const uint4 ma = matches[va ? ia : 0u], mb = matches[vb ? ib : 0u];
+        bool in_a = false, in_b = false, open_a = va, open_b = vb;
+        if (screen) {
+            const v2f p1x = {(float)ma.x, (float)mb.x}, p1y = {(float)ma.y, (float)mb.y};
+            const v2f p2x = {(float)ma.z, (float)mb.z}, p2y = {(float)ma.w, (float)mb.w};
+            const v2f r0 = pk_fma(p2x, bc(ff[0]), pk_fma(p2y, bc(ff[3]), bc(ff[6])));
+            const v2f r1 = pk_fma(p2x, bc(ff[1]), pk_fma(p2y, bc(ff[4]), bc(ff[7])));
+            const v2f r2 = pk_fma(p2x, bc(ff[2]), pk_fma(p2y, bc(ff[5]), bc(ff[8])));
+            const v2f nn = pk_fma(r0, p1x, pk_fma(r1, p1y, r2));
+            const v2f a0 = pk_fma(p1x, bc(ff[0]), pk_fma(p1y, bc(ff[1]), bc(ff[2])));
+            const v2f a1 = pk_fma(p1x, bc(ff[3]), pk_fma(p1y, bc(ff[4]), bc(ff[5])));
+            const v2f den = pk_fma(a0, a0, pk_fma(a1, a1, pk_fma(r0, r0, r1 * r1)));
+            const v2f an = __builtin_elementwise_abs(nn);
+            const v2f lo = __builtin_elementwise_max(an - bc(En), bc(0.0f)), hi = an + bc(En);
+            const v2f lhs_out = lo * lo, rhs_out = bc(T_out) * (den + bc(Eden));
+            const v2f den_lo = den - bc(Eden);
+            const v2f lhs_in = hi * hi, rhs_in = bc(T_in) * den_lo;
+            // (comparisons with NaN are false: such a pair stays open)
+            const bool out_a = lhs_out.x > rhs_out.x, out_b = lhs_out.y > rhs_out.y;
+            const bool sure_a = den_lo.x > 0.0f && lhs_in.x <= rhs_in.x, sure_b = den_lo.y > 0.0f && lhs_in.y <= rhs_in.y;
+            in_a = va && sure_a;
+            in_b = vb && sure_b;
+            open_a = va && !sure_a && !out_a;
+            open_b = vb && !sure_b && !out_b;
+        }
+        if (__builtin_amdgcn_ballot_w64(open_a || open_b) != 0ull) { // rare (never, when the screen is off: always)
+            double err;
+            if (open_a) in_a = match_fits(f, ma, t, t_hi, err);
+            if (open_b) in_b = match_fits(f, mb, t, t_hi, err);
+        }
+        count += (uint32_t)__popcll(__ballot(in_a)) + (uint32_t)__popcll(__ballot(in_b));
     }
     if (lane == 0) {
         out_count[h] = alive ? count : 0u;
@@ -710,7 +796,7 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     // scratch: the per-block counts live in out_err_sum's first words until the count kernel overwrites them; the
     // round maximum sits behind the live count
     uint32_t *block_counts = reinterpret_cast<uint32_t *>(out_err_sum);
-    uint32_t *tied = n_live + 1; // [2 + TIED_CAP]: number, slots, the maximum itself
+    uint32_t *tied = n_live + 1; // [2 + TIED_CAP]: number, slots, the maximum itself; then one word: the largest coordinate
     const uint32_t nblocks = (H + 1023) / 1024;
     const uint4 *m4 = reinterpret_cast<const uint4 *>(matches);
     (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
@@ -719,7 +805,8 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     hipLaunchKernelGGL(ransac_live_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, (const uint32_t *)block_counts, live);
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
     hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 3) / 4), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
-                       (const uint32_t *)n_live, min_count, (const RansacBest *)best, out_count, out_err_sum);
+                       (const uint32_t *)n_live, min_count, (const RansacBest *)best, (const uint32_t *)(n_live + 3 + TIED_CAP),
+                       out_count, out_err_sum);
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
     hipLaunchKernelGGL(ransac_tied_sum_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied,
@@ -1370,6 +1457,40 @@ extern "C" int cvhip_ransac_score(cvhip_device *dev, const double *F, uint32_t H
     return CVHIP_OK;
 }
 
+// Test hook: what ONE ROUND's scoring computes for caller-given hypotheses - the inlier counts of the counting kernel
+// (packed-f32 screen, f64 in the guard band) and the ordered error sums of the hypotheses tied at the maximum count
+// (0 for every other one).  No pruning (no best of earlier rounds, min_count 0): counts must equal cvhip_ransac_score's.
+extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint32_t H, const uint32_t *matches, uint32_t N,
+                                        double t, uint32_t *out_count, double *out_err_sum)
+{
+    if (!dev || (!F && H) || (!matches && N) || !out_count || !out_err_sum) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (H == 0) return CVHIP_OK;
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    DevAllocs mem(dev->d);
+    double *d_F = nullptr, *d_err = nullptr;
+    uint32_t *d_m = nullptr, *d_cnt = nullptr, *d_live = nullptr;
+    RansacBest *d_best = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_F, (size_t)H * 9));
+    CVHIP_TRY_HIP(mem.alloc(&d_err, std::max<size_t>(H, 64)));
+    CVHIP_TRY_HIP(mem.alloc(&d_m, (size_t)std::max(N, 1u) * 4));
+    CVHIP_TRY_HIP(mem.alloc(&d_cnt, H));
+    CVHIP_TRY_HIP(mem.alloc(&d_live, (size_t)H + 4 + TIED_CAP));
+    CVHIP_TRY_HIP(mem.alloc(&d_best, 1));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_F, F, (size_t)H * 9 * sizeof(double), dev_ptr(F) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (N) CVHIP_TRY_HIP(hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    CVHIP_TRY_HIP(hipMemsetAsync(d_best, 0, sizeof(RansacBest), s));
+    CVHIP_TRY_HIP(hipMemsetAsync(d_err, 0, std::max<size_t>(H, 64) * sizeof(double), s));
+    hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
+                       d_live + H + 3 + TIED_CAP);
+    launch_ransac_score_round(d_F, H, d_m, N, t, d_live, d_live + H, 0u, d_best, d_cnt, d_err, s);
+    CVHIP_TRY_HIP(hipGetLastError());
+    CVHIP_TRY_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)H * sizeof(uint32_t), dev_ptr(out_count) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(out_err_sum, d_err, (size_t)H * sizeof(double), dev_ptr(out_err_sum) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    return CVHIP_OK;
+}
+
 extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint64_t seed,
                                    double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask)
 {
@@ -1395,6 +1516,9 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)CHECK_INTERVAL + 4 + TIED_CAP) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
+    if (e == hipSuccess)
+        hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
+                           d_live + CHECK_INTERVAL + 3 + TIED_CAP);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
@@ -1464,6 +1588,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
+    if (e == hipSuccess) // the scale of the counting kernel's f32 screen: one word behind the round's maximum list
+        hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
+                           d_live + H + 3 + TIED_CAP);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
@@ -1473,15 +1600,23 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // registers each - cannot get onto the chip while the counting kernel fills it; generated two rounds ahead, it is
     // already queued when a counting kernel drains, starts in the gap that follows (ordered sums, best pick, the host's
     // early-exit read) and finishes under the next counting kernel.  An early exit discards at most two generated rounds.
+    // The early exit (:135-141) needs more than `early_exit` inliers: with fewer matches than that it can never fire, and
+    // the rounds are enqueued back to back with ONE host synchronisation at the end instead of a 4-byte read per round.
+    const bool may_exit_early = N > early_exit;
     hipStream_t g = nullptr;
-    hipEvent_t ready[GEN_DEPTH] = {}, uploaded = nullptr;
+    hipEvent_t ready[GEN_DEPTH] = {}, scored[GEN_DEPTH] = {}, uploaded = nullptr;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g, hipStreamNonBlocking);
-    for (uint32_t b = 0; b < GEN_DEPTH && e == hipSuccess; b++) e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming);
+    for (uint32_t b = 0; b < GEN_DEPTH && e == hipSuccess; b++) {
+        e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&scored[b], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&uploaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(uploaded, s);
     if (e == hipSuccess) e = hipStreamWaitEvent(g, uploaded, 0);
-    const auto generate_round = [&](uint32_t r) { // into buffer r % GEN_DEPTH, whose last reader (round r - GEN_DEPTH) is done
+    const auto generate_round = [&](uint32_t r) { // into buffer r % GEN_DEPTH, once its last reader (round r - GEN_DEPTH) is done
         const uint32_t b = r % GEN_DEPTH;
+        hipError_t ge = r >= GEN_DEPTH ? hipStreamWaitEvent(g, scored[b], 0) : hipSuccess;
+        if (ge != hipSuccess) return ge;
         generate(m4, r, (int)b, d_F + (size_t)b * H * 9, g);
         return hipEventRecord(ready[b], g);
     };
@@ -1489,12 +1624,14 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
         const uint32_t b = round % GEN_DEPTH;
         double *F_round = d_F + (size_t)b * H * 9;
-        if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1); // (round - 1 was synchronised below)
+        if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
         launch_ransac_score_round(F_round, H, d_m, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, F_round, d_cnt, d_err, H, min_count,
                            (const uint32_t *)(d_live + H + 1), d_best);
         if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(scored[b], s);
+        if (!may_exit_early && round + 1 < rounds) continue;
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (h_best.valid && h_best.matches_count > early_exit) break; // :135-141
@@ -1516,8 +1653,10 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
             if (out_inlier_mask) std::memcpy(out_inlier_mask, h_mask.data(), N);
         }
     }
-    for (uint32_t b = 0; b < GEN_DEPTH; b++)
+    for (uint32_t b = 0; b < GEN_DEPTH; b++) {
         if (ready[b]) (void)hipEventDestroy(ready[b]);
+        if (scored[b]) (void)hipEventDestroy(scored[b]);
+    }
     if (uploaded) (void)hipEventDestroy(uploaded);
     if (g) (void)hipStreamDestroy(g);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));

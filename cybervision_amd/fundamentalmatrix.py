@@ -42,6 +42,18 @@ def ransac_score(device, F, matches, t: float):
     return cnt, err
 
 
+def ransac_round_score(device, F, matches, t: float):
+    """cvhip_ransac_round_score: one RANSAC round's scoring of caller-given hypotheses (counting kernel + ordered sums
+    of the hypotheses tied at the maximum) -> (count[H] uint32, err_sum[H] float64, 0 where not computed)."""
+    F = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(-1, 9))
+    m = _matches(matches)
+    cnt = np.zeros(F.shape[0], dtype=np.uint32)
+    err = np.zeros(F.shape[0], dtype=np.float64)
+    _lib.check(_lib.lib().cvhip_ransac_round_score(device.handle, _p(F), F.shape[0], _p(m), m.shape[0], float(t), _p(cnt), _p(err)),
+               "cvhip_ransac_round_score")
+    return cnt, err
+
+
 def find_ransac_affine(device, matches, seed: int = 0):
     """FundamentalMatrix::new(Affine, _).find_ransac(matches) entirely on the device
     (cvhip_ransac_affine).  -> (F[3, 3] float64, inlier_mask[N] bool).  Raises CvhipError (code -5) with

@@ -330,6 +330,13 @@ int cvhip_ransac_affine_models(cvhip_device *dev, const uint32_t *matches, uint3
 /* fits_model (fundamentalmatrix.rs:452-458) of one F for every match - the inlier filter of optimize_result
  * (:233-236, 248-254).  out_mask: N bytes, 1 = inlier.  Host or device pointers. */
 int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t N, double t, uint8_t *out_mask);
+/* Test hook: the scoring of ONE RANSAC round for caller-given hypotheses, as the device loops run it - inlier counts
+ * from the counting kernel (one wave per hypothesis; pairs decided in packed f32 against rigorous error bounds, the
+ * reference's f64 expression inside the guard band, so the counts are exact) and the reference's ordered error sum
+ * for the hypotheses tied at the largest count (0 for all others: Ord, :623-649, never looks at theirs).  No pruning.
+ * out_count must equal cvhip_ransac_score's counts; out_err_sum its sums where non-zero. */
+int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
+                             uint32_t *out_count, double *out_err_sum);
 /* FundamentalMatrix::new(projection, max_dimension).find_ransac(matches) in one call (fundamentalmatrix.rs:72-147
  * and optimize_result :231-257): cvhip_ransac_affine for projection 0 (max_dimension unused); for projection 1
  * cvhip_ransac_perspective, then the LM refit of the winner on its inliers (cvhip_optimize_perspective_f_device: the

@@ -118,6 +118,53 @@ def test_ransac_score_ragged_sizes(gpu_device, oracle):
         assert (got_c == want_c).all() and (got_e.view(np.uint64) == want_e.view(np.uint64)).all()
 
 
+def test_round_counting_kernel_is_exact(gpu_device, oracle, oracle_fm):
+    """The counting kernel of a RANSAC round decides most (hypothesis, match) pairs in packed f32 against error bounds
+    and only the guard band in f64: its counts must be the f64 counts - on good hypotheses whose inliers sit right at
+    the threshold (t chosen AS the error of individual matches, and one ulp either side), on perturbed, random,
+    huge, tiny and non-finite hypotheses; the ordered sums of the hypotheses tied at the maximum must be the oracle's."""
+    import cases
+
+    m, truth, _, _ = cases.perspective_matches(n=5000, outlier_frac=0.3)
+    F0, _ = fundamentalmatrix.find_ransac_perspective_device(gpu_device, m, 2048.0, seed=2, rounds=1, refit=False)
+    rng = np.random.default_rng(8)
+    hyps = [F0]
+    for scale in (1e-7, 1e-5, 1e-3, 1e-1):
+        for _ in range(6):
+            hyps.append(F0 * (1.0 + scale * rng.standard_normal((3, 3))))
+    hyps += [rng.standard_normal((3, 3)) for _ in range(6)]
+    hyps += [F0 * 1e-9, F0 * 1e-30, F0 * 1e9, F0 * 1e200, F0 * 1e-200]  # screen switched off by its range guards
+    bad = F0.copy()
+    bad[1, 1] = np.nan
+    inf = F0.copy()
+    inf[0, 2] = np.inf
+    hyps += [bad, inf, np.zeros((3, 3))]
+    hyps += [F0, F0]  # exact duplicates: tied at the maximum -> their ordered sums are computed
+    F = np.stack(hyps)
+    errs = np.sort(oracle_fm.reprojection_error(F0, m))
+    ts = [20.48, 0.5, 1e-3]
+    for q in (0.3, 0.5, 0.7):  # thresholds ON a match's error: err == t is an inlier, one ulp below t is not
+        e = float(errs[int(q * len(errs))])
+        ts += [e, float(np.nextafter(e, 0.0)), float(np.nextafter(e, np.inf))]
+    for t in ts:
+        want_c, want_e = oracle.ransac_score(F, m, t)
+        full_c, _ = fundamentalmatrix.ransac_score(gpu_device, F, m, t)
+        got_c, got_e = fundamentalmatrix.ransac_round_score(gpu_device, F, m, t)
+        assert (full_c == want_c).all()
+        assert (got_c == want_c).all(), (t, np.nonzero(got_c != want_c)[0], got_c[got_c != want_c], want_c[got_c != want_c])
+        top = want_c.max()
+        tied = np.nonzero(want_c == top)[0]
+        if top > 0 and len(tied) > 1:
+            assert (got_e[tied].view(np.uint64) == want_e[tied].view(np.uint64)).all()
+        assert (got_e[want_c != top] == 0.0).all()
+    assert want_c[0] > 1000
+    # ragged sizes around the 128-match step of the kernel
+    for n in (1, 63, 64, 65, 127, 128, 129, 1000):
+        want_c, _ = oracle.ransac_score(F, m[:n], 20.48)
+        got_c, _ = fundamentalmatrix.ransac_round_score(gpu_device, F, m[:n], 20.48)
+        assert (got_c == want_c).all(), n
+
+
 def affine_matches(n=4000, outlier_frac=0.35, seed=5):
     """Matches of a known affine geometry x2^T F x1 = 0 with F = f_tilt(12 deg): the point in image 2 lies on
     the line through (x1, y1) with that direction, at a random signed distance (integer rounding noise)."""
