@@ -1603,22 +1603,26 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // The early exit (:135-141) needs more than `early_exit` inliers: with fewer matches than that it can never fire, and
     // the rounds are enqueued back to back with ONE host synchronisation at the end instead of a 4-byte read per round.
     const bool may_exit_early = N > early_exit;
-    hipStream_t g = nullptr;
+    // (one generator stream per round in flight: the LM tails of consecutive rounds - a couple of hundred waves each,
+    // bound by their longest loop - then run side by side instead of queueing behind each other)
+    constexpr uint32_t GEN_STREAMS = GEN_DEPTH - 1;
+    hipStream_t g[GEN_STREAMS] = {};
     hipEvent_t ready[GEN_DEPTH] = {}, scored[GEN_DEPTH] = {}, uploaded = nullptr;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g, hipStreamNonBlocking);
+    for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = hipStreamCreateWithFlags(&g[k], hipStreamNonBlocking);
     for (uint32_t b = 0; b < GEN_DEPTH && e == hipSuccess; b++) {
         e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&scored[b], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&uploaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(uploaded, s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(g, uploaded, 0);
+    for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = hipStreamWaitEvent(g[k], uploaded, 0);
     const auto generate_round = [&](uint32_t r) { // into buffer r % GEN_DEPTH, once its last reader (round r - GEN_DEPTH) is done
         const uint32_t b = r % GEN_DEPTH;
-        hipError_t ge = r >= GEN_DEPTH ? hipStreamWaitEvent(g, scored[b], 0) : hipSuccess;
+        hipStream_t gs = g[r % GEN_STREAMS];
+        hipError_t ge = r >= GEN_DEPTH ? hipStreamWaitEvent(gs, scored[b], 0) : hipSuccess;
         if (ge != hipSuccess) return ge;
-        generate(m4, r, (int)b, d_F + (size_t)b * H * 9, g);
-        return hipEventRecord(ready[b], g);
+        generate(m4, r, (int)b, d_F + (size_t)b * H * 9, gs);
+        return hipEventRecord(ready[b], gs);
     };
     for (uint32_t r = 0; r + 1 < GEN_DEPTH && r < rounds && e == hipSuccess; r++) e = generate_round(r);
     for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
@@ -1636,7 +1640,8 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (h_best.valid && h_best.matches_count > early_exit) break; // :135-141
     }
-    if (g) (void)hipStreamSynchronize(g); // a round generated ahead of an early exit, or of an error
+    for (uint32_t k = 0; k < GEN_STREAMS; k++)
+        if (g[k]) (void)hipStreamSynchronize(g[k]); // rounds generated ahead of an early exit, or of an error
     int rc = CVHIP_OK;
     if (e == hipSuccess && !h_best.valid) rc = fail(CVHIP_ERR_NO_MODEL, "No reliable matches found"); // :145
     if (e == hipSuccess && rc == CVHIP_OK) {
@@ -1658,7 +1663,8 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         if (scored[b]) (void)hipEventDestroy(scored[b]);
     }
     if (uploaded) (void)hipEventDestroy(uploaded);
-    if (g) (void)hipStreamDestroy(g);
+    for (uint32_t k = 0; k < GEN_STREAMS; k++)
+        if (g[k]) (void)hipStreamDestroy(g[k]);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
     return rc;
 }
