@@ -23,6 +23,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <cmath>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "orb_pattern.inc"
@@ -522,10 +524,13 @@ __global__ __launch_bounds__(1024) void final_compact_kernel(const uint32_t *__r
 // (Iterator::min_by keeps the first of equal elements).
 // ---------------------------------------------------------------------------------------------
 constexpr int MATCH_TILE = 512;
+// One thread per query descriptor, the candidates streamed through LDS (every lane reads the same candidate:
+// broadcast).  blockIdx.y splits the CANDIDATE list, so that 30 000 queries are 118 x S workgroups instead of 118 (less
+// than half a wave per SIMD: 2.5 ms); the splits meet in one 64-bit atomicMin per query on (distance << 32 | j) -
+// the smallest distance, and among equal distances the smallest j: exactly what the serial scan's strict `<` keeps.
 __global__ __launch_bounds__(256) void match_kernel(const uint32_t *__restrict__ desc1, uint32_t n1,
-                                                     const uint32_t *__restrict__ desc2, uint32_t n2,
-                                                     uint32_t threshold, uint32_t *__restrict__ best_j,
-                                                     uint32_t *__restrict__ best_d)
+                                                     const uint32_t *__restrict__ desc2, uint32_t n2, uint32_t chunk,
+                                                     uint32_t threshold, unsigned long long *__restrict__ best)
 {
     __shared__ uint4 tile[MATCH_TILE * 2];
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
@@ -535,8 +540,9 @@ __global__ __launch_bounds__(256) void match_kernel(const uint32_t *__restrict__
         a1 = reinterpret_cast<const uint4 *>(desc1)[2 * (size_t)q + 1];
     }
     uint32_t bd = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
-    for (uint32_t base = 0; base < n2; base += MATCH_TILE) {
-        const uint32_t n = min((uint32_t)MATCH_TILE, n2 - base);
+    const uint32_t first = blockIdx.y * chunk, last = min(n2, first + chunk);
+    for (uint32_t base = first; base < last; base += MATCH_TILE) {
+        const uint32_t n = min((uint32_t)MATCH_TILE, last - base);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < 2 * n; i += 256)
             tile[i] = reinterpret_cast<const uint4 *>(desc2)[2 * (size_t)base + i];
@@ -551,16 +557,19 @@ __global__ __launch_bounds__(256) void match_kernel(const uint32_t *__restrict__
             }
         }
     }
-    if (q < n1) {
-        best_j[q] = bj;
-        best_d[q] = bd; // 0xFFFFFFFF = no match; sorts last
-    }
+    if (q < n1 && bj != 0xFFFFFFFFu) atomicMin(&best[q], ((unsigned long long)bd << 32) | bj);
 }
-
-__global__ void iota_kernel(uint32_t *p, uint32_t n)
+// best[] -> the sort's keys (distance; 0xFFFFFFFF = no match, sorts last), the matched index and the query index
+__global__ __launch_bounds__(256) void match_unpack_kernel(const unsigned long long *__restrict__ best, uint32_t n1,
+                                                            uint32_t *__restrict__ best_j, uint32_t *__restrict__ best_d,
+                                                            uint32_t *__restrict__ q_index)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n1) return;
+    const unsigned long long k = best[q];
+    best_j[q] = (uint32_t)k;
+    best_d[q] = (uint32_t)(k >> 32);
+    q_index[q] = q;
 }
 
 __global__ void match_gather_kernel(const uint32_t *__restrict__ sorted_q, const uint32_t *__restrict__ sorted_d,
@@ -734,17 +743,35 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     CVHIP_TRY_HIP(hipGetLastError());
 
     // 4. orientation on the host with libm, exactly as the reference (orb.rs:337-341, 365-366)
+    // (glibc's atan2 / sin / cos are ~70 ns per keypoint: 30 000 keypoints per image made this loop, on one thread, the
+    // largest item of an extraction - the keypoints are independent, so a few host threads share it)
     std::vector<double> h_sc((size_t)count * 3, 0.0);
-    for (uint32_t r = 0; r < count; r++) {
-        if (!h_mom[4 * (size_t)r + 3] || h_idx[r] == 0xFFFFFFFFu) continue;
-        const double x = (double)h_kp[2 * (size_t)h_idx[r]], y = (double)h_kp[2 * (size_t)h_idx[r] + 1];
-        const double m00 = (double)h_mom[4 * (size_t)r + 0];
-        const double centroid_x = (double)h_mom[4 * (size_t)r + 1] / m00;
-        const double centroid_y = (double)h_mom[4 * (size_t)r + 2] / m00;
-        const double angle = std::atan2(centroid_y - y, centroid_x - x);
-        h_sc[3 * (size_t)r + 0] = std::sin(angle);
-        h_sc[3 * (size_t)r + 1] = std::cos(angle);
-        h_sc[3 * (size_t)r + 2] = 1.0;
+    const auto orient = [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t r = r0; r < r1; r++) {
+            if (!h_mom[4 * (size_t)r + 3] || h_idx[r] == 0xFFFFFFFFu) continue;
+            const double x = (double)h_kp[2 * (size_t)h_idx[r]], y = (double)h_kp[2 * (size_t)h_idx[r] + 1];
+            const double m00 = (double)h_mom[4 * (size_t)r + 0];
+            const double centroid_x = (double)h_mom[4 * (size_t)r + 1] / m00;
+            const double centroid_y = (double)h_mom[4 * (size_t)r + 2] / m00;
+            const double angle = std::atan2(centroid_y - y, centroid_x - x);
+            h_sc[3 * (size_t)r + 0] = std::sin(angle);
+            h_sc[3 * (size_t)r + 1] = std::cos(angle);
+            h_sc[3 * (size_t)r + 2] = 1.0;
+        }
+    };
+    {
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t nthreads = std::min({8u, hw, count / 1024u + 1u});
+        std::vector<std::thread> pool;
+        const uint32_t per = (count + nthreads - 1) / nthreads;
+        try {
+            for (uint32_t k = 1; k < nthreads; k++)
+                pool.emplace_back(orient, std::min(count, k * per), std::min(count, (k + 1) * per));
+        } catch (const std::system_error &) { // no more threads: the caller's thread does what was not handed out
+            orient(std::min(count, (uint32_t)(pool.size() + 1) * per), count);
+        }
+        orient(0, std::min(count, per));
+        for (auto &th : pool) th.join();
     }
 
     // 5. descriptors + ordered compaction
@@ -808,9 +835,16 @@ extern "C" int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const 
     CVHIP_TRY_HIP(hipMemcpyAsync(d_desc1, desc1, (size_t)n1 * 32, kind(desc1), s));
     CVHIP_TRY_HIP(hipMemcpyAsync(d_desc2, desc2, (size_t)n2 * 32, kind(desc2), s));
     CVHIP_TRY_HIP(hipMemsetAsync(d_n, 0, sizeof(uint32_t), s));
-    hipLaunchKernelGGL(match_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, d_desc1, n1, d_desc2, n2, threshold, d_bj,
-                       d_bd);
-    hipLaunchKernelGGL(iota_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, d_q, n1);
+    unsigned long long *d_key = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_key, n1));
+    CVHIP_TRY_HIP(hipMemsetAsync(d_key, 0xFF, (size_t)n1 * sizeof(unsigned long long), s)); // no match
+    const uint32_t qblocks = (n1 + 255) / 256, tiles = (n2 + MATCH_TILE - 1) / MATCH_TILE;
+    const uint32_t splits = std::max(1u, std::min(tiles, (2048u + qblocks - 1) / qblocks)); // >= ~2 workgroups per SIMD
+    const uint32_t chunk = (tiles + splits - 1) / splits * MATCH_TILE;
+    hipLaunchKernelGGL(match_kernel, dim3(qblocks, (n2 + chunk - 1) / chunk), dim3(256), 0, s, d_desc1, n1, d_desc2, n2, chunk,
+                       threshold, d_key);
+    hipLaunchKernelGGL(match_unpack_kernel, dim3(qblocks), dim3(256), 0, s, (const unsigned long long *)d_key, n1, d_bj, d_bd,
+                       d_q);
     // stable ascending sort by distance (sort_by_key, pointmatching.rs:74); unmatched = ~0 go last
     size_t tmp_bytes = 0;
     CVHIP_TRY_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_bd, d_bd_sorted, d_q, d_q_sorted, (size_t)n1, 0u, 32u, s));
