@@ -503,6 +503,8 @@ void cvhip_device_destroy(cvhip_device *dev)
     for (auto &b : dev->d.parked) free_buffer_set(b);
     dev->d.parked.clear();
     if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
+    if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
+    if (dev->d.orb_pattern) (void)hipFree(dev->d.orb_pattern);
     delete dev;
 }
 

@@ -173,7 +173,28 @@ struct Device {
     int low_power = 0;
     std::vector<CtxBuffers> parked; // at most PARK_LIMIT sets, most recently used last
     Arena arena;
+    // page-locked host staging of the sparse-stage entry points (grow-only): a pageable hipMemcpy is staged by the
+    // runtime in small pieces and costs ~50 us however few bytes it moves - an ORB extraction made nine of them
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    void *orb_pattern = nullptr; // the BRIEF pattern in device memory, uploaded once per handle
 };
+// -> at least `bytes` of page-locked host memory owned by the handle (nullptr: out of memory)
+inline void *pinned_scratch(Device &d, size_t bytes)
+{
+    if (bytes <= d.pinned_cap) return d.pinned;
+    if (d.pinned) (void)hipHostFree(d.pinned);
+    d.pinned = nullptr;
+    d.pinned_cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&d.pinned, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        d.pinned = nullptr;
+        return nullptr;
+    }
+    d.pinned_cap = want;
+    return d.pinned;
+}
 constexpr size_t PARK_LIMIT = 2;
 
 // RAII view of the arena for one entry-point call: alloc() until the call returns, everything is released together

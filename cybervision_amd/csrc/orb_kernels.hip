@@ -392,11 +392,12 @@ __global__ __launch_bounds__(64) void moments_kernel(const double *__restrict__ 
             m01 += __shfl_down(m01, s, 64);
         }
     }
-    if (lane == 0) {
-        out[4 * (size_t)r + 0] = m00;
-        out[4 * (size_t)r + 1] = m10;
-        out[4 * (size_t)r + 2] = m01;
-        out[4 * (size_t)r + 3] = ok ? 1ull : 0ull;
+    if (lane == 0) { // five words per rank: the moments, the validity flag, the keypoint itself (x | y << 32)
+        out[5 * (size_t)r + 0] = m00;
+        out[5 * (size_t)r + 1] = m10;
+        out[5 * (size_t)r + 2] = m01;
+        out[5 * (size_t)r + 3] = ok ? 1ull : 0ull;
+        out[5 * (size_t)r + 4] = (unsigned long long)x | ((unsigned long long)y << 32);
     }
 }
 
@@ -679,8 +680,8 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     CVHIP_TRY_HIP(mem.alloc(&d_counts, nblocks));
     CVHIP_TRY_HIP(mem.alloc(&d_total, 1));
     CVHIP_TRY_HIP(hipMemcpyAsync(d_img, img, n, dev_ptr(img) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    const uint32_t mm_init[2] = {255u, 0u};
-    CVHIP_TRY_HIP(hipMemcpyAsync(d_mm, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, s));
+    CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_mm), 255, 1, s)); // {min, max} = {255, 0}
+    CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_mm + 1), 0, 1, s));
 
     // 1. contrast stretch, FAST score, NMS, scan-ordered corner list
     const unsigned rblocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
@@ -690,10 +691,12 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, d_adj, w, h, d_score);
     hipLaunchKernelGGL(nms_count_kernel, dim3(nblocks), dim3(256), 0, s, d_score, w, h, d_counts);
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, nblocks, d_total);
-    uint32_t n_fast = 0;
-    CVHIP_TRY_HIP(hipMemcpyAsync(&n_fast, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    uint32_t *h_n_fast = static_cast<uint32_t *>(pinned_scratch(dev->d, 4096));
+    if (!h_n_fast) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
+    CVHIP_TRY_HIP(hipMemcpyAsync(h_n_fast, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     CVHIP_TRY_HIP(hipStreamSynchronize(s));
     CVHIP_TRY_HIP(hipGetLastError());
+    const uint32_t n_fast = *h_n_fast;
     if (n_fast == 0) {
         *out_n = 0;
         return CVHIP_OK;
@@ -731,28 +734,32 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     hipLaunchKernelGGL(blur_h_kernel, grid2d, dim3(256), 0, s, d_img, w, h, k11, d_blur_h);
     hipLaunchKernelGGL(blur_v_kernel, grid2d, dim3(256), 0, s, d_blur_h, w, h, k11, d_blur);
     unsigned long long *d_mom = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_mom, (size_t)count * 4));
+    CVHIP_TRY_HIP(mem.alloc(&d_mom, (size_t)count * 5));
     hipLaunchKernelGGL(moments_kernel, dim3(count), dim3(64), 0, s, d_blur, w, h, d_kp, d_idx_sorted, count, d_mom);
-    std::vector<unsigned long long> h_mom((size_t)count * 4);
-    std::vector<uint32_t> h_idx(count), h_kp;
-    CVHIP_TRY_HIP(hipMemcpyAsync(h_mom.data(), d_mom, h_mom.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    CVHIP_TRY_HIP(hipMemcpyAsync(h_idx.data(), d_idx_sorted, count * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    h_kp.resize((size_t)n_fast * 2);
-    CVHIP_TRY_HIP(hipMemcpyAsync(h_kp.data(), d_kp, h_kp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // one page-locked staging area for everything that crosses the bus from here on:
+    // [moments + keypoint, 5 u64 per rank] [sin, cos, valid: 3 f64 per rank] [n_out + outputs]
+    const uint32_t out_cap = std::min(cap, count);
+    const size_t mom_bytes = (size_t)count * 5 * sizeof(unsigned long long), sc_bytes = (size_t)count * 3 * sizeof(double);
+    const size_t pack_bytes = 256 + (size_t)out_cap * 10 * sizeof(uint32_t);
+    char *stage = static_cast<char *>(pinned_scratch(dev->d, mom_bytes + sc_bytes + pack_bytes));
+    if (!stage) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
+    const unsigned long long *h_mom = reinterpret_cast<const unsigned long long *>(stage);
+    double *h_sc = reinterpret_cast<double *>(stage + mom_bytes);
+    char *h_pack = stage + mom_bytes + sc_bytes;
+    CVHIP_TRY_HIP(hipMemcpyAsync(stage, d_mom, mom_bytes, hipMemcpyDeviceToHost, s));
     CVHIP_TRY_HIP(hipStreamSynchronize(s));
     CVHIP_TRY_HIP(hipGetLastError());
 
     // 4. orientation on the host with libm, exactly as the reference (orb.rs:337-341, 365-366)
-    // (glibc's atan2 / sin / cos are ~70 ns per keypoint: 30 000 keypoints per image made this loop, on one thread, the
-    // largest item of an extraction - the keypoints are independent, so a few host threads share it)
-    std::vector<double> h_sc((size_t)count * 3, 0.0);
+    // (glibc's atan2 / sin / cos are ~70 ns per keypoint; the keypoints are independent, so a few host threads share them)
     const auto orient = [&](uint32_t r0, uint32_t r1) {
         for (uint32_t r = r0; r < r1; r++) {
-            if (!h_mom[4 * (size_t)r + 3] || h_idx[r] == 0xFFFFFFFFu) continue;
-            const double x = (double)h_kp[2 * (size_t)h_idx[r]], y = (double)h_kp[2 * (size_t)h_idx[r] + 1];
-            const double m00 = (double)h_mom[4 * (size_t)r + 0];
-            const double centroid_x = (double)h_mom[4 * (size_t)r + 1] / m00;
-            const double centroid_y = (double)h_mom[4 * (size_t)r + 2] / m00;
+            h_sc[3 * (size_t)r + 0] = h_sc[3 * (size_t)r + 1] = h_sc[3 * (size_t)r + 2] = 0.0;
+            if (!h_mom[5 * (size_t)r + 3]) continue; // (an entry past the Some(...) ones has no valid patch either)
+            const double x = (double)(uint32_t)h_mom[5 * (size_t)r + 4], y = (double)(uint32_t)(h_mom[5 * (size_t)r + 4] >> 32);
+            const double m00 = (double)h_mom[5 * (size_t)r + 0];
+            const double centroid_x = (double)h_mom[5 * (size_t)r + 1] / m00;
+            const double centroid_y = (double)h_mom[5 * (size_t)r + 2] / m00;
             const double angle = std::atan2(centroid_y - y, centroid_x - x);
             h_sc[3 * (size_t)r + 0] = std::sin(angle);
             h_sc[3 * (size_t)r + 1] = std::cos(angle);
@@ -761,7 +768,7 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     };
     {
         const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t nthreads = std::min({8u, hw, count / 1024u + 1u});
+        const uint32_t nthreads = std::min({4u, hw, count / 2048u + 1u});
         std::vector<std::thread> pool;
         const uint32_t per = (count + nthreads - 1) / nthreads;
         try {
@@ -774,33 +781,31 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
         for (auto &th : pool) th.join();
     }
 
-    // 5. descriptors + ordered compaction
+    // 5. descriptors + ordered compaction; host destinations are filled through ONE copy of {n, xy, desc}
     double *d_sc = nullptr;
-    signed char *d_pat = nullptr;
-    uint32_t *d_desc = nullptr, *d_flags = nullptr, *d_out_xy = out_xy, *d_out_desc = out_desc, *d_out_n = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_sc, h_sc.size()));
-    CVHIP_TRY_HIP(mem.alloc(&d_pat, 1024));
+    uint32_t *d_desc = nullptr, *d_flags = nullptr, *d_pack = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_sc, (size_t)count * 3));
     CVHIP_TRY_HIP(mem.alloc(&d_desc, (size_t)count * 8));
     CVHIP_TRY_HIP(mem.alloc(&d_flags, count));
-    CVHIP_TRY_HIP(mem.alloc(&d_out_n, 1));
+    CVHIP_TRY_HIP(mem.alloc(&d_pack, pack_bytes / sizeof(uint32_t)));
+    if (!dev->d.orb_pattern) {
+        CVHIP_TRY_HIP(hipMalloc(&dev->d.orb_pattern, 1024));
+        CVHIP_TRY_HIP(hipMemcpyAsync(dev->d.orb_pattern, CVHIP_ORB_PATTERN, 1024, hipMemcpyHostToDevice, s));
+    }
     const bool xy_dev = dev_ptr(out_xy), desc_dev = dev_ptr(out_desc);
-    const uint32_t out_cap = std::min(cap, count);
-    if (!xy_dev) CVHIP_TRY_HIP(mem.alloc(&d_out_xy, (size_t)out_cap * 2));
-    if (!desc_dev) CVHIP_TRY_HIP(mem.alloc(&d_out_desc, (size_t)out_cap * 8));
-    CVHIP_TRY_HIP(hipMemcpyAsync(d_sc, h_sc.data(), h_sc.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    CVHIP_TRY_HIP(hipMemcpyAsync(d_pat, CVHIP_ORB_PATTERN, 1024, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(brief_kernel, dim3(count), dim3(64), 0, s, d_blur, w, h, d_kp, d_idx_sorted, count, d_sc, d_pat,
-                       d_desc, d_flags);
+    uint32_t *d_out_n = d_pack, *d_out_xy = xy_dev ? out_xy : d_pack + 64, *d_out_desc = desc_dev ? out_desc : d_pack + 64 + (size_t)out_cap * 2;
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_sc, h_sc, sc_bytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(brief_kernel, dim3(count), dim3(64), 0, s, d_blur, w, h, d_kp, d_idx_sorted, count, d_sc,
+                       (const signed char *)dev->d.orb_pattern, d_desc, d_flags);
     hipLaunchKernelGGL(final_compact_kernel, dim3(1), dim3(1024), 0, s, d_flags, d_kp, d_idx_sorted, d_desc, count,
                        out_cap, d_out_xy, d_out_desc, d_out_n);
-    uint32_t n_out = 0;
-    CVHIP_TRY_HIP(hipMemcpyAsync(&n_out, d_out_n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    const size_t back = (xy_dev && desc_dev) ? 256 : pack_bytes;
+    CVHIP_TRY_HIP(hipMemcpyAsync(h_pack, d_pack, back, hipMemcpyDeviceToHost, s));
     CVHIP_TRY_HIP(hipStreamSynchronize(s));
     CVHIP_TRY_HIP(hipGetLastError());
-    if (!xy_dev && n_out)
-        CVHIP_TRY_HIP(hipMemcpy(out_xy, d_out_xy, (size_t)n_out * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (!desc_dev && n_out)
-        CVHIP_TRY_HIP(hipMemcpy(out_desc, d_out_desc, (size_t)n_out * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t n_out = *reinterpret_cast<const uint32_t *>(h_pack);
+    if (!xy_dev && n_out) std::memcpy(out_xy, h_pack + 256, (size_t)n_out * 2 * sizeof(uint32_t));
+    if (!desc_dev && n_out) std::memcpy(out_desc, h_pack + 256 + (size_t)out_cap * 2 * sizeof(uint32_t), (size_t)n_out * 8 * sizeof(uint32_t));
     *out_n = n_out;
     return CVHIP_OK;
 }

@@ -574,14 +574,17 @@ __device__ __forceinline__ bool match_fits(const double (&f)[9], uint4 m, double
 }
 
 // Largest coordinate of the match list (one word, once per call): the scale of the f32 screen's error bounds.
+// Also writes the match list once as f32 (exact below 2^24; a larger coordinate switches the screen off through W), so
+// that the counting kernel's screen does not convert the same 29 000 matches for every one of 25 000 hypotheses.
 __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__restrict__ matches, uint32_t N,
-                                                                 uint32_t *__restrict__ out)
+                                                                 uint32_t *__restrict__ out, float4 *__restrict__ matches_f32)
 {
     __shared__ uint32_t wmax[16];
     uint32_t m = 1u;
     for (uint32_t i = threadIdx.x; i < N; i += 1024) {
         const uint4 v = matches[i];
         m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
+        matches_f32[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
     }
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_down(m, sft, 64));
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
                                                             const uint32_t *__restrict__ n_live, uint32_t min_count,
                                                             const RansacBest *__restrict__ best,
                                                             const uint32_t *__restrict__ coord_max,
+                                                            const float4 *__restrict__ matches_f32,
                                                             uint32_t *__restrict__ out_count,
                                                             double *__restrict__ out_err_sum)
 {
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     const float En = (float)(En_d * (1.0 + 0x1p-20)), Eden = (float)(Eden_d * (1.0 + 0x1p-20));
     // the screen runs only where every bound and every product it is compared with stays a NORMAL f32 number
     // (E_den >= 32u Tmax^2 >= 2e-18, times t >= 1e-6; squares below 1e31); false for NaN / inf coefficients too
-    const bool screen = Tmax >= 1e-6 && Tmax * W <= 1e12 && Tr2 <= 1e12 && t >= 1e-6 && t <= 1e12;
+    const bool screen = Tmax >= 1e-6 && Tmax * W <= 1e12 && Tr2 <= 1e12 && t >= 1e-6 && t <= 1e12 && W < 16777216.0;
     const float T_out = (float)(t * (1.0 + 0x1p-18)), T_in = (float)(t * (1.0 - 0x1p-18));
     float ff[9];
 #pragma unroll
@@ -655,11 +659,10 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
         }
         const uint32_t ia = base + lane, ib = base + 64 + lane;
         const bool va = ia < N, vb = ib < N;
-        const uint4 ma = matches[va ? ia : 0u], mb = matches[vb ? ib : 0u];
         bool in_a = false, in_b = false, open_a = va, open_b = vb;
         if (screen) {
-            const v2f p1x = {(float)ma.x, (float)mb.x}, p1y = {(float)ma.y, (float)mb.y};
-            const v2f p2x = {(float)ma.z, (float)mb.z}, p2y = {(float)ma.w, (float)mb.w};
+            const float4 fa = matches_f32[va ? ia : 0u], fb = matches_f32[vb ? ib : 0u];
+            const v2f p1x = {fa.x, fb.x}, p1y = {fa.y, fb.y}, p2x = {fa.z, fb.z}, p2y = {fa.w, fb.w};
             const v2f r0 = pk_fma(p2x, bc(ff[0]), pk_fma(p2y, bc(ff[3]), bc(ff[6])));
             const v2f r1 = pk_fma(p2x, bc(ff[1]), pk_fma(p2y, bc(ff[4]), bc(ff[7])));
             const v2f r2 = pk_fma(p2x, bc(ff[2]), pk_fma(p2y, bc(ff[5]), bc(ff[8])));
@@ -682,8 +685,8 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
         }
         if (__builtin_amdgcn_ballot_w64(open_a || open_b) != 0ull) { // rare (never, when the screen is off: always)
             double err;
-            if (open_a) in_a = match_fits(f, ma, t, t_hi, err);
-            if (open_b) in_b = match_fits(f, mb, t, t_hi, err);
+            if (open_a) in_a = match_fits(f, matches[ia], t, t_hi, err);
+            if (open_b) in_b = match_fits(f, matches[ib], t, t_hi, err);
         }
         count += (uint32_t)__popcll(__ballot(in_a)) + (uint32_t)__popcll(__ballot(in_b));
     }
@@ -789,8 +792,8 @@ __global__ __launch_bounds__(1024) void ransac_tied_sum_kernel(const double *__r
     }
 }
 
-static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
-                                      uint32_t *live, uint32_t *n_live, uint32_t min_count, RansacBest *best,
+static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, const float4 *matches_f32,
+                                      uint32_t N, double t, uint32_t *live, uint32_t *n_live, uint32_t min_count, RansacBest *best,
                                       uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
     // scratch: the per-block counts live in out_err_sum's first words until the count kernel overwrites them; the
@@ -806,7 +809,7 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
     hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 3) / 4), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, (const RansacBest *)best, (const uint32_t *)(n_live + 3 + TIED_CAP),
-                       out_count, out_err_sum);
+                       matches_f32, out_count, out_err_sum);
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
     hipLaunchKernelGGL(ransac_tied_sum_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied,
@@ -1481,9 +1484,11 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     if (N) CVHIP_TRY_HIP(hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     CVHIP_TRY_HIP(hipMemsetAsync(d_best, 0, sizeof(RansacBest), s));
     CVHIP_TRY_HIP(hipMemsetAsync(d_err, 0, std::max<size_t>(H, 64) * sizeof(double), s));
+    float4 *d_mf = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_mf, std::max(N, 1u)));
     hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
-                       d_live + H + 3 + TIED_CAP);
-    launch_ransac_score_round(d_F, H, d_m, N, t, d_live, d_live + H, 0u, d_best, d_cnt, d_err, s);
+                       d_live + H + 3 + TIED_CAP, d_mf);
+    launch_ransac_score_round(d_F, H, d_m, d_mf, N, t, d_live, d_live + H, 0u, d_best, d_cnt, d_err, s);
     CVHIP_TRY_HIP(hipGetLastError());
     CVHIP_TRY_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)H * sizeof(uint32_t), dev_ptr(out_count) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     CVHIP_TRY_HIP(hipMemcpyAsync(out_err_sum, d_err, (size_t)H * sizeof(double), dev_ptr(out_err_sum) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -1516,9 +1521,11 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     if (e == hipSuccess) e = hipMalloc(&d_live, ((size_t)CHECK_INTERVAL + 4 + TIED_CAP) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
+    float4 *d_mf = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&d_mf, (size_t)N * sizeof(float4));
     if (e == hipSuccess)
         hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
-                           d_live + CHECK_INTERVAL + 3 + TIED_CAP);
+                           d_live + CHECK_INTERVAL + 3 + TIED_CAP, d_mf);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
@@ -1526,7 +1533,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
         hipLaunchKernelGGL(ransac_generate_affine_kernel, dim3((CHECK_INTERVAL + 63) / 64), dim3(64), 0, s, m4,
                            std::min(N, TOP_INLIERS), RANSAC_T, (unsigned long long)seed, round, CHECK_INTERVAL,
                            (const uint32_t *)nullptr, d_F);
-        launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL, RANSAC_D + RANSAC_N, d_best,
+        launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, d_mf, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL, RANSAC_D + RANSAC_N, d_best,
                                   d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, CHECK_INTERVAL,
                            RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best);
@@ -1559,6 +1566,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     (void)hipFree(d_best);
     (void)hipFree(d_mask);
     (void)hipFree(d_live);
+    (void)hipFree(d_mf);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("ransac_affine: ") + hipGetErrorString(e));
     return rc;
 }
@@ -1585,12 +1593,14 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = mem.alloc(&d_mask, N);
     uint32_t *d_live = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_live, (size_t)H + 4 + TIED_CAP);
+    float4 *d_mf = nullptr;
+    if (e == hipSuccess) e = mem.alloc(&d_mf, N);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     if (e == hipSuccess) // the scale of the counting kernel's f32 screen: one word behind the round's maximum list
         hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
-                           d_live + H + 3 + TIED_CAP);
+                           d_live + H + 3 + TIED_CAP, d_mf);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
@@ -1630,7 +1640,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         double *F_round = d_F + (size_t)b * H * 9;
         if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
-        launch_ransac_score_round(F_round, H, d_m, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
+        launch_ransac_score_round(F_round, H, d_m, d_mf, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, F_round, d_cnt, d_err, H, min_count,
                            (const uint32_t *)(d_live + H + 1), d_best);
         if (e == hipSuccess) e = hipGetLastError();
