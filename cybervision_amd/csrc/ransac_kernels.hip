@@ -1,12 +1,20 @@
-// ransac_kernels.hip — RANSAC hypothesis scoring for gfx950.
+// ransac_kernels.hip — FundamentalMatrix::find_ransac (zlogic/cybervision src/fundamentalmatrix.rs:72-257) for gfx950.
 //
-// Replaces the all-matches fold of FundamentalMatrix::validate_f
-// (zlogic/cybervision src/fundamentalmatrix.rs:210-216) with fits_model / reprojection_error
-// (:452-471) for a whole batch of hypotheses.  One lane per hypothesis: its F sits in
-// registers, the match list streams through LDS in tiles that every lane reads at the same
-// address (LDS broadcast), and count/error-sum are folded serially in match order — the same
-// order as the reference's iterator fold, so both outputs are bit-identical to --mode=cpu.
-// f64 throughout, contraction off; expression order follows nalgebra 0.35's
+// In file order:
+//  * namespace lm: optimize_perspective_f (:391-426) - the reference's Levenberg-Marquardt loop (:515-621), Jacobian
+//    (:473-512) and parameter map, ONE __host__ __device__ implementation for validate_f's per-hypothesis call
+//    (device, 7 observations, register-resident) and the host form of the final refit;
+//  * ransac_score_kernel: the all-matches fold of validate_f (:210-216) with fits_model / reprojection_error
+//    (:452-471) for a batch of hypotheses, one lane per hypothesis, count and ordered error sum bit-identical to
+//    --mode=cpu (cvhip_ransac_score);
+//  * a ROUND's scoring as the device loops run it: live-slot compaction, ransac_count_kernel (one wave per hypothesis;
+//    packed-f32 screen with rigorous bounds, f64 in the guard band: exact counts), the round's maximum, ordered sums
+//    only where a tie in the count needs them, Ord (:623-649) as a reduction;
+//  * the generators: affine (4-point, one-sided Jacobi SVD) and perspective (7-point pencil / root / queued LM);
+//  * ransac_rounds: generation two rounds ahead of scoring on separate streams; ransac_refit_kernel: optimize_result's
+//    refit (:246) on one workgroup, bit-equal to the host loop;
+//  * the C entry points (include/cvhip.h).
+// f64 throughout except the screen, contraction off; expression order follows nalgebra 0.35's
 // published gemv / dot algorithms (column-by-column axpy; 3-vector dot = (a0*b0 + a1*b1) + a2*b2).
 #include "cvhip_internal.hpp"
 
