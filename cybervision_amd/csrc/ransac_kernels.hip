@@ -1807,7 +1807,9 @@ extern "C" int cvhip_optimize_perspective_f(const double *F, const uint32_t *mat
 //    order), then combined and given its tail by one thread exactly as long_dot does - the additions and their order
 //    are the serial function's, so the values are too;
 //  * the 7x7 system, norms, rho and the control flow are thread 0's (lm::solve7, same code), broadcast through LDS.
-// J'J is recomputed only when J changed (a rejected step leaves J, hence J'J before the damping term, as it was), and
+// The Jacobian is kept column by column (a chain's operands are then consecutive in memory: eight threads of a dot
+// product share cache lines instead of touching eight).  J'J is recomputed only when J changed (a rejected step
+// leaves J, hence J'J before the damping term, as it was), and
 // the closing test's r.r is the `after` (accepted step) or `before` (rejected) that was just computed from the same
 // vector.  tests/test_orb_ransac_gpu.py compares the result with the host function bit for bit.
 // ---------------------------------------------------------------------------------------------------------
@@ -1822,6 +1824,7 @@ struct Shared {
     double q[7], g[7], A0[49], step[7], trial[7];
     double parts[MAX_DOTS * 8], dotv[MAX_DOTS];
     DotJob jobs[MAX_DOTS];
+    int pair_a[28], pair_b[28];
     double mu, nu, rho;
     int action;
 };
@@ -1877,18 +1880,33 @@ __device__ void linearise(Shared &sh, const uint4 *__restrict__ inl, uint32_t n,
         const uint4 m = inl[i];
         double row[7];
         lm::gradient_of(M, lm::make_obs(m.x, m.y, m.z, m.w), row);
-        for (int j = 0; j < 7; j++) J[(size_t)i * 7 + j] = row[j];
+        for (int j = 0; j < 7; j++) J[(size_t)j * n + i] = row[j];
     }
-    if (threadIdx.x < 7) sh.jobs[threadIdx.x] = DotJob{J + threadIdx.x, res, 7u, 1u};
+    if (threadIdx.x < 7) sh.jobs[threadIdx.x] = DotJob{J + (size_t)threadIdx.x * n, res, 1u, 1u};
     dots(sh, 7, n);
     if (threadIdx.x < 7) sh.g[threadIdx.x] = sh.dotv[threadIdx.x];
     __syncthreads();
 }
 __device__ void normal_matrix(Shared &sh, uint32_t n, const double *J)
 {
-    if (threadIdx.x < 49) sh.jobs[threadIdx.x] = DotJob{J + threadIdx.x / 7, J + threadIdx.x % 7, 7u, 7u};
-    dots(sh, 49, n);
-    if (threadIdx.x < 49) sh.A0[threadIdx.x] = sh.dotv[threadIdx.x];
+    // a[i] * b[i] == b[i] * a[i]: entry (j, i) of J'J is entry (i, j) bit for bit, so 28 of the 49 dots are evaluated
+    if (threadIdx.x < 28) {
+        int a = 0, rem = (int)threadIdx.x; // pair number -> (a, b), a <= b
+        while (rem >= 7 - a) {
+            rem -= 7 - a;
+            a++;
+        }
+        const int b = a + rem;
+        sh.jobs[threadIdx.x] = DotJob{J + (size_t)a * n, J + (size_t)b * n, 1u, 1u};
+        sh.pair_a[threadIdx.x] = a;
+        sh.pair_b[threadIdx.x] = b;
+    }
+    dots(sh, 28, n);
+    if (threadIdx.x < 28) {
+        const int a = sh.pair_a[threadIdx.x], b = sh.pair_b[threadIdx.x];
+        sh.A0[a * 7 + b] = sh.dotv[threadIdx.x];
+        sh.A0[b * 7 + a] = sh.dotv[threadIdx.x];
+    }
     __syncthreads();
 }
 __device__ double largest7(const double *v)
@@ -1900,7 +1918,7 @@ __device__ double largest7(const double *v)
 }
 } // namespace refit
 
-// inl: the n inliers; r, r_new [n], J [n x 7]: workspace; F_in: the winner (F[8] = 1); F_out / refined as
+// inl: the n inliers; r, r_new [n], J [7 x n, column by column]: workspace; F_in: the winner (F[8] = 1); F_out / refined as
 // cvhip_optimize_perspective_f
 __global__ __launch_bounds__(refit::THREADS) void ransac_refit_kernel(const uint4 *__restrict__ inl, uint32_t n, double *r,
                                                                        double *r_new, double *J, const double *F_in,
