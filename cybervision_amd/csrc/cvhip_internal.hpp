@@ -285,7 +285,7 @@ struct cvhip_ctx {
     int search_version = 3;
     int range_mode = 0; // search_range_kernel: 0 = integer box sums + chain where needed, 1 = chain only, 2 / 3 = test hooks
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
-    // per-direction scratch of a search pass (the two passes of a level are independent and run on two streams)
+    // per-direction scratch of a search pass (the two passes of a level are independent: one launch, blockIdx.z picks one)
     uint32_t *range = nullptr, *range_rev = nullptr;
     unsigned long long *contenders = nullptr, *contenders_rev = nullptr; // filter -> exact kernel hand-off, one word per searched pixel
     uint32_t *work = nullptr;                 // tile work lists: per direction {declined n, whole n, declined scan, whole scan}, then two item arrays
