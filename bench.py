@@ -223,14 +223,25 @@ def main():
         # torch.distributed hook is used instead - the line says which.
         comm = None
         if not rehearsal:
+            # ncclCommInitRank is a collective: a rank that cannot even load RCCL must not leave the others waiting in
+            # it.  So every rank first probes the library locally (making an id loads librccl and resolves the symbols),
+            # the ranks agree, and only then rank 0's id goes round and the communicator is created.
+            uid_local = None
             try:
-                uid = [sharding.RcclCommunicator.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                comm = sharding.RcclCommunicator(dev, uid[0], rank, world)
-                collective = "library RCCL (cvhip_rccl_*), gather to rank 0"
+                uid_local = sharding.RcclCommunicator.unique_id()
             except Exception as exc:  # noqa: BLE001 - reported, then the hook path takes over
                 print(f"[bench] rank {rank}: library RCCL path unavailable ({exc}); using the torch.distributed hook", flush=True)
-                comm = None
+            usable = torch.tensor([1 if uid_local is not None else 0], device="cuda")
+            dist.all_reduce(usable, op=dist.ReduceOp.MIN)
+            if int(usable[0]) == 1:
+                uid = [uid_local if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                try:
+                    comm = sharding.RcclCommunicator(dev, uid[0], rank, world)
+                    collective = "library RCCL (cvhip_rccl_*), gather to rank 0"
+                except Exception as exc:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: cvhip_rccl_create failed ({exc}); using the torch.distributed hook", flush=True)
+                    comm = None
         ok = torch.tensor([1 if comm is not None else 0], device="cpu" if rehearsal else "cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # all ranks take the same path
         if int(ok[0]) == 0 and comm is not None:
