@@ -265,7 +265,30 @@ def main():
 
     l0_events = []  # (start, end) of the full-resolution level of every timed step (SURVEY §8d secondary metric)
 
+    # N > 1 only: a collective that never completes (a rank died, a link is down) would block every other rank inside
+    # RCCL for good.  A watchdog thread ends this process - loudly, with a non-zero code - when no step or fence has
+    # completed for three minutes, so a stuck run fails instead of holding its GPUs until someone else's limit.
+    progress = {"t": time.monotonic(), "what": "setup"}
+
+    def beat(what):
+        progress["t"] = time.monotonic()
+        progress["what"] = what
+
+    if world > 1:
+        import threading
+
+        def watchdog():
+            while True:
+                time.sleep(5.0)
+                idle = time.monotonic() - progress["t"]
+                if idle > 180.0:
+                    print(f"[bench] rank {rank}: no progress for {idle:.0f} s after '{progress['what']}' - aborting", flush=True)
+                    os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+
     def step(timed=False):
+        beat("step start")
         pc.first_pass = True
         for i in range(steps + 1):
             k = steps - i
@@ -282,6 +305,7 @@ def main():
         pc.complete(out_xy=out_xy, out_corr=out_corr)
 
     def fence():
+        beat("fence start")
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
