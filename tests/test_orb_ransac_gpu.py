@@ -158,6 +158,21 @@ def test_round_counting_kernel_is_exact(gpu_device, oracle, oracle_fm):
             assert (got_e[tied].view(np.uint64) == want_e[tied].view(np.uint64)).all()
         assert (got_e[want_c != top] == 0.0).all()
     assert want_c[0] > 1000
+    # coordinates at the top of the u16 range (the bounds scale with the largest coordinate) and hypotheses of
+    # arbitrary shape; thresholds again placed on individual errors of each hypothesis in turn
+    rng = np.random.default_rng(12)
+    big = rng.integers(0, 65536, size=(3000, 4)).astype(np.uint32)
+    Fb = np.stack([rng.standard_normal((3, 3)) * rng.choice([1e-6, 1e-3, 1.0, 1e3], size=(3, 3)) for _ in range(12)])
+    for hsel in range(0, 12, 3):
+        eb = np.sort(oracle_fm.reprojection_error(Fb[hsel], big))
+        for q in (0.2, 0.6):
+            t = float(eb[int(q * len(eb))])
+            if not (np.isfinite(t) and t > 0):
+                continue
+            for tt in (t, float(np.nextafter(t, 0.0)), float(np.nextafter(t, np.inf))):
+                want_c, _ = oracle.ransac_score(Fb, big, tt)
+                got_c, _ = fundamentalmatrix.ransac_round_score(gpu_device, Fb, big, tt)
+                assert (got_c == want_c).all(), (hsel, q, tt, got_c, want_c)
     # ragged sizes around the 128-match step of the kernel
     for n in (1, 63, 64, 65, 127, 128, 129, 1000):
         want_c, _ = oracle.ransac_score(F, m[:n], 20.48)
