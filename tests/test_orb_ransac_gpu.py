@@ -82,6 +82,24 @@ def test_matcher_tie_rules(gpu_device, oracle):
     assert (got_m == want_m).all() and (got_d == want_d).all()
 
 
+def test_matcher_ties_across_candidate_chunks(gpu_device, oracle):
+    """The candidate list is split across workgroups (512-descriptor chunks) that meet in an atomicMin on
+    (distance, index): equal distances in DIFFERENT chunks must still resolve to the first index, as the reference's
+    serial scan does.  Every candidate descriptor occurs 75 times, spread over all chunks; queries hit them exactly, at
+    distance 1 and at distance 2."""
+    rng = np.random.default_rng(17)
+    base = rng.integers(0, 2 ** 32, size=(40, 8), dtype=np.uint64).astype(np.uint32)
+    desc2 = np.tile(base, (75, 1))                       # 3000 candidates, duplicates 40 apart
+    desc1 = np.concatenate([base, base ^ np.uint32(1), base ^ np.uint32(3), np.roll(base, 1, axis=0)])
+    xy1 = np.stack([np.arange(len(desc1)), np.arange(len(desc1)) + 3], axis=1).astype(np.uint32)
+    xy2 = np.stack([np.arange(len(desc2)), 2 * np.arange(len(desc2))], axis=1).astype(np.uint32)
+    for thr in (0, 1, 64):
+        want_m, want_d = oracle.match_points(xy1, desc1, xy2, desc2, thr)
+        got_m, got_d = pointmatching.match_points(gpu_device, xy1, desc1, xy2, desc2, thr)
+        assert got_m.shape == want_m.shape and (got_m == want_m).all() and (got_d == want_d).all()
+    assert (want_m[:, 2] < 40).all()  # (x2 = the candidate's index: always a first occurrence)
+
+
 def ransac_inputs(n=3000, hyp=700, seed=2):
     rng = np.random.default_rng(seed)
     x1 = rng.integers(0, 2000, size=n)
