@@ -393,7 +393,7 @@ def test_device_refit_equals_host_refit_bit_for_bit(gpu_device, oracle):
         starts.append(P / P[2, 2])
     refined_some = False
     for F in starts:
-        for n in (len(inl), 1024, 1001, 808, 807, 801, 64, 15, 8, 7):
+        for n in (len(inl), 1024, 1001, 808, 807, 801, 64, 15, 8, 7, 3, 1, 0):
             host = fundamentalmatrix.optimize_perspective_f(F, inl[:n])
             dev = fundamentalmatrix.optimize_perspective_f_device(gpu_device, F, inl[:n])
             assert (host is None) == (dev is None), (n, host, dev)
