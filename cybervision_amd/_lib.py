@@ -21,6 +21,7 @@ class CvhipError(RuntimeError):
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float)
+MATCHES_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int)
 _vp = C.c_void_p
 _u32 = C.c_uint32
@@ -66,7 +67,7 @@ SIGNATURES = {
     "cvhip_ctx_set_borrow_inputs": (C.c_int, [_vp, C.c_int]),
     "cvhip_downsample_box": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
     "cvhip_resize_lanczos3": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),
-    "cvhip_orb_extract": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "cvhip_orb_extract": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32), PROGRESS_FN, _vp]),
     "cvhip_match_points": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cvhip_ransac_affine": (C.c_int, [_vp, _vp, _u32, C.c_uint64, _vp, C.POINTER(_u32), _vp]),
     "cvhip_ransac_perspective": (C.c_int, [_vp, _vp, _u32, C.c_double, C.c_uint64, _u32, _vp, C.POINTER(_u32), _vp]),
@@ -74,7 +75,8 @@ SIGNATURES = {
     "cvhip_ransac_affine_models": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp]),
     "cvhip_fits_model": (C.c_int, [_vp, _vp, _vp, _u32, C.c_double, _vp]),
     "cvhip_ransac_round_score": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp, _vp]),
-    "cvhip_find_ransac": (C.c_int, [_vp, C.c_int, _vp, _u32, C.c_double, C.c_uint64, _vp, C.POINTER(_u32), _vp]),
+    "cvhip_find_ransac": (C.c_int, [_vp, C.c_int, _vp, _u32, C.c_double, C.c_uint64, _vp, C.POINTER(_u32), _vp, PROGRESS_FN,
+                                    MATCHES_FN, _vp]),
     "cvhip_optimize_perspective_f": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "cvhip_optimize_perspective_f_device": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "cvhip_ransac_score": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp, _vp]),
@@ -112,4 +114,5 @@ def check(rc: int, where: str):
 
 
 NULL_PROGRESS = PROGRESS_FN()
+NULL_MATCHES = MATCHES_FN()
 NULL_ALLGATHER = ALLGATHER_FN()

@@ -3,6 +3,10 @@
 `python -m cybervision_amd.build` or `cybervision_amd.build.build()`.  hipcc cross-compiles
 without a GPU.  -ffp-contract=off is REQUIRED for parity: the reference (Rust) never fuses
 a*b+c, and hipcc's default for device code is -ffp-contract=fast.
+
+Every source is compiled to its own object (in parallel, only where it or a header changed) and
+the objects are linked into the one shared library; no relocatable device code is needed because
+no kernel calls across translation units.
 """
 from __future__ import annotations
 
@@ -10,14 +14,16 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
+OBJ = PKG / "build"
 LIB = PKG / "libcvhip.so"
 SOURCES = ["cvhip_api.hip", "corr_kernels.hip", "orb_kernels.hip", "ransac_kernels.hip", "track_kernels.hip", "resize_kernels.hip", "cvhip_rccl.hip"]
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
 ]
@@ -31,18 +37,39 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm under /opt/rocm)")
 
 
-def needs_build() -> bool:
-    if not LIB.exists():
+def _headers() -> list[Path]:
+    return [*CSRC.glob("*.hpp"), *CSRC.glob("*.inc"), *CSRC.glob("*.h"), PKG.parent / "include" / "cvhip.h", Path(__file__)]
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
         return True
-    t = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "cvhip.h", Path(__file__)]
+    t = target.stat().st_mtime
     return any(d.stat().st_mtime > t for d in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, [CSRC / s for s in SOURCES] + _headers())
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), *FLAGS, "-o", str(LIB), *[str(CSRC / s) for s in SOURCES], *LINK]
+    OBJ.mkdir(exist_ok=True)
+    cc, hdrs = hipcc(), _headers()
+
+    def compile_one(src: str) -> Path:
+        obj = OBJ / (src + ".o")
+        if force or _stale(obj, [CSRC / src] + hdrs):
+            cmd = [cc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *[str(o) for o in objs], *LINK]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

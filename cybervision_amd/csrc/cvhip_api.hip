@@ -439,6 +439,21 @@ static void report(cvhip_progress_fn progress, void *user, int dir, float value)
     progress(user, dir == 0 ? value * 0.98f / 2.0f : 0.51f + value * 0.98f / 2.0f);
 }
 
+void device_free(cvhip_device *dev)
+{
+    (void)hipSetDevice(dev->d.ordinal);
+    if (dev->d.stream) {
+        (void)hipStreamSynchronize(dev->d.stream);
+        if (dev->d.owns_stream) (void)hipStreamDestroy(dev->d.stream);
+    }
+    for (auto &b : dev->d.parked) free_buffer_set(b);
+    dev->d.parked.clear();
+    if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
+    if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
+    if (dev->d.orb_pattern) (void)hipFree(dev->d.orb_pattern);
+    delete dev;
+}
+
 } // namespace cvhip
 
 using namespace cvhip;
@@ -446,7 +461,7 @@ using namespace cvhip;
 extern "C" {
 
 const char *cvhip_last_error(void) { return g_last_error.c_str(); }
-uint32_t cvhip_abi_version(void) { return 1; }
+uint32_t cvhip_abi_version(void) { return 2; } // 2: listeners on cvhip_orb_extract / cvhip_find_ransac
 
 static int device_create(int low_power, int ordinal, bool caller_stream, void *hip_stream, cvhip_device **out);
 
@@ -496,16 +511,12 @@ void cvhip_device_destroy(cvhip_device *dev)
 {
     if (!dev) return;
     (void)hipSetDevice(dev->d.ordinal);
-    if (dev->d.stream) {
-        (void)hipStreamSynchronize(dev->d.stream);
-        if (dev->d.owns_stream) (void)hipStreamDestroy(dev->d.stream);
+    if (dev->d.stream) (void)hipStreamSynchronize(dev->d.stream);
+    if (dev->d.comm_refs > 0) { // a communicator still enqueues on this handle's stream: its destroy finishes the job
+        dev->d.destroy_pending = true;
+        return;
     }
-    for (auto &b : dev->d.parked) free_buffer_set(b);
-    dev->d.parked.clear();
-    if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
-    if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
-    if (dev->d.orb_pattern) (void)hipFree(dev->d.orb_pattern);
-    delete dev;
+    device_free(dev);
 }
 
 const char *cvhip_device_name(const cvhip_device *dev) { return dev ? dev->d.name.c_str() : ""; }
@@ -987,7 +998,7 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, ui
 int cvhip_ctx_set_profiling(cvhip_ctx *ctx, int time_kernels, int count_candidates)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
-    ctx->time_kernels = time_kernels ? 1 : 0;
+    ctx->time_kernels = time_kernels == 2 ? 2 : (time_kernels ? 1 : 0);
     ctx->count_candidates = count_candidates ? 1 : 0;
     return CVHIP_OK;
 }

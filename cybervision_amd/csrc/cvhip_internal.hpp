@@ -178,6 +178,10 @@ struct Device {
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     void *orb_pattern = nullptr; // the BRIEF pattern in device memory, uploaded once per handle
+    // RCCL communicators created on this handle (cvhip_rccl_create) enqueue on its stream: while any is alive,
+    // cvhip_device_destroy only marks the handle and the last cvhip_rccl_destroy frees it
+    int comm_refs = 0;
+    bool destroy_pending = false;
 };
 // -> at least `bytes` of page-locked host memory owned by the handle (nullptr: out of memory)
 inline void *pinned_scratch(Device &d, size_t bytes)
@@ -263,6 +267,10 @@ struct DirState {
 struct cvhip_device {
     cvhip::Device d;
 };
+
+namespace cvhip {
+void device_free(cvhip_device *dev); // cvhip_api.hip: what cvhip_device_destroy does once nothing references the handle
+}
 
 struct cvhip_ctx {
     cvhip_device *dev = nullptr;

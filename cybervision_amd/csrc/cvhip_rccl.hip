@@ -133,6 +133,7 @@ int cvhip_rccl_create(cvhip_device *dev, const uint8_t *id, uint32_t rank, uint3
         delete c;
         return nccl_fail("ncclCommInitRank", r);
     }
+    dev->d.comm_refs++; // the communicator uses the handle's stream: the handle outlives it (cvhip_device_destroy defers)
     *out = c;
     return CVHIP_OK;
 }
@@ -143,7 +144,10 @@ void cvhip_rccl_destroy(cvhip_rccl *comm)
     (void)hipSetDevice(comm->dev->d.ordinal);
     (void)hipStreamSynchronize(comm->dev->d.stream);
     if (comm->comm && api().CommDestroy) (void)api().CommDestroy(comm->comm);
+    cvhip_device *dev = comm->dev;
     delete comm;
+    // a cvhip_device_destroy that arrived while this communicator was alive was deferred: finish it now
+    if (--dev->d.comm_refs == 0 && dev->d.destroy_pending) cvhip::device_free(dev);
 }
 
 int cvhip_rccl_allgather(cvhip_rccl *comm, void *buf, uint64_t shard_bytes)
@@ -165,15 +169,17 @@ int cvhip_rccl_gather(cvhip_rccl *comm, void *buf, uint64_t shard_bytes, uint32_
     uint8_t *base = static_cast<uint8_t *>(buf);
     hipStream_t s = comm->dev->d.stream;
     // one grouped exchange: every other rank sends its chunk straight into the root's buffer over its own xGMI
-    // link (7 concurrent point-to-point transfers on an 8-GPU node; no ring)
+    // link (7 concurrent point-to-point transfers on an 8-GPU node; no ring).  A world of one exchanges its chunk with
+    // itself in place - the same grouped ncclSend / ncclRecv, so a single-GPU box executes this path too.
+    const bool self = comm->world == 1;
     CVHIP_TRY_NCCL(api().GroupStart());
     ncclResult_t r = ncclSuccess;
     if (comm->rank == root) {
         for (uint32_t p = 0; p < comm->world && r == ncclSuccess; p++)
-            if (p != root) r = api().Recv(base + (size_t)p * shard_bytes, (size_t)shard_bytes, ncclUint8, (int)p, comm->comm, s);
-    } else {
-        r = api().Send(base + (size_t)comm->rank * shard_bytes, (size_t)shard_bytes, ncclUint8, (int)root, comm->comm, s);
+            if (p != root || self) r = api().Recv(base + (size_t)p * shard_bytes, (size_t)shard_bytes, ncclUint8, (int)p, comm->comm, s);
     }
+    if ((comm->rank != root || self) && r == ncclSuccess)
+        r = api().Send(base + (size_t)comm->rank * shard_bytes, (size_t)shard_bytes, ncclUint8, (int)root, comm->comm, s);
     const ncclResult_t e = api().GroupEnd();
     if (r != ncclSuccess) return nccl_fail("ncclSend/ncclRecv", r);
     if (e != ncclSuccess) return nccl_fail("ncclGroupEnd", e);
@@ -199,7 +205,7 @@ int cvhip_ctx_gather_bands_rccl(cvhip_ctx *ctx, cvhip_rccl *comm, int root)
     uint32_t lw = 0, lh = 0, rps = 0;
     CVHIP_TRY(cvhip_ctx_level_grid(ctx, 0, &cells, &lw, &lh, nullptr, nullptr, &rps));
     const uint64_t shard_bytes = (uint64_t)rps * lw * sizeof(uint2);
-    if (comm->world == 1) return CVHIP_OK;
+    if (root >= (int)comm->world) return fail(CVHIP_ERR_INVALID, "root out of range");
     if (root < 0) return cvhip_rccl_allgather(comm, cells, shard_bytes);
     return cvhip_rccl_gather(comm, cells, shard_bytes, (uint32_t)root);
 }

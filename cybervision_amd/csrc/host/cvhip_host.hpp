@@ -166,12 +166,20 @@ namespace orb {
 using Keypoint = std::pair<Point2D<size_t>, std::array<uint32_t, 8>>; // orb.rs:9
 constexpr uint32_t MAX_KEYPOINTS = 10000;                            // orb.rs:41
 
-inline std::vector<Keypoint> extract_points(GpuDevice &dev, const Grid<uint8_t> &img) // orb.rs:50-84
+// orb.rs:43-48: `Option<&PL>` becomes a nullable pointer; report_status is called on the calling thread
+struct ProgressListener {
+    virtual void report_status(float pos) const = 0;
+    virtual ~ProgressListener() = default;
+};
+inline std::vector<Keypoint> extract_points(GpuDevice &dev, const Grid<uint8_t> &img,
+                                            const ProgressListener *progress_listener = nullptr) // orb.rs:50-84
 {
     std::vector<uint32_t> xy(2 * MAX_KEYPOINTS), desc(8 * MAX_KEYPOINTS);
     uint32_t n = 0;
+    const auto thunk = [](void *user, float pos) { static_cast<const ProgressListener *>(user)->report_status(pos); };
     check(cvhip_orb_extract(dev.handle(), img.data(), (uint32_t)img.width(), (uint32_t)img.height(), MAX_KEYPOINTS,
-                            xy.data(), desc.data(), &n),
+                            xy.data(), desc.data(), &n, progress_listener ? +thunk : nullptr,
+                            const_cast<ProgressListener *>(progress_listener)),
           "cvhip_orb_extract");
     std::vector<Keypoint> out(n);
     for (uint32_t i = 0; i < n; i++) {

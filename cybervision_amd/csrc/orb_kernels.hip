@@ -659,8 +659,12 @@ extern "C" int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint3
 }
 
 extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
-                                 uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n)
+                                 uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n, cvhip_progress_fn progress, void *user)
 {
+    // ProgressListener::report_status at the reference's stage boundaries (orb.rs:60-66, 93-100, 112-118, 138-146, 358-363)
+    const auto report = [&](float pos) {
+        if (progress) progress(user, pos);
+    };
     if (!dev || !img || !out_xy || !out_desc || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
     if (w < 2 * FAST_KERNEL_SIZE + 1 || h < 2 * FAST_KERNEL_SIZE + 1)
         return fail(CVHIP_ERR_INVALID, "image smaller than the FAST ring");
@@ -689,6 +693,7 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     hipLaunchKernelGGL(contrast_kernel, dim3(rblocks), dim3(256), 0, s, d_img, n, d_mm, d_adj);
     dim3 grid2d((w + 63) / 64, (h + 3) / 4);
     hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, d_adj, w, h, d_score);
+    report(0.20f);
     hipLaunchKernelGGL(nms_count_kernel, dim3(nblocks), dim3(256), 0, s, d_score, w, h, d_counts);
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, nblocks, d_total);
     uint32_t *h_n_fast = static_cast<uint32_t *>(pinned_scratch(dev->d, 4096));
@@ -697,13 +702,16 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     CVHIP_TRY_HIP(hipStreamSynchronize(s));
     CVHIP_TRY_HIP(hipGetLastError());
     const uint32_t n_fast = *h_n_fast;
+    report(0.25f);
     if (n_fast == 0) {
         *out_n = 0;
+        report(1.0f);
         return CVHIP_OK;
     }
     uint32_t *d_kp = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_kp, (size_t)n_fast * 2));
     hipLaunchKernelGGL(nms_write_kernel, dim3(nblocks), dim3(256), 0, s, d_score, w, h, d_counts, n_fast, d_kp);
+    report(0.35f);
 
     // 2. Harris on the original image, stable descending sort, top MAX_KEYPOINTS
     Taps7 k7;
@@ -724,6 +732,7 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx_sorted,
                                                  (size_t)n_fast, 0u, 64u, s));
     const uint32_t count = std::min(n_fast, MAX_KEYPOINTS); // entries past the Some(...) ones carry idx = ~0
+    report(0.70f);
 
     // 3. blur of the original image, patch moments
     Taps11 k11;
@@ -807,6 +816,7 @@ extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t
     if (!xy_dev && n_out) std::memcpy(out_xy, h_pack + 256, (size_t)n_out * 2 * sizeof(uint32_t));
     if (!desc_dev && n_out) std::memcpy(out_desc, h_pack + 256 + (size_t)out_cap * 2 * sizeof(uint32_t), (size_t)n_out * 8 * sizeof(uint32_t));
     *out_n = n_out;
+    report(1.0f);
     return CVHIP_OK;
 }
 

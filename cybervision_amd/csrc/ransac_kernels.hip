@@ -1504,6 +1504,27 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     return CVHIP_OK;
 }
 
+// The listener of the cvhip_find_ransac call in progress on this thread (fundamentalmatrix.rs:41-47, 103): the model
+// entry points below are reached through it and report once per round.
+namespace {
+struct RansacListener {
+    cvhip_progress_fn progress = nullptr;
+    cvhip_matches_fn matches = nullptr;
+    void *user = nullptr;
+    uint64_t max_matches = 0;
+    bool wants_counts() const { return matches != nullptr; }
+    void round_done(uint32_t finished, uint32_t total, bool have_count, uint64_t best_count)
+    {
+        if (progress) progress(user, (float)finished / (float)total); // counter / ransac_k, :119-123
+        if (matches && have_count) {                                  // max_matches.fetch_max(count), :126-131
+            max_matches = std::max(max_matches, best_count);
+            matches(user, max_matches);
+        }
+    }
+};
+thread_local RansacListener g_listener;
+} // namespace
+
 extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint64_t seed,
                                    double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask)
 {
@@ -1548,6 +1569,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) g_listener.round_done(round + 1, RANSAC_K / CHECK_INTERVAL, true, h_best.valid ? h_best.matches_count : 0);
         if (h_best.valid && h_best.matches_count > EARLY_EXIT) break; // :135-141
     }
     int rc = CVHIP_OK;
@@ -1653,9 +1675,13 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
                            (const uint32_t *)(d_live + H + 1), d_best);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(scored[b], s);
-        if (!may_exit_early && round + 1 < rounds) continue;
+        if (!may_exit_early && !g_listener.wants_counts() && round + 1 < rounds) {
+            g_listener.round_done(round + 1, rounds, false, 0); // position only: the round is enqueued, not finished
+            continue;
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) g_listener.round_done(round + 1, rounds, true, h_best.valid ? h_best.matches_count : 0);
         if (h_best.valid && h_best.matches_count > early_exit) break; // :135-141
     }
     for (uint32_t k = 0; k < GEN_STREAMS; k++)
@@ -2109,9 +2135,20 @@ extern "C" int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32
 // + optimize_result :231-257): the device RANSAC of the model, then for the perspective model the reference's LM
 // refit of the winner on its inliers and the re-selection of the inliers with the refitted matrix.
 extern "C" int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32_t *matches, uint32_t N, double max_dimension,
-                                 uint64_t seed, double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask)
+                                 uint64_t seed, double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask,
+                                 cvhip_progress_fn progress, cvhip_matches_fn report_matches, void *user)
 {
     if (projection != 0 && projection != 1) return fail(CVHIP_ERR_INVALID, "projection must be 0 or 1");
+    struct ListenerScope { // the listener is this call's: installed for its duration on this thread
+        ListenerScope(cvhip_progress_fn p, cvhip_matches_fn m, void *u)
+        {
+            g_listener = RansacListener{};
+            g_listener.progress = p;
+            g_listener.matches = m;
+            g_listener.user = u;
+        }
+        ~ListenerScope() { g_listener = RansacListener{}; }
+    } scope(progress, report_matches, user);
     if (projection == 0) return cvhip_ransac_affine(dev, matches, N, seed, out_F, out_inlier_count, out_inlier_mask);
     if (!dev || !matches || !out_F) return fail(CVHIP_ERR_INVALID, "null argument");
     try {

@@ -7,9 +7,9 @@
 // each output sample a normalised weighted sum over the source samples within `support * max(ratio, 1)` of its
 // centre, all in f32, weights w((i - (centre - 0.5)) / sratio) with the Lanczos3 window sinc(x) sinc(x / 3),
 // accumulated in source order, clamped to [0, 255] and rounded to nearest after the second pass only.  Equal
-// dimensions are a plain copy.  TOLERANCE parity (stated in the tests: at most one grey level, on < 0.1 % of the
-// pixels, against an independent numpy restatement): the weights go through libm's sinf, which is not
-// reproducible across platforms, and nothing in the reference pins the crate's output.
+// dimensions are a plain copy.  The weights go through glibc's sinf (Rust's f32::sin on linux-gnu); everything else
+// is one IEEE f32 operation per step in the crate's order (-ffp-contract=off), so the output equals the oracle's
+// restatement byte for byte (tests/test_resize.py, MAX_DIFF = 0).  Nothing in the reference pins the crate's output.
 // The weight tables are built on the host (glibc sinf, like the reference's host code) - one row of taps per output
 // row / column - and the two passes are plain streaming kernels (coalesced along x).
 #include "cvhip_internal.hpp"

@@ -156,15 +156,19 @@ class FundamentalMatrix:
         self.max_dimension = float(max_dimension)
         self.ransac_t = RANSAC_T_AFFINE if self.projection == ProjectionMode.Affine else RANSAC_T_PERSPECTIVE * self.max_dimension
 
-    def find_ransac(self, device, point_matches, seed: int = 0):
+    def find_ransac(self, device, point_matches, seed: int = 0, progress_listener=None):
         """-> (F [3, 3] float64, inliers [n, 4] uint32, inlier_mask [N] bool).  Raises CvhipError (code -5) with the
-        reference's RansacError messages ("Not enough matches", "No reliable matches found")."""
+        reference's RansacError messages ("Not enough matches", "No reliable matches found").  progress_listener:
+        the reference's `Option<&PL>` (:41-47, 103) - an object with report_status(pos) and report_matches(count)."""
         m = _matches(point_matches)
         N = len(m)
         F = np.zeros(9, dtype=np.float64)
         mask = np.zeros(max(N, 1), dtype=np.uint8)
         cnt = C.c_uint32(0)
+        pl = progress_listener
+        cb_s = _lib.PROGRESS_FN(lambda _u, v: pl.report_status(v)) if pl is not None else _lib.NULL_PROGRESS
+        cb_m = _lib.MATCHES_FN(lambda _u, c: pl.report_matches(int(c))) if pl is not None else _lib.NULL_MATCHES
         _lib.check(_lib.lib().cvhip_find_ransac(device.handle, int(self.projection), _p(m), N, self.max_dimension, seed,
-                                                _p(F), C.byref(cnt), _p(mask)), "cvhip_find_ransac")
+                                                _p(F), C.byref(cnt), _p(mask), cb_s, cb_m, None), "cvhip_find_ransac")
         mask = mask[:N].astype(bool)
         return F.reshape(3, 3), m[mask], mask

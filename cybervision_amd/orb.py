@@ -20,8 +20,9 @@ def optimal_scale_steps(width: int, height: int) -> int:
     return int(math.floor(math.log2(m / KEYPOINT_SCALE_MIN_SIZE)))
 
 
-def extract_points(device, img, cap: int = MAX_KEYPOINTS):
-    """-> (xy[n, 2] uint32, desc[n, 8] uint32), in the reference's order."""
+def extract_points(device, img, cap: int = MAX_KEYPOINTS, progress=None):
+    """-> (xy[n, 2] uint32, desc[n, 8] uint32), in the reference's order.  progress(pos): the reference's
+    `Option<&PL>` (orb.rs:43-53), called at its stage boundaries."""
     if hasattr(img, "data_ptr"):
         ptr, w, h = C.c_void_p(img.data_ptr()), int(img.shape[1]), int(img.shape[0])
     else:
@@ -30,8 +31,9 @@ def extract_points(device, img, cap: int = MAX_KEYPOINTS):
     xy = np.zeros((cap, 2), dtype=np.uint32)
     desc = np.zeros((cap, 8), dtype=np.uint32)
     n = C.c_uint32(0)
+    cb = _lib.PROGRESS_FN(lambda _u, v: progress(v)) if progress else _lib.NULL_PROGRESS
     _lib.check(_lib.lib().cvhip_orb_extract(device.handle, ptr, w, h, cap, C.c_void_p(xy.ctypes.data),
-                                            C.c_void_p(desc.ctypes.data), C.byref(n)), "cvhip_orb_extract")
+                                            C.c_void_p(desc.ctypes.data), C.byref(n), cb, None), "cvhip_orb_extract")
     return xy[:n.value].copy(), desc[:n.value].copy()
 
 

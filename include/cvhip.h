@@ -46,6 +46,9 @@ typedef struct cvhip_ctx cvhip_ctx;
 /* Progress hook: replaces ProgressListener::report_status (correlation/mod.rs:56-61).
  * Invoked synchronously on the calling thread between kernel submissions; never retained. */
 typedef void (*cvhip_progress_fn)(void *user, float pos);
+/* fundamentalmatrix.rs:41-47: the RANSAC listener's second method, ProgressListener::report_matches(matches_count) -
+ * the largest inlier count seen so far.  Same rules as cvhip_progress_fn. */
+typedef void (*cvhip_matches_fn)(void *user, uint64_t matches_count);
 
 /* Message of the calling thread's last error ("" if none). Static lifetime per thread. */
 const char *cvhip_last_error(void);
@@ -257,8 +260,10 @@ int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint32_t w, uint
  * Luma8 image to nw x nh (the caller passes (w as f32 * scale) as u32, (h as f32 * scale) as u32, :149-150).  The
  * `image` crate (0.25.10) is not vendored with the reference; this is its published separable algorithm (vertical pass
  * to f32, horizontal pass, f32 weights normalised per output sample, clamp + round to nearest at the end; equal
- * dimensions are a copy) - TOLERANCE parity: the tests allow one grey level on < 0.1 % of the pixels against an
- * independent restatement, and nothing pins either to the crate.  Host or device pointers. */
+ * dimensions are a copy).  Weights come from glibc's sinf on the host (what Rust's f32::sin resolves to on linux-gnu);
+ * every other step is a single IEEE f32 operation in the crate's order, so the bytes equal the oracle's restatement
+ * (oracle/cvref_resize.py, same sinf) exactly - tested with MAX_DIFF = 0.  Nothing pins either to the crate itself
+ * ("parity unpinned").  Host or device pointers. */
 int cvhip_resize_lanczos3(cvhip_device *dev, const uint8_t *src, uint32_t w, uint32_t h, uint8_t *dst, uint32_t nw,
                           uint32_t nh);
 
@@ -267,9 +272,13 @@ int cvhip_resize_lanczos3(cvhip_device *dev, const uint8_t *src, uint32_t w, uin
  * out_xy: 2*cap u32 (x, y), out_desc: 8*cap u32, *out_n = keypoints written (<= cap).
  * Order = the reference's (Harris-descending stable, then BRIEF filter).  cap >= 10000 to
  * receive everything the reference returns (MAX_KEYPOINTS, orb.rs:41).
+ * progress (may be NULL) replaces `Option<&PL>` (orb.rs:43-53): the reference reports from inside its parallel
+ * loops, FAST rows 0 .. 0.20 (orb.rs:93-100), scores .. 0.25 (:112-118), non-maximum suppression .. 0.35 (:138-146),
+ * Harris .. 0.70 (:60-66), BRIEF .. 1.0 (:358-363); here the same positions are reported on the calling thread as
+ * the stages complete (0.25 and 1.0 after the stage's results have reached the host, the others at submission).
  * ---------------------------------------------------------------------------------------- */
 int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
-                      uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n);
+                      uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n, cvhip_progress_fn progress, void *user);
 
 /* ------------------------------------------------------------------------------------------
  * Keypoint matcher — replaces KeypointMatching::match_points (pointmatching.rs:43-77).
@@ -341,9 +350,15 @@ int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint32_t H, con
  * and optimize_result :231-257): cvhip_ransac_affine for projection 0 (max_dimension unused); for projection 1
  * cvhip_ransac_perspective, then the LM refit of the winner on its inliers (cvhip_optimize_perspective_f_device: the
  * reference's loop, values equal to the host function's) and the inliers of the refitted matrix.  This is what reconstruction.rs:502-526
- * calls.  out_F: 9 doubles row-major; out_inlier_mask: N bytes (may be NULL). */
+ * calls.  out_F: 9 doubles row-major; out_inlier_mask: N bytes (may be NULL).
+ * progress / report_matches (either may be NULL) replace `Option<&PL>` (fundamentalmatrix.rs:41-47, 103): the reference
+ * reports iteration / ransac_k per iteration (:119-123) and the running maximum of the inlier counts (:126-131); here
+ * both are reported once per 50 000-iteration round on the calling thread - pos = finished rounds / 20 - and, because
+ * report_matches needs the round's best count on the host, a listener costs one 4-byte read per round that a call
+ * without one only pays where the early exit (:135-141) can fire. */
 int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32_t *matches, uint32_t N, double max_dimension,
-                      uint64_t seed, double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask);
+                      uint64_t seed, double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask,
+                      cvhip_progress_fn progress, cvhip_matches_fn report_matches, void *user);
 /* optimize_perspective_f (fundamentalmatrix.rs:391-426) as optimize_result applies it to the winning model
  * (:246): the reference's own Levenberg-Marquardt loop (least_squares, :515-621) with its analytic Jacobian
  * (f_jacobian, :473-512) over the 7 free parameters of F (:429-449), then the rank test (:418-423).  Host

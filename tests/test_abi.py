@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def _declared_symbols():
     text = (ROOT / "include" / "cvhip.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cvhip_[a-z0-9_]+)\s*\(", text)) - {"cvhip_progress_fn"})
+    return sorted(set(re.findall(r"\b(cvhip_[a-z0-9_]+)\s*\(", text)) - {"cvhip_progress_fn", "cvhip_matches_fn"})
 
 
 def test_header_declares_symbols():
@@ -33,7 +33,7 @@ def test_binding_table_matches_header():
     from cybervision_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib().cvhip_abi_version() == 1
+    assert _lib.lib().cvhip_abi_version() == 2
 
 
 def test_no_product_dependency_on_oracle():

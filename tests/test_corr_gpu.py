@@ -815,3 +815,98 @@ def test_independent_band_mode_eight_bands_1024(gpu_device):
         assert_same_grid(main.complete(F), want, "1024^2 stitched from 8 independent bands")
     finally:
         main.close()
+
+
+def _digest_of(xy, corr):
+    import hashlib
+
+    valid = xy[..., 0] >= 0
+    score_bits = np.where(valid, corr.view(np.uint32), np.uint32(0))
+    return (int(valid.sum()), hashlib.sha256(np.ascontiguousarray(xy, dtype=np.int32).tobytes()).hexdigest(),
+            hashlib.sha256(np.ascontiguousarray(score_bits).tobytes()).hexdigest())
+
+
+@pytest.mark.parametrize("den", [2, 4, 8])
+def test_config4_band_plan_4096_matches_oracle_digest(gpu_device, den):
+    """BASELINE config 4 as far as one GPU allows: the N-rank independent-band plan (cvhip_ctx_set_row_band(r, N)) on the
+    4096^2 headline pair.  The N band contexts run one after the other on this GPU - each the whole 7-level pyramid on
+    its band + halo, no exchange between levels - their forward bands are stitched into context 0 (what the single
+    RCCL gather does on an N-GPU node) and complete()'s grid must hash to the ORACLE's full-size digest."""
+    import json
+    import torch
+
+    from cybervision_amd import sharding
+
+    want = json.loads((Path(__file__).parent / "golden" / "corr_4096_digest.json").read_text())
+    size = want["size"]
+    a, b, _ = synth.make_pair(size, size)
+    steps = synth.optimal_scale_steps(size, size)
+    c = dict(img1=a, img2=b, F=synth.F_HORIZONTAL, projection=0, steps=steps)
+    p1, p2 = cases.pyramids(c)
+    Fd = correlation.CorrelationDirection.Forward
+    main = correlation.PointCorrelations(gpu_device, (size, size), (size, size), c["F"])
+    try:
+        for r in range(den):
+            pc = main if r == 0 else correlation.PointCorrelations(gpu_device, (size, size), (size, size), c["F"])
+            try:
+                assert pc.set_row_band(r, den), "the headline geometry is row-local"
+                for i in range(steps + 1):
+                    k = steps - i
+                    pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+                gpu_device.synchronize()
+                if r:
+                    g, g0 = pc.level_grid(Fd), main.level_grid(Fd)
+                    assert (g["lw"], g["lh"]) == (size, size)
+                    r0, r1 = sharding.shard_rows(g["lh"], r, den)
+                    assert r1 - r0 == size // den
+                    nbytes = (r1 - r0) * g["lw"] * 8
+                    sharding.alias_bytes(g0["cells"] + r0 * g["lw"] * 8, nbytes, True).copy_(
+                        sharding.alias_bytes(g["cells"] + r0 * g["lw"] * 8, nbytes, True))
+                    torch.cuda.synchronize()
+            finally:
+                if r:
+                    pc.close()
+        xy, corr = main.complete(Fd)
+    finally:
+        main.close()
+    n, xy_sha, score_sha = _digest_of(xy, corr)
+    assert n == want["forward"]["matches"]
+    assert xy_sha == want["forward"]["xy_sha256"], f"4096^2 stitched from {den} bands: match plane differs from the oracle"
+    assert score_sha == want["forward"]["score_sha256"], f"4096^2 stitched from {den} bands: scores differ from the oracle"
+
+
+def test_library_rccl_path_world1(oracle):
+    """The collectives inside the library (cvhip_rccl_*), at the world size one GPU allows: id -> communicator on a
+    device handle that owns a PRIVATE stream -> cvhip_ctx_set_row_shard_rccl drives a whole pyramid (the all-gather hook
+    fires after every search pass of a sharded level) -> in-place ncclAllGather of the level grid -> the band gather,
+    which exchanges the chunk with itself through the same grouped ncclSend / ncclRecv the N-rank gather uses.  The grid
+    must still be the oracle's afterwards.  Lifetime: the device handle is destroyed BEFORE the communicator; the
+    library defers the handle's release to cvhip_rccl_destroy."""
+    from cybervision_amd import sharding
+
+    c = cases.make_case("sem320x200")
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    want = run_oracle(oracle, c)
+    Fd = correlation.CorrelationDirection.Forward
+    dev = correlation.create_gpu_context()  # private stream
+    comm = sharding.RcclCommunicator(dev, sharding.RcclCommunicator.unique_id(), 0, 1)
+    pc = correlation.PointCorrelations(dev, (w1, h1), (w2, h2), c["F"])
+    try:
+        pc.set_row_shard_rccl(comm)
+        for i in range(c["steps"] + 1):
+            k = c["steps"] - i
+            pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+        g = pc.level_grid(Fd)
+        assert g["rows_per_shard"] == g["lh"] == h1
+        comm.allgather(g["cells"], g["rows_per_shard"] * g["lw"] * 8)   # ncclAllGather, in place, on the handle's stream
+        comm.gather(g["cells"], g["rows_per_shard"] * g["lw"] * 8, 0)   # grouped ncclSend + ncclRecv (self exchange)
+        pc.gather_bands_rccl(comm, 0)                                   # the same through the context
+        pc.gather_bands_rccl(comm, -1)                                  # "to every rank" = all-gather
+        dev.synchronize()
+        assert_same_grid(pc.complete(Fd), want, "library RCCL path, world 1")
+    finally:
+        pc.close()
+        dev.close()    # deferred: the communicator still references the handle
+        comm.close()   # releases both

@@ -442,3 +442,45 @@ def test_orb_multiscale_driver_matches_oracle(gpu_device, oracle):
     want_xy, want_desc = np.concatenate(want_xy), np.concatenate(want_desc)
     assert len(want_xy) > 1000
     assert (got_xy == want_xy).all() and (got_desc == want_desc).all()
+
+
+def test_progress_listeners_of_orb_and_ransac(gpu_device):
+    """`Option<&PL>` of orb::extract_points (orb.rs:43-53) and find_ransac (fundamentalmatrix.rs:41-47, 103) through the
+    ABI: positions rise through the reference's stage boundaries to 1.0, report_matches carries the running maximum of
+    the inlier counts, and a listener changes nothing about the results."""
+    import cases
+
+    img = orb_image(640, 480)
+    pos = []
+    xy, desc = orb.extract_points(gpu_device, img, progress=pos.append)
+    xy0, desc0 = orb.extract_points(gpu_device, img)
+    assert (xy == xy0).all() and (desc == desc0).all() and len(xy) > 100
+    assert pos == sorted(pos) and pos[0] == pytest.approx(0.20) and pos[-1] == 1.0
+    assert [round(p, 2) for p in pos] == [0.20, 0.25, 0.35, 0.70, 1.0]
+    pos = []
+    assert len(orb.extract_points(gpu_device, np.full((64, 64), 7, dtype=np.uint8), progress=pos.append)[0]) == 0
+    assert pos[-1] == 1.0  # no corners: the listener still sees the end
+
+    class Listener:
+        def __init__(self):
+            self.status, self.matches = [], []
+
+        def report_status(self, p):
+            self.status.append(p)
+
+        def report_matches(self, c):
+            self.matches.append(c)
+
+    m, truth, _, _ = cases.perspective_matches(n=4000, outlier_frac=0.3)
+    fmx = fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Perspective, 2048.0)
+    pl = Listener()
+    F, inliers, mask = fmx.find_ransac(gpu_device, m, seed=3, progress_listener=pl)
+    F0, _, mask0 = fmx.find_ransac(gpu_device, m, seed=3)
+    assert (F == F0).all() and (mask == mask0).all()
+    assert len(pl.status) == 20 and pl.status == sorted(pl.status) and pl.status[-1] == 1.0  # 20 rounds, no early exit
+    assert len(pl.matches) == 20 and pl.matches == sorted(pl.matches) and 0.9 * truth.sum() < pl.matches[-1] <= len(m)
+    ma, truth_a, _ = affine_matches()
+    pl = Listener()
+    fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Affine, 2000.0).find_ransac(gpu_device, ma, seed=7, progress_listener=pl)
+    assert 1 <= len(pl.status) <= 20 and pl.status == sorted(pl.status)   # early exit above 1000 inliers (:135-141)
+    assert pl.matches == sorted(pl.matches) and pl.matches[-1] > 1000

@@ -1,15 +1,15 @@
 """Pyramid levels: SourceImage::resize = the `image` crate's Lanczos3
-(reconstruction.rs:146-162).  TOLERANCE parity - the crate is not vendored with the reference and f32 sin differs
-between libm implementations: the device (weights from glibc sinf on the host, f32 accumulation in tap order) must
-agree with the oracle's independent numpy restatement (numpy's own f32 sin) to within ONE grey level, on fewer than
-0.1 % of the pixels."""
+(reconstruction.rs:146-162).  The crate is not vendored with the reference, so nothing pins either side to it
+("parity unpinned"); but the device (weights from glibc sinf on the host, f32 accumulation in tap order, no
+contraction) and the oracle's numpy restatement (the same glibc sinf through ctypes, the same single IEEE f32
+operations in the same order) must agree BIT FOR BIT: byte output, MAX_DIFF = 0."""
 import numpy as np
 import pytest
 
 from cybervision_amd import synth
 
-MAX_DIFF = 1            # grey levels
-MAX_FRACTION = 1e-3     # of the pixels
+MAX_DIFF = 0            # grey levels: byte output is bit-exact against the oracle
+MAX_FRACTION = 0.0      # of the pixels
 
 
 @pytest.fixture(scope="module")

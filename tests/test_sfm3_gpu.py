@@ -113,7 +113,10 @@ def test_sfm3_full_size_properties_2048(gpu_device, oracle_fm):
     views, pyramids, K, poses = build_views(size)
     dev_pyr = [[torch.from_numpy(l).cuda() for l in p] for p in pyramids]
     res = reconstruction.reconstruct_pairs(gpu_device, dev_pyr, fundamentalmatrix.ProjectionMode.Perspective, seed=5)
-    assert [len(k[0]) for k in res["keypoints"]] == [len(k[0]) for k in res["keypoints"]]
+    # determinism of the sparse front end: a second extraction of every view gives the same keypoints and descriptors
+    again = [reconstruction.ImageReconstruction(gpu_device).extract_keypoints(p) for p in dev_pyr]
+    for (xy_a, desc_a), (xy_b, desc_b) in zip(res["keypoints"], again):
+        assert xy_a.shape == xy_b.shape and (xy_a == xy_b).all() and (desc_a == desc_b).all()
     assert all(10000 < len(k[0]) <= 40000 for k in res["keypoints"])  # <= 10 000 per level, 4 levels
     t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * size
     rec = reconstruction.ImageReconstruction(gpu_device)
