@@ -63,6 +63,8 @@ SIGNATURES = {
     "cvhip_ctx_get_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_u32), C.c_int]),
     "cvhip_ctx_get_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int]),
     "cvhip_ctx_set_range_mode": (C.c_int, [_vp, C.c_int]),
+    "cvhip_ctx_set_exact_scores": (C.c_int, [_vp, C.c_int]),
+    "cvhip_ctx_set_async_readback": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_search_version": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_borrow_inputs": (C.c_int, [_vp, C.c_int]),
     "cvhip_downsample_box": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),

@@ -218,6 +218,16 @@ class PointCorrelations:
     def set_search_version(self, version: int):
         _lib.check(_lib.lib().cvhip_ctx_set_search_version(self._h, version), "cvhip_ctx_set_search_version")
 
+    def set_async_readback(self, enable: bool):
+        """complete() into page-locked HOST arrays returns once the copies are enqueued; they are complete after
+        device.synchronize() (include/cvhip.h)."""
+        _lib.check(_lib.lib().cvhip_ctx_set_async_readback(self._h, int(enable)), "cvhip_ctx_set_async_readback")
+
+    def set_exact_scores(self, all_passes: bool):
+        """Scores of EVERY pass are the reference's bits (default: only the observable ones - the forward pass at
+        scale 1; include/cvhip.h).  Positions are exact either way."""
+        _lib.check(_lib.lib().cvhip_ctx_set_exact_scores(self._h, int(all_passes)), "cvhip_ctx_set_exact_scores")
+
     def set_range_mode(self, mode: int):
         """Test hook of the search-range kernel (include/cvhip.h): 0 default, 1 chain only, 2 / 3 mixed paths."""
         _lib.check(_lib.lib().cvhip_ctx_set_range_mode(self._h, mode), "cvhip_ctx_set_range_mode")

@@ -1263,7 +1263,16 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
             float bcorr = 0.0f;
             uint32_t bxy = 0;
             const float avg1 = ps.st1.x, sdev1 = ps.st1.y;
-            for (uint32_t j = 0; j < count; j++) {
+            // positions-only pass (CorrParams::need_scores): a single contender clearly above the threshold IS the
+            // match - every other candidate has g < g* - 2 delta, hence f < f*, and f* >= g* - delta >= threshold
+            uint32_t ecount = count;
+            if (!p.need_scores && count == 1u && runmax >= p.threshold + S2_DELTA) {
+                const uint32_t code = (uint32_t)clist & 0x7FFFu;
+                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                cell = make_uint2(c.x | (c.y << 16), __float_as_uint(runmax));
+                ecount = 0u;
+            }
+            for (uint32_t j = 0; j < ecount; j++) {
                 const uint32_t code = (uint32_t)(clist >> (15u * j)) & 0x7FFFu;
                 const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
                 const uint2 is2 = lds_is[(c.y - (uint32_t)cy0) * cw + (c.x - (uint32_t)cx0)];

@@ -234,6 +234,7 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
     p.pk = ds.k;
     p.k = (uint32_t)k;
     p.first_pass = first_pass ? 1 : 0;
+    p.need_scores = (dir == 0 && k == 0) || c->exact_scores ? 1 : 0;
     const double *F = p.F;
     const bool affine_form = F[0] == 0.0 && F[1] == 0.0 && F[3] == 0.0 && F[4] == 0.0;
     p.affine = 0;
@@ -448,6 +449,17 @@ void device_free(cvhip_device *dev)
     }
     for (auto &b : dev->d.parked) free_buffer_set(b);
     dev->d.parked.clear();
+    {
+        auto &rb = dev->d.rb;
+        if (rb.stream) (void)hipStreamSynchronize(rb.stream);
+        for (int i = 0; i < 2; i++) {
+            if (rb.xy[i]) (void)hipFree(rb.xy[i]);
+            if (rb.corr[i]) (void)hipFree(rb.corr[i]);
+            if (rb.done[i]) (void)hipEventDestroy(rb.done[i]);
+        }
+        if (rb.ready) (void)hipEventDestroy(rb.ready);
+        if (rb.stream) (void)hipStreamDestroy(rb.stream);
+    }
     if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
     if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
     if (dev->d.orb_pattern) (void)hipFree(dev->d.orb_pattern);
@@ -526,6 +538,7 @@ int cvhip_device_synchronize(cvhip_device *dev)
     if (!dev) return fail(CVHIP_ERR_INVALID, "dev is null");
     CVHIP_TRY(set_device(dev));
     CVHIP_TRY_HIP(hipStreamSynchronize(dev->d.stream));
+    if (dev->d.rb.stream) CVHIP_TRY_HIP(hipStreamSynchronize(dev->d.rb.stream)); // asynchronous readbacks in flight
     return CVHIP_OK;
 }
 
@@ -770,6 +783,33 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     return CVHIP_OK;
 }
 
+// The staging sets of host-destination complete() calls (Device::Readback): room for n pixels, stream and events made.
+static int readback_reserve(Device &d, size_t n)
+{
+    auto &rb = d.rb;
+    if (!rb.stream) {
+        CVHIP_TRY_HIP(hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+        CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.ready, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.done[i], hipEventDisableTiming));
+    }
+    if (n <= rb.cap_px) return CVHIP_OK;
+    CVHIP_TRY_HIP(hipStreamSynchronize(rb.stream));
+    for (int i = 0; i < 2; i++) {
+        if (rb.xy[i]) (void)hipFree(rb.xy[i]);
+        if (rb.corr[i]) (void)hipFree(rb.corr[i]);
+        rb.xy[i] = nullptr;
+        rb.corr[i] = nullptr;
+        rb.pending[i] = false;
+    }
+    rb.cap_px = 0;
+    for (int i = 0; i < 2; i++) {
+        CVHIP_TRY_HIP(hipMalloc(&rb.xy[i], n * 2 * sizeof(int32_t)));
+        CVHIP_TRY_HIP(hipMalloc(&rb.corr[i], n * sizeof(float)));
+    }
+    rb.cap_px = n;
+    return CVHIP_OK;
+}
+
 int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr)
 {
     if (!ctx || !out_xy) return fail(CVHIP_ERR_INVALID, "null argument");
@@ -780,15 +820,20 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
     const size_t n = (size_t)ds.gw * ds.gh;
     const bool xy_dev = is_device_ptr(out_xy);
     const bool corr_dev = out_corr ? is_device_ptr(out_corr) : true;
+    const bool to_host = !xy_dev || (out_corr && !corr_dev);
     int32_t *d_xy = out_xy;
     float *d_corr = out_corr;
-    if (!xy_dev) CVHIP_TRY_HIP(hipMalloc(&d_xy, n * 2 * sizeof(int32_t)));
-    if (out_corr && !corr_dev) {
-        hipError_t e = hipMalloc(&d_corr, n * sizeof(float));
-        if (e != hipSuccess) {
-            if (!xy_dev) (void)hipFree(d_xy);
-            return fail(CVHIP_ERR_NOMEM, "allocating readback buffer");
-        }
+    auto &rb = ctx->dev->d.rb;
+    int set = 0;
+    if (to_host) {
+        // Host destinations: the grid is expanded into one of two device staging sets owned by the handle and copied
+        // out on the handle's copy stream; the set being refilled waits (on the device) for its previous copy.
+        CVHIP_TRY(readback_reserve(ctx->dev->d, n));
+        set = rb.next;
+        rb.next ^= 1;
+        if (rb.pending[set]) CVHIP_TRY_HIP(hipStreamWaitEvent(s, rb.done[set], 0));
+        if (!xy_dev) d_xy = rb.xy[set];
+        if (out_corr && !corr_dev) d_corr = rb.corr[set];
     }
     if (ds.valid) {
         (void)timed(ctx, cvhip_ctx::K_EXPAND,
@@ -797,16 +842,20 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
         launch_fill_u32(reinterpret_cast<uint32_t *>(d_xy), 0xFFFFFFFFu, n * 2, s);
         if (d_corr) launch_fill_u32(reinterpret_cast<uint32_t *>(d_corr), 0x7FC00000u, n, s);
     }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && !xy_dev) e = hipMemcpyAsync(out_xy, d_xy, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && out_corr && !corr_dev)
-        e = hipMemcpyAsync(out_corr, d_corr, n * sizeof(float), hipMemcpyDeviceToHost, s);
-    // Host destinations are complete on return; device destinations are written in stream order on the
-    // context's stream (no host synchronisation: the caller's next submission simply queues behind it).
-    if (e == hipSuccess && (!xy_dev || (out_corr && !corr_dev))) e = hipStreamSynchronize(s);
-    if (!xy_dev) (void)hipFree(d_xy);
-    if (out_corr && !corr_dev) (void)hipFree(d_corr);
-    if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("complete: ") + hipGetErrorString(e));
+    CVHIP_TRY_HIP(hipGetLastError());
+    if (to_host) {
+        CVHIP_TRY_HIP(hipEventRecord(rb.ready, s));
+        CVHIP_TRY_HIP(hipStreamWaitEvent(rb.stream, rb.ready, 0));
+        if (!xy_dev) CVHIP_TRY_HIP(hipMemcpyAsync(out_xy, d_xy, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, rb.stream));
+        if (out_corr && !corr_dev)
+            CVHIP_TRY_HIP(hipMemcpyAsync(out_corr, d_corr, n * sizeof(float), hipMemcpyDeviceToHost, rb.stream));
+        CVHIP_TRY_HIP(hipEventRecord(rb.done[set], rb.stream));
+        rb.pending[set] = true;
+        // Host destinations are complete on return - unless the caller asked for asynchronous readback
+        // (cvhip_ctx_set_async_readback: page-locked destinations, completion at cvhip_device_synchronize).  Device
+        // destinations are written in stream order on the context's stream (no host synchronisation).
+        if (!ctx->async_readback) CVHIP_TRY_HIP(hipStreamSynchronize(rb.stream));
+    }
     return CVHIP_OK;
 }
 
@@ -1058,6 +1107,20 @@ int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
     ctx->borrow_inputs = borrow != 0;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_async_readback(cvhip_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    ctx->async_readback = enable != 0;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_exact_scores(cvhip_ctx *ctx, int all_passes)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    ctx->exact_scores = all_passes != 0;
     return CVHIP_OK;
 }
 

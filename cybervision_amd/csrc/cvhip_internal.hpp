@@ -55,6 +55,12 @@ struct CorrParams {
     uint32_t k;              // this level's k
     uint32_t row0, row1;     // rows of the searched image handled by this launch
     int first_pass;
+    // 1: the scores this pass writes can reach the caller and must be the reference's bits - the forward pass of the
+    // full-resolution level, or every pass under cvhip_ctx_set_exact_scores.  0: only the match POSITIONS of this pass
+    // are ever read (search range and cross-check of the next passes; the reference overwrites the cells of a coarser
+    // level, mod.rs:311-316, and drops the reverse grid, mod.rs:208-215), so a pixel whose filter band holds ONE
+    // contender clearly above the threshold is settled without the exact 121-term evaluation.
+    int need_scores;
     // Affine F (first two columns zero): F*p = (F02, F12, .) for every finite pixel, so the epipolar line's direction
     // is one constant, evaluated once on the host with the reference's expression (mod.rs:397-408; IEEE division,
     // the same bits as on the device).  affine = 1: the |l.x| > |l.y| branch, aff_c = -F12/F02, aff_div = F02;
@@ -178,6 +184,18 @@ struct Device {
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     void *orb_pattern = nullptr; // the BRIEF pattern in device memory, uploaded once per handle
+    // complete() into HOST memory (GpuContext::complete_process, gpu/mod.rs:210-216): two device staging sets that the
+    // full-resolution grid is expanded into, and a copy stream of its own, so that the 12 B/px transfer of one pair can
+    // run under the search of the next (cvhip_ctx_set_async_readback) and no call allocates.  Grow-only, per handle.
+    struct Readback {
+        int32_t *xy[2] = {nullptr, nullptr};
+        float *corr[2] = {nullptr, nullptr};
+        size_t cap_px = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
+        bool pending[2] = {false, false};
+        int next = 0;
+    } rb;
     // RCCL communicators created on this handle (cvhip_rccl_create) enqueue on its stream: while any is alive,
     // cvhip_device_destroy only marks the handle and the last cvhip_rccl_destroy frees it
     int comm_refs = 0;
@@ -290,6 +308,8 @@ struct cvhip_ctx {
     uint2 *istats[2] = {nullptr, nullptr};
     // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,
     // 3 = displacement-plane box filter (falls back to 2 per workgroup) + exact re-evaluation
+    bool async_readback = false; // cvhip_ctx_set_async_readback
+    bool exact_scores = false; // cvhip_ctx_set_exact_scores: every pass writes the reference's scores (tests)
     int search_version = 3;
     int range_mode = 0; // search_range_kernel: 0 = integer box sums + chain where needed, 1 = chain only, 2 / 3 = test hooks
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)

@@ -114,6 +114,13 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
  * or any later work on that stream, orders after them).  The context can be destroyed or reused
  * for cvhip_complete_dir afterwards. */
 int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr);
+/* Asynchronous readback for pipelines that correlate pair after pair (reconstruction.rs:680-730): with enable = 1,
+ * cvhip_complete into HOST destinations returns once the copies are enqueued - on the handle's own copy stream, behind
+ * the grid expansion, from one of two device staging sets - so that the 12 B/px transfer of this pair runs under the
+ * search of the next.  The destinations must be page-locked (hipHostMalloc / hipHostRegister; a pageable destination
+ * makes the copy synchronous again) and are complete after cvhip_device_synchronize; at most two readbacks are in
+ * flight per device handle (a third waits, on the device, for the first).  Default 0: complete on return. */
+int cvhip_ctx_set_async_readback(cvhip_ctx *ctx, int enable);
 /* Same for either direction (dir 1 = correlated_points_reverse, mod.rs:65); test hook. */
 int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr);
 
@@ -241,6 +248,16 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
  * epipolar lines), with 2 for every other geometry and as the per-workgroup fallback; 4 = 3 with the
  * box kernel launched for every geometry (testing).  All give identical results. */
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
+/* Which passes write the reference's SCORES.  Match positions are the reference's in every pass, always.  Scores are
+ * only observable for the forward grid of the last (full-resolution) level: the reference overwrites every cell a
+ * coarser level wrote, None included (mod.rs:311-316), and complete() drops the reverse grid (mod.rs:208-215); nothing
+ * else ever reads a score (estimate_search_range and cross_check_point look at positions only, mod.rs:468-540,
+ * 588-624).  By default (all_passes = 0) the forward pass at scale 1 evaluates every recorded contender with the
+ * reference's serial f32 chain, as before, and every other pass does so only where it decides something (several
+ * contenders inside the filter's band, or one within the band of the threshold); a cell settled without it holds the
+ * filter's estimate of its score (within 2.5e-5 of the reference's).  all_passes = 1: the reference's bits in every
+ * cell of every pass - for tests that read coarser levels or the reverse grid through cvhip_complete_dir. */
+int cvhip_ctx_set_exact_scores(cvhip_ctx *ctx, int all_passes);
 /* Test hook of the search-range kernel (estimate_search_range, mod.rs:468-540): 0 (default) = integer box sums with the
  * reference's f64 chain only where the rounding of `len` is open, 1 = the chain for every pixel, 2 / 3 = every third
  * block of a box-sum tile through the staged / the global-memory chain.  All give identical results. */

@@ -30,11 +30,14 @@ def assert_same_grid(got, want, what):
     assert np.isnan(gc[~valid]).all()
 
 
-def run_gpu(dev, c, fused=True, both=False, version=None, counters=None, range_mode=None):
+def run_gpu(dev, c, fused=True, both=False, version=None, counters=None, range_mode=None, exact_scores=None):
+    """exact_scores: None = on exactly when the reverse grid is read (its scores are only the reference's bits under
+    cvhip_ctx_set_exact_scores; the forward grid of the last level always is)."""
     p1, p2 = cases.pyramids(c)
     h1, w1 = c["img1"].shape
     h2, w2 = c["img2"].shape
     pc = correlation.PointCorrelations(dev, (w1, h1), (w2, h2), c["F"], correlation.ProjectionMode(c["projection"]))
+    pc.set_exact_scores(both if exact_scores is None else exact_scores)
     if version is not None:
         pc.set_search_version(version)
     if range_mode is not None:
@@ -186,6 +189,7 @@ def test_each_level_matches_oracle(gpu_device, oracle):
     h2, w2 = c["img2"].shape
     F, D = correlation.CorrelationDirection.Forward, correlation.CorrelationDirection.Reverse
     pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"])
+    pc.set_exact_scores(True)  # coarser levels and the reverse grid are read here
     oc = oracle.Corr((w1, h1), (w2, h2), c["F"], 0, 8)
     try:
         for i in range(c["steps"] + 1):
@@ -208,6 +212,28 @@ def test_each_level_matches_oracle(gpu_device, oracle):
     finally:
         pc.close()
         oc.close()
+
+
+@pytest.mark.parametrize("name", ["h256", "sem320x200", "tilt3_200x150", "persp_240x180", "vert_200x260", "tilt60_150x200"])
+@pytest.mark.parametrize("version", [2, 3])
+def test_default_score_mode_positions_exact_everywhere(gpu_device, oracle, name, version):
+    """Default mode (cvhip_ctx_set_exact_scores off): passes whose scores cannot reach the caller skip the exact chain
+    for pixels with one clear contender.  The forward grid - positions and score bits - and the reverse POSITIONS
+    must still be the oracle's; the reverse scores (never observable in the reference, mod.rs:208-215) hold the
+    filter's estimate, within its proven bound of the reference's.  Far fewer exact evaluations are spent."""
+    c = cases.make_case(name)
+    want_f, want_r = run_oracle(oracle, c, both=True)
+    cnt, cnt_all = {}, {}
+    got_f, got_r = run_gpu(gpu_device, c, both=True, version=version, counters=cnt, exact_scores=False)
+    run_gpu(gpu_device, c, both=True, version=version, counters=cnt_all, exact_scores=True)
+    assert_same_grid(got_f, want_f, f"{name} forward, default score mode")
+    assert (got_r[0] == want_r[0]).all(), f"{name}: reverse match positions differ in default score mode"
+    valid = want_r[0][..., 0] >= 0
+    assert np.abs(got_r[1][valid] - want_r[1][valid]).max() <= 2.5e-5
+    assert cnt["candidates"] == cnt_all["candidates"]
+    assert cnt["exact_evals"] <= cnt_all["exact_evals"]
+    if name in ("h256", "sem320x200", "tilt3_200x150"):  # (steep cases spend theirs in the whole-corridor fallback)
+        assert cnt["exact_evals"] < 0.75 * cnt_all["exact_evals"]
 
 
 def test_candidate_counter_matches_oracle(gpu_device, oracle):
