@@ -13,15 +13,24 @@ N > 1: the SAME pair is row-sharded over the ranks (strong scaling), bands are a
 with RCCL after every sharded search pass; every rank ends with the full, identical grid.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
-dominant kernel (search_kernel, timed live with HIP events on its own stream) and
+dominant kernel (search3_box_kernel, timed live with HIP events on its own stream) and
 `cpu_baseline` (the C restatement of the reference's --mode=cpu path, oracle/, timed on this
-node's host cores on a bounded sample).
+node's host cores on a bounded sample).  At N = 1 the same line also carries, measured after the
+timed region: `readback` (SURVEY 8(d)'s t_dense with the final grid landing in page-locked HOST
+memory - per pair, and with the transfer of one pair under the search of the next),
+`geometry_sweep` (the same 4096^2 workload with the epipolar lines tilted by 3 .. 90 degrees) and
+`sfm3` (BASELINE config 5, per-stage times).
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a
+child process, before anything touches the GPU) and exits with its code.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -63,6 +72,26 @@ def _profile_json(name):
     return json.loads(f.read_text()) if f.exists() else None
 
 
+KERNEL_SOURCES = ("cybervision_amd/csrc/corr_kernels.hip", "cybervision_amd/csrc/box_body.inc")
+
+
+def kernel_source_sha16():
+    """sha256 of the dense kernels' sources: the PMC profiles record it when they are collected, so the line can say
+    whether the instruction counts it divides by still describe the kernels that ran."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def profile_source(name):
+    d = _profile_json(name)
+    if not d:
+        return None
+    return {"profile": f"profiles/{name}", "collected_at_commit": d.get("git_head"), "kernel_source_sha16": d.get("kernel_source_sha16"),
+            "matches_the_kernels_that_ran": d.get("kernel_source_sha16") == kernel_source_sha16()}
+
+
 def traffic_per_launch(world):
     """HBM bytes per search-kernel launch from the rocprofv3 PMC passes of this same command
     (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied: scripts/collect_traffic.py);
@@ -95,26 +124,26 @@ def valu_profile(world):
             "cycles_per_valu_instr": big.get("cycles_per_valu_instr")}
 
 
-def bench_sfm3(args):
+def measure_sfm3(size, steps, warmup):
     """BASELINE config 5 ("3-image perspective SFM: ORB + RANSAC F-matrix on GPU + pairwise dense correlation"):
-    three synthetic 2048^2 perspective views, resident in HBM as u8 pyramids; one step = per-level ORB on the three
+    three synthetic size^2 perspective views, resident in HBM as u8 pyramids; one step = per-level ORB on the three
     images, 3 x matcher (threshold 48), 3 x perspective find_ransac (device RANSAC + LM refit), 3 x dense correlation
     with the perspective parameter set (reconstruction.rs:261-277, 400-526, 540-588).  Single GPU ("replicas only":
-    the sparse stage does not shard).  A secondary line, not the headline metric."""
+    the sparse stage does not shard)."""
     import torch
 
     from cybervision_amd import correlation, reconstruction, synth
     from cybervision_amd.fundamentalmatrix import ProjectionMode
 
-    size = 2048 if args.size == 4096 else args.size
     views, K, poses = synth.make_sfm_views(size)
-    steps = synth.optimal_scale_steps(size, size)
+    lsteps = synth.optimal_scale_steps(size, size)
     torch.cuda.set_device(0)
     dev = correlation.create_gpu_context(ordinal=0, stream=torch.cuda.current_stream().cuda_stream)
-    pyr = [[torch.from_numpy(l).cuda() for l in synth.box_pyramid(v, steps)] for v in views]
+    pyr = [[torch.from_numpy(l).cuda() for l in synth.box_pyramid(v, lsteps)] for v in views]
     acc, n_pairs, matches, inliers, dense_cells = {}, 0, [], [], []
-    for it in range(args.warmup + args.steps):
-        if it == args.warmup:
+    t0 = time.perf_counter()
+    for it in range(warmup + steps):
+        if it == warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             acc = {}
@@ -128,22 +157,43 @@ def bench_sfm3(args):
         matches.append(int(len(e["matches"])))
         inliers.append(int(len(e["inliers"])) if e["inliers"] is not None else 0)
         dense_cells.append(reconstruction.match_count(e["xy"]) if "xy" in e else 0)
-    stage_ms = {k: round(v / args.steps, 3) for k, v in acc.items()}
-    mpx = n_pairs * size * size / 1e6
+    dev.close()
+    stage_ms = {k: round(v / steps, 3) for k, v in acc.items()}
+    return {"size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
+            "dense_mpixels_per_s": round(n_pairs * size * size / 1e6 / (stage_ms["dense"] / 1e3), 2),
+            "whole_pipeline_mpixels_per_s": round(3 * size * size / 1e6 / (dt / steps), 2),
+            "keypoints": [int(len(k[0])) for k in res["keypoints"]], "matches": matches, "ransac_inliers": inliers,
+            "dense_matches": dense_cells, "pairs_with_f": n_pairs}
+
+
+def bench_sfm3(args):
+    """`--config sfm3`: config 5 as a line of its own (a secondary line, not the headline metric)."""
+    size = 2048 if args.size == 4096 else args.size
+    m = measure_sfm3(size, args.steps, args.warmup)
     print(json.dumps({
         "metric": f"Mpixels/s dense correlation, 3 x {size}x{size} perspective views (3 pairs), config 5", "secondary": True,
-        "value": round(mpx / (stage_ms["dense"] / 1e3), 2), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True,
+        "value": m["dense_mpixels_per_s"], "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8 / f32 / f64 as in the reference", "data": "synthetic",
         "config": {"workload": f"3 perspective views {size}x{size} of one depth surface (synth.make_sfm_views), per-level ORB, "
                                "matcher thr 48, perspective RANSAC (20 x 50 000 samples, early exit) + LM refit, 3 pairwise "
-                               f"dense correlations (9 stripes, thr 0.5, {steps + 1} levels)", "parallelism": "single GPU"},
-        "stage_ms_per_step": stage_ms,
-        "whole_pipeline_mpixels_per_s": round(3 * size * size / 1e6 / (dt / args.steps), 2),
-        "keypoints": [int(len(k[0])) for k in res["keypoints"]], "matches": matches, "ransac_inliers": inliers,
-        "dense_matches": dense_cells,
+                               f"dense correlations (9 stripes, thr 0.5, {m['levels']} levels)", "parallelism": "single GPU"},
+        "stage_ms_per_step": m["stage_ms"],
+        "whole_pipeline_mpixels_per_s": m["whole_pipeline_mpixels_per_s"],
+        "keypoints": m["keypoints"], "matches": m["matches"], "ransac_inliers": m["ransac_inliers"],
+        "dense_matches": m["dense_matches"],
     }), flush=True)
-    dev.close()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (one rank per
+    GPU over RCCL) - before this process has imported torch or touched the GPU - and return its exit code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -157,9 +207,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512, help="side of the first crop timed on the CPU")
     ap.add_argument("--config", default="dense4096", choices=["dense4096", "sfm3"],
                     help="dense4096 (default): the headline metric; sfm3: BASELINE config 5, a secondary line")
+    ap.add_argument("--no-extras", action="store_true", help="skip readback / geometry_sweep / sfm3 in the headline line")
+    ap.add_argument("--sweep-tilts", default="3,10,30,60,90", help="tilts (degrees) of geometry_sweep")
     args = ap.parse_args()
     if args.config == "sfm3":
         return bench_sfm3(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))  # nothing has touched the GPU yet: the ranks are child processes
 
     import torch
     import torch.distributed as dist
@@ -168,8 +222,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}")
     # CVHIP_BENCH_BACKEND=gloo: rehearsal of the N-rank code path on a box with ONE GPU - every rank uses cuda:0 and
     # the gather is staged through the host (sharding.make_allgather); the numbers it prints are not a benchmark
     backend = os.environ.get("CVHIP_BENCH_BACKEND", "nccl")
@@ -187,20 +240,25 @@ def main():
     from cybervision_amd import correlation, sharding, synth
 
     W = H = args.size
-    img1, img2, _ = synth.make_pair(W, H)
     steps = synth.optimal_scale_steps(W, H)
-    pyr1 = synth.box_pyramid(img1, steps)
-    pyr2 = synth.box_pyramid(img2, steps)
+
     def resident(p):
         # u8 level image in HBM with 64 readable bytes behind it, so that the library can use it in place
         # (cvhip_ctx_set_borrow_inputs) instead of copying it into its own padded buffer on every call
-        buf = torch.zeros(p.size + 64, dtype=torch.uint8, device="cuda")
-        buf[:p.size].copy_(torch.from_numpy(p).reshape(-1))
-        return buf[:p.size].view(p.shape[0], p.shape[1])
+        buf = torch.zeros(p.numel() + 64, dtype=torch.uint8, device="cuda")
+        buf[:p.numel()].copy_(p.reshape(-1))
+        return buf[:p.numel()].view(p.shape[0], p.shape[1])
 
-    d1 = [resident(p) for p in pyr1]
-    d2 = [resident(p) for p in pyr2]
-    level_dims = [(p.shape[1], p.shape[0], q.shape[1], q.shape[0]) for p, q in zip(pyr1, pyr2)]
+    def resident_pyramids(tilt_deg=0.0):
+        # the synthetic pair and its 2x2 box pyramids, built on the device (synth.make_pair_torch: the same integer
+        # arithmetic as synth.make_pair, byte-identical - tests/test_sharding_cpu.py)
+        a, b, _ = synth.make_pair_torch(W, H, tilt_deg=tilt_deg, device="cuda")
+        pa, pb = synth.box_pyramid_torch(a, steps), synth.box_pyramid_torch(b, steps)
+        return [resident(p) for p in pa], [resident(p) for p in pb]
+
+    d1, d2 = resident_pyramids()
+    img1, img2 = d1[0].cpu().numpy(), d2[0].cpu().numpy()  # host copies of the pair, for the CPU baseline
+    level_dims = [(int(p.shape[1]), int(p.shape[0]), int(q.shape[1]), int(q.shape[0])) for p, q in zip(d1, d2)]
 
     stream = torch.cuda.current_stream()
     dev = correlation.create_gpu_context(ordinal=local_rank, stream=stream.cuda_stream)
@@ -210,6 +268,31 @@ def main():
     final_gather = None
     sim = None
     collective = None
+    comm = None
+
+    # N > 1 only: a collective that never completes (a rank died, a link is down) would block every other rank inside
+    # RCCL for good - ncclCommInitRank included, so the watchdog starts BEFORE the communicator is made.  It ends this
+    # process - loudly, with a non-zero code - when no step or fence has completed for three minutes, so a stuck run
+    # fails instead of holding its GPUs until someone else's limit.
+    progress = {"t": time.monotonic(), "what": "setup"}
+
+    def beat(what):
+        progress["t"] = time.monotonic()
+        progress["what"] = what
+
+    if world > 1:
+        import threading
+
+        def watchdog():
+            while True:
+                time.sleep(5.0)
+                idle = time.monotonic() - progress["t"]
+                if idle > 180.0:
+                    print(f"[bench] rank {rank}: no progress for {idle:.0f} s after '{progress['what']}' - aborting", flush=True)
+                    os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+
     if args.simulate_shard:  # single-GPU emulation of ONE rank's share of an N-GPU run (no collectives)
         num, den = (int(v) for v in args.simulate_shard.split("/"))
         sim = (num, den)
@@ -221,7 +304,6 @@ def main():
         # the handle's stream, no torch in the data path); torch.distributed only carries the 128-byte id.  If that
         # cannot be set up (or in the one-GPU gloo rehearsal, where RCCL refuses several ranks per GPU) the
         # torch.distributed hook is used instead - the line says which.
-        comm = None
         if not rehearsal:
             # ncclCommInitRank is a collective: a rank that cannot even load RCCL must not leave the others waiting in
             # it.  So every rank first probes the library locally (making an id loads librccl and resolves the symbols),
@@ -237,6 +319,7 @@ def main():
                 uid = [uid_local if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
                 try:
+                    beat("cvhip_rccl_create")
                     comm = sharding.RcclCommunicator(dev, uid[0], rank, world)
                     collective = "library RCCL (cvhip_rccl_*), gather to rank 0"
                 except Exception as exc:  # noqa: BLE001
@@ -264,28 +347,6 @@ def main():
     out_corr = torch.empty((H, W), dtype=torch.float32, device="cuda")
 
     l0_events = []  # (start, end) of the full-resolution level of every timed step (SURVEY §8d secondary metric)
-
-    # N > 1 only: a collective that never completes (a rank died, a link is down) would block every other rank inside
-    # RCCL for good.  A watchdog thread ends this process - loudly, with a non-zero code - when no step or fence has
-    # completed for three minutes, so a stuck run fails instead of holding its GPUs until someone else's limit.
-    progress = {"t": time.monotonic(), "what": "setup"}
-
-    def beat(what):
-        progress["t"] = time.monotonic()
-        progress["what"] = what
-
-    if world > 1:
-        import threading
-
-        def watchdog():
-            while True:
-                time.sleep(5.0)
-                idle = time.monotonic() - progress["t"]
-                if idle > 180.0:
-                    print(f"[bench] rank {rank}: no progress for {idle:.0f} s after '{progress['what']}' - aborting", flush=True)
-                    os._exit(3)
-
-        threading.Thread(target=watchdog, daemon=True).start()
 
     def step(timed=False):
         beat("step start")
@@ -332,15 +393,109 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     l0_ms = sum(a.elapsed_time(b) for a, b in l0_events) / max(len(l0_events), 1)
-    ktimes_search = pc.get_kernel_times()["search"]
-    search_ms_local = ktimes_search["ms"]          # the search launches of ONE step
-    search_launches = ktimes_search["launches"]
+    ktimes_last = pc.get_kernel_times()
+    search_ms_local = ktimes_last["search"]["ms"]  # the box-kernel launches of ONE step (the first pass runs the
+    search_launches = ktimes_last["search"]["launches"]  # candidate filter: class "search_filter", not counted here)
     # per-class breakdown of one more (untimed) step
     pc.set_profiling(1, False)
     step()
     fence()
     ktimes = pc.get_kernel_times()
     pc.set_profiling(0, False)
+
+    extras = world == 1 and sim is None and not args.no_extras
+    readback = geometry_sweep = sfm3 = None
+    if extras:
+        # ---- t_dense INCLUDING the final readback of the forward grid into host memory
+        # (GpuContext::complete_process lands in a host Grid, gpu/mod.rs:210-216).  Page-locked destinations.
+        # (a) per pair: complete() returns when the 201 MB are in host memory, then the next pair starts;
+        # (b) pipelined, as a reconstruction correlates pair after pair (reconstruction.rs:680-730): the transfer of
+        #     pair i runs on the handle's copy stream under the search of pair i + 1 (cvhip_ctx_set_async_readback,
+        #     two staging sets, two host buffers); the clock stops when the last grid is in host memory.
+        host = [(torch.empty((H, W, 2), dtype=torch.int32).pin_memory(), torch.empty((H, W), dtype=torch.float32).pin_memory())
+                for _ in range(2)]
+
+        def step_host(i):
+            pc.first_pass = True
+            for j in range(steps + 1):
+                k = steps - j
+                pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+            hx, hc = host[i & 1]
+            pc.complete(out_xy=hx.numpy(), out_corr=hc.numpy())
+
+        rb_steps = max(3, min(args.steps, 10))
+        step_host(0)
+        step_host(1)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(rb_steps):
+            step_host(i)
+        dev.synchronize()
+        rb_sync_ms = (time.perf_counter() - t1) * 1e3 / rb_steps
+        same_host = bool(torch.equal(host[(rb_steps - 1) & 1][0], out_xy.cpu()))
+        pc.set_async_readback(True)
+        step_host(0)
+        dev.synchronize()
+        t1 = time.perf_counter()
+        for i in range(rb_steps):
+            step_host(i)
+        dev.synchronize()
+        rb_pipe_ms = (time.perf_counter() - t1) * 1e3 / rb_steps
+        pc.set_async_readback(False)
+        same_host = same_host and bool(torch.equal(host[(rb_steps - 1) & 1][0], out_xy.cpu()))
+        mpx_ = W * H / 1e6
+        readback = {"t_dense_with_readback_ms": round(rb_sync_ms, 4), "mpixels_per_s_with_readback": round(mpx_ / (rb_sync_ms / 1e3), 1),
+                    "t_dense_with_readback_pipelined_ms": round(rb_pipe_ms, 4),
+                    "mpixels_per_s_with_readback_pipelined": round(mpx_ / (rb_pipe_ms / 1e3), 1),
+                    "bytes_to_host_per_pair": W * H * 12, "steps": rb_steps, "host_grid_equals_device_grid": same_host,
+                    "note": "complete() into page-locked host memory (12 B/px: int32 x, y + f32 score); pipelined = the "
+                            "transfer of pair i under the search of pair i+1 (cvhip_ctx_set_async_readback)"}
+        del host
+
+    pc.close()
+    pc = None
+    if extras:
+        # ---- the same workload with the epipolar lines tilted: pairs displaced along the tilted direction
+        # (synth.make_pair(tilt_deg=...)), F = synth.f_tilt(theta); everything else as in the headline step
+        geometry_sweep = {}
+        for tilt in [float(v) for v in args.sweep_tilts.split(",") if v]:
+            d1, d2 = None, None
+            d1, d2 = resident_pyramids(tilt)
+            pcs = correlation.PointCorrelations(dev, (W, H), (W, H), synth.f_tilt(tilt), correlation.ProjectionMode.Affine)
+            pcs.set_borrow_inputs(True)
+
+            def step_tilt(level0_events=None):
+                pcs.first_pass = True
+                for j in range(steps + 1):
+                    k = steps - j
+                    if level0_events is not None and k == 0:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream)
+                    pcs.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+                    if level0_events is not None and k == 0:
+                        e1.record(stream)
+                        level0_events.append((e0, e1))
+                pcs.complete(out_xy=out_xy, out_corr=out_corr)
+
+            step_tilt()
+            fence()
+            n_sw = 5
+            t1 = time.perf_counter()
+            for _ in range(n_sw):
+                step_tilt()
+            fence()
+            ms_sw = (time.perf_counter() - t1) * 1e3 / n_sw
+            ev = []
+            step_tilt(ev)
+            fence()
+            geometry_sweep[f"{tilt:g}"] = {"ms_per_step": round(ms_sw, 3), "mpixels_per_s": round(W * H / 1e6 / (ms_sw / 1e3), 1),
+                                           "level0_ms": round(ev[0][0].elapsed_time(ev[0][1]), 3),
+                                           "matched_fraction": round(float((out_xy[..., 0] >= 0).float().mean().item()), 4)}
+            pcs.close()
+        d1 = d2 = None
+        torch.cuda.empty_cache()
+        # ---- BASELINE config 5, per-stage times
+        sfm3 = measure_sfm3(2048 if W == 4096 else max(W // 2, 256), 5, 1)
 
     sharded_ok = None
     if world > 1:
@@ -390,11 +545,17 @@ def main():
         ach_gbs = bytes_alg / world / (search_ms_per_step / 1e3) / 1e9
         ach_tmacs = macs_alg / world / (search_ms_per_step / 1e3) / 1e12
         # The dominant kernel is bound by VALU instruction issue, not by HBM and not by the matrix pipe (DESIGN.md
-        # section 6): `achieved` is the rate of VALU lane-operations it executes (wave-instructions of the PMC pass of
-        # this same command x 64 lanes / the launch time measured live with HIP events), `peak` one operation per lane
-        # per clock on 1024 SIMD-32 units at 2.4 GHz.  dot4 and DPP instructions hold the pipe for 4 cycles instead of
-        # 2, so the pipes are full (`valu_busy`, from SQ_ACTIVE_INST_VALU) well below that peak; the efficiency figure
-        # of the algorithm is `valu_lane_instr_per_candidate` (the reference spends 363 flops per candidate).
+        # section 6).  `achieved` = VALU lane-operations per second of the box kernel: its wave-instructions per step
+        # (SQ_INSTS_VALU of the committed PMC pass of this same command - `source` says which, and whether it was
+        # collected from the kernels that just ran) x 64 lanes / the duration of ITS launches, measured live with HIP
+        # events in the timed region.  `peak` = MI355X_MICROARCH.md's issue rate for plain VALU (a wave64 instruction
+        # every 2 cycles per SIMD-32: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz).  The kernel's stream is mostly the
+        # half-rate class (v_dot4_u32_u8, DPP-modified adds, 24-bit multiplies, conversions: 4 cycles - `peak_half_rate`),
+        # so its pipes are saturated (`valu_busy`, SQ_ACTIVE_INST_VALU against GRBM_GUI_ACTIVE; the two counters run on
+        # different clock domains, hence readings slightly above 1) at roughly half of `peak`: `frac` is relative to an
+        # ASSUMED issue width of 32 lanes per SIMD and clock, and `frac_of_half_rate_peak` is the same rate against
+        # the class the stream is actually made of.  The efficiency figure of the ALGORITHM is
+        # `valu_lane_instr_per_candidate` (the reference spends 363 flops per candidate).
         vp = valu_profile(world)
         valu_peak = 256 * 4 * 32 * 2.4e9 / 1e12
         if vp and vp["wave_instr_per_step"]:
@@ -402,13 +563,16 @@ def main():
             ach_valu = lane_ops / (search_ms_per_step / 1e3) / 1e12
             roofline = {"kernel": SEARCH_KERNEL, "bound": "valu", "achieved": round(ach_valu, 2), "peak": round(valu_peak, 1),
                         "unit": "T lane-ops/s (VALU instructions x 64)", "frac": round(ach_valu / valu_peak, 4),
+                        "peak_half_rate": round(valu_peak / 2, 1), "frac_of_half_rate_peak": round(ach_valu / (valu_peak / 2), 4),
                         "valu_busy": vp["valu_busy"], "cycles_per_valu_instr": vp["cycles_per_valu_instr"],
-                        "valu_lane_instr_per_candidate": round(vp["wave_instr_per_step"] * 64.0 / max(candidates, 1), 1)}
+                        "valu_lane_instr_per_candidate": round(vp["wave_instr_per_step"] * 64.0 / max(candidates, 1), 1),
+                        "source": profile_source("current_pmc.json")}
         else:  # no PMC data for this configuration: only the HBM figures below are measured
             roofline = {"kernel": SEARCH_KERNEL, "bound": "valu", "achieved": None, "peak": round(valu_peak, 1),
                         "unit": "T lane-ops/s (VALU instructions x 64)", "frac": None}
         roofline.update({
             "traffic": traffic_per_launch(world),
+            "traffic_source": profile_source("current_traffic.json"),
             "launches_per_step": launches_per_step,
             "avg_launch_ms": round(search_ms_per_step / max(launches_per_step, 1), 4),
             # secondary: the HBM side of the same kernel (compute-bound by construction: ~30 B per ~72 candidates)
@@ -475,6 +639,12 @@ def main():
                 "sample": (f"top-left {S}x{S} crop of the same pair" if S < W else f"the whole {S}x{S} pair")
                           + f", full {csteps + 1}-level pyramid, C restatement of --mode=cpu (oracle/), {tc:.2f} s",
             }
+        if readback is not None:
+            result["readback"] = readback
+        if geometry_sweep is not None:
+            result["geometry_sweep"] = geometry_sweep
+        if sfm3 is not None:
+            result["sfm3"] = sfm3
         if world > 1:
             result["collective"] = collective
             result["ranks_seen"] = ranks_seen
@@ -483,7 +653,10 @@ def main():
             result["rehearsal"] = f"{backend}: all {world} ranks on one GPU, gather staged through the host - not a measurement"
         print(json.dumps(result), flush=True)
 
-    pc.close()
+    if pc is not None:
+        pc.close()
+    if comm is not None:
+        comm.close()   # before the device handle it was made on (the library would defer the handle's release otherwise)
     dev.close()
     if world > 1:
         dist.destroy_process_group()

@@ -196,11 +196,11 @@ class PointCorrelations:
                    "cvhip_ctx_get_profile")
         return {"launches": n.value, "search_ms": ms.value, "candidates": cand.value}
 
-    KERNEL_CLASSES = ("window_stats", "search_range", "search", "exact", "cross_check", "expand")
+    KERNEL_CLASSES = ("window_stats", "search_range", "search", "exact", "cross_check", "expand", "search_filter")
 
     def get_kernel_times(self, reset: bool = True):
-        ms = (C.c_double * 6)()
-        n = (C.c_uint32 * 6)()
+        ms = (C.c_double * 7)()
+        n = (C.c_uint32 * 7)()
         _lib.check(_lib.lib().cvhip_ctx_get_kernel_times(self._h, ms, n, int(reset)), "cvhip_ctx_get_kernel_times")
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(self.KERNEL_CLASSES)}
 

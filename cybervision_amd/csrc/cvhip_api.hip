@@ -133,7 +133,7 @@ template <typename F> static int timed(cvhip_ctx *c, int cls, F &&launch, hipStr
 {
     if (!s) s = c->dev->d.stream;
     // time_kernels: 0 = off, 1 = every class, 2 = the search class only
-    if (!c->time_kernels || (c->time_kernels == 2 && cls != cvhip_ctx::K_SEARCH)) {
+    if (!c->time_kernels || (c->time_kernels == 2 && cls != cvhip_ctx::K_SEARCH && cls != cvhip_ctx::K_FILTER)) {
         launch();
         return CVHIP_OK;
     }
@@ -367,7 +367,7 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
             } else {
                 // candidate filter over every tile; the (rare) tiles with whole-corridor pixels queue themselves for
                 // the fallback kernel, whose declined list stays empty here
-                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] { launch_search2_filter(jobs, m, s); }, s));
+                CVHIP_TRY(timed(c, cvhip_ctx::K_FILTER, [&] { launch_search2_filter(jobs, m, s); }, s));
                 if (!(p.debug & 1))
                     CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, false, s); }, s));
             }
@@ -1061,8 +1061,9 @@ int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms,
     CVHIP_TRY(resolve_events(ctx));
     unsigned long long cand = 0;
     CVHIP_TRY_HIP(hipMemcpy(&cand, ctx->d_cand, sizeof(cand), hipMemcpyDeviceToHost));
-    if (launches) *launches = ctx->prof_launches[cvhip_ctx::K_SEARCH];
-    if (search_ms) *search_ms = ctx->prof_ms[cvhip_ctx::K_SEARCH];
+    // "search" here = the launches of the kernel that does the level's search: the box filter, or the candidate filter
+    if (launches) *launches = ctx->prof_launches[cvhip_ctx::K_SEARCH] + ctx->prof_launches[cvhip_ctx::K_FILTER];
+    if (search_ms) *search_ms = ctx->prof_ms[cvhip_ctx::K_SEARCH] + ctx->prof_ms[cvhip_ctx::K_FILTER];
     if (candidates) *candidates = (uint64_t)cand;
     if (reset) {
         for (int i = 0; i < cvhip_ctx::K_COUNT; i++) {
@@ -1074,7 +1075,7 @@ int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms,
     return CVHIP_OK;
 }
 
-int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[6], uint32_t launches[6], int reset)
+int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[7], uint32_t launches[7], int reset)
 {
     if (!ctx || !ms || !launches) return fail(CVHIP_ERR_INVALID, "null argument");
     CVHIP_TRY(set_device(ctx->dev));

@@ -337,7 +337,7 @@ struct cvhip_ctx {
     int time_kernels = 0, count_candidates = 0;
     unsigned long long *d_cand = nullptr;
     // kernel classes timed with HIP events when time_kernels is set
-    enum { K_STATS = 0, K_RANGE, K_SEARCH, K_EXACT, K_CROSS, K_EXPAND, K_COUNT };
+    enum { K_STATS = 0, K_RANGE, K_SEARCH, K_EXACT, K_CROSS, K_EXPAND, K_FILTER, K_COUNT };
     struct TimedLaunch {
         hipEvent_t e0, e1;
         int cls;

@@ -232,10 +232,11 @@ int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms,
 
 /* Per-kernel-class device time since the last reset (needs time_kernels = 1), measured with HIP
  * events on the context's stream: [0] window statistics, [1] search-range estimation, [2] search
- * (version 3: box filter; 2: candidate filter; 1: the whole search), [3] fallback kernels (whole-corridor
+ * (version 3: the box filter; 1: the whole search), [3] fallback kernels (whole-corridor
  * exact re-evaluation; for version 3 also the candidate filter on the workgroups the box filter
- * declined), [4] cross-check, [5] grid expansion in complete().  Synchronises. */
-int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[6], uint32_t launches[6], int reset);
+ * declined), [4] cross-check, [5] grid expansion in complete(), [6] the candidate filter launched as a level's search
+ * (the first pass, steep geometry, search version 2).  Synchronises. */
+int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[7], uint32_t launches[7], int reset);
 /* Device counters of the search kernel since the last reset (needs count_candidates = 1):
  * out[0] candidates that passed the reference's bounds/stdev tests (== candidates above),
  * out[1] exact 121-term f32 evaluations, out[2] pixels whose filter band held 2..4 contenders,

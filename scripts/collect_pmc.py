@@ -49,6 +49,17 @@ for name, c in sorted(acc.items()):
     b["grid"] = grid[big]
     k["largest_launch"] = b
     res["kernels"][name] = k
+# provenance: the commit the profile was taken at (handed in, the GPU box has no .git) and the dense kernels' sources
+import hashlib
+import os
+from pathlib import Path
+
+_root = Path(__file__).resolve().parent.parent
+_h = hashlib.sha256()
+for _rel in ("cybervision_amd/csrc/corr_kernels.hip", "cybervision_amd/csrc/box_body.inc"):
+    _h.update((_root / _rel).read_bytes())
+res["kernel_source_sha16"] = _h.hexdigest()[:16]
+res["git_head"] = os.environ.get("CVHIP_GIT_HEAD")
 json.dump(res, open(out, "w"), indent=1)
 for n in ("search3_box_kernel", "window_stats_kernel", "search_range_kernel", "cross_check_kernel"):
     if n in res["kernels"]:

@@ -37,5 +37,16 @@ for name in sorted(F):
     res["kernels"][name] = {"launches_per_step": n / steps_in_run, "fetch_size_kib_per_step": f / steps_in_run,
                             "write_size_kib_per_step": w / steps_in_run,
                             "hbm_bytes_per_step": (2 * f + w) * 1024 / steps_in_run}
+# provenance: the commit the profile was taken at (handed in, the GPU box has no .git) and the dense kernels' sources
+import hashlib
+import os
+from pathlib import Path
+
+_root = Path(__file__).resolve().parent.parent
+_h = hashlib.sha256()
+for _rel in ("cybervision_amd/csrc/corr_kernels.hip", "cybervision_amd/csrc/box_body.inc"):
+    _h.update((_root / _rel).read_bytes())
+res["kernel_source_sha16"] = _h.hexdigest()[:16]
+res["git_head"] = os.environ.get("CVHIP_GIT_HEAD")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res["kernels"].get("search3_box_kernel", res["kernels"].get("search2_filter_kernel")), indent=1))

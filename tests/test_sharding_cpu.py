@@ -46,3 +46,17 @@ def test_band_allgather_over_gloo(world):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {rank} ok" in out, out
+
+
+def test_torch_generator_equals_numpy_generator():
+    """bench.py builds its pairs with synth.make_pair_torch (on the GPU): same integer arithmetic, same bytes."""
+    import numpy as np
+
+    from cybervision_amd import synth
+
+    for (w, h, tilt, seed) in [(300, 200, 0.0, 1234), (257, 311, 30.0, 7), (128, 128, 90.0, 1234)]:
+        a, b, d = synth.make_pair(w, h, seed=seed, tilt_deg=tilt)
+        ta, tb, td = synth.make_pair_torch(w, h, seed=seed, tilt_deg=tilt, device="cpu")
+        assert (ta.numpy() == a).all() and (tb.numpy() == b).all() and (td.numpy() == d).all()
+        for p, q in zip(synth.box_pyramid(a, 2), synth.box_pyramid_torch(ta, 2)):
+            assert (q.numpy() == p).all()
