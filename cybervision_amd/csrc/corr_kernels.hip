@@ -1372,18 +1372,30 @@ constexpr int S3_LANE0 = 11;
 constexpr int S3_OUT = S3_OUT_PX;
 constexpr int S3_COLS = 128;  // staged columns per copy / per statistics row
 // LDS plan.  The lean (rectified) instantiation walks at most 9 dy planes: 20 staged rows = 9 + 10 window rows (+1),
-// 5 dwords per line and copy.  The stepped instantiations - tilted affine lines, and perspective pairs whose 9
-// stripes leave the 9-plane plan no slack for the rows the lines cross inside a box - get 13 planes: 24 staged
-// rows, 6 dwords, 28 KB instead of 22.5 (5 workgroups per CU, which is their launch bound anyway).
-template <bool STEP> struct S3Plan {
-    static constexpr int MAXH = STEP ? 13 : 9;                       // dy planes
-    static constexpr int NDW = STEP ? 6 : 5;                         // staged dwords per line and copy
-    static constexpr int TAIL_BYTES = (NDW - 4) * 4;                 // per line: the dwords after the first four
-    static constexpr int B16_OFF = 0;                                // [4][128] uint4: rows 0..15 of the copy
-    static constexpr int TAIL_OFF = 4 * S3_COLS * 16;                // [4][128] u32 / uint2: rows 16..19 / 16..23
-    static constexpr int IS_OFF = TAIL_OFF + 4 * S3_COLS * TAIL_BYTES; // [MAXH + 3][128] uint2: candidate statistics
+// 5 dwords per line and copy, four row-shifted copies (one per wave row) - 22.5 KB, static.  The stepped
+// instantiations - epipolar lines of ANY slope, and perspective pairs - stage one tall copy of every line in dynamic
+// LDS and read 24 bytes (6 dwords) of it per step, which serve up to 14 - 3 = 11 planes at any byte alignment of the
+// wave's first row (box_body.inc; sizes per launch: CorrParams::box_pd / box_sh).
+template <bool STEP, bool WIDE = true> struct S3Plan {
+    static constexpr int MAXH = STEP ? 11 : 9;                       // dy planes (stepped: per step)
+    static constexpr int NDW = STEP ? 6 : 5;                         // dwords read per line and step
+    static constexpr int TAIL_BYTES = 4;                             // (lean) per line: the dword after the first four
+    static constexpr int B16_OFF = 0;                                // (lean) [4][128] uint4: rows 0..15 of the copy
+    static constexpr int TAIL_OFF = 4 * S3_COLS * 16;                // (lean) [4][128] u32: rows 16..19
+    static constexpr int IS_OFF = TAIL_OFF + 4 * S3_COLS * TAIL_BYTES; // (lean) [MAXH + 3][128] uint2: candidate statistics
     static constexpr int LDS_BYTES = IS_OFF + (MAXH + 3) * S3_COLS * 8;
+    // Stepped plan, two widths: boxes of up to 61 steps (128 lines, 128 cells per statistics row) where the lines are
+    // shallow enough for that to leave five workgroups per CU; up to 33 steps (100 lines, 96 cells) for steeper lines,
+    // whose boxes are taller - the statistics rows are what fills the LDS.
+    static constexpr int LINES = STEP && !WIDE ? 100 : S3_COLS;      // target lines staged per workgroup
+    static constexpr int ISP = STEP && !WIDE ? 96 : S3_COLS;         // cells per row of candidate statistics
 };
+// dynamic LDS of a stepped launch: LINES lines of pd dwords, then sh statistics rows of ISP cells
+static inline uint32_t search3_step_lds_bytes(uint32_t pd, uint32_t sh, bool wide)
+{
+    return wide ? (uint32_t)S3Plan<true, true>::LINES * pd * 4u + sh * (uint32_t)S3Plan<true, true>::ISP * 8u
+                : (uint32_t)S3Plan<true, false>::LINES * pd * 4u + sh * (uint32_t)S3Plan<true, false>::ISP * 8u;
+}
 
 __device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t v)
 {
@@ -1436,8 +1448,11 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 // Launch bound of the lean instantiation: 6 waves/SIMD (76 VGPRs, no spill).  7 waves - what its 22.5 KB of LDS would
 // admit - was measured 1.8 % faster (5.89 vs 6.00 ms per 4096^2 pair) but only with 10 VGPRs spilled: 28 B of scratch
 // per lane x 54 M threads put +1.17 GB per step on the L2 write-back counter (whole step 3.0 -> 4.2 GB).  Not taken.
+#ifndef CVHIP_STEP_WAVES
+#define CVHIP_STEP_WAVES 5
+#endif
 template <bool COUNT, bool STEP, bool TR>
-__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(SearchJob ja, SearchJob jb)
+__global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void search3_box_kernel(SearchJob ja, SearchJob jb)
 {
     const SearchJob &j = this_job(); // both directions of a level in one launch (see search_range_kernel)
     const CorrParams &p = j.p;
@@ -1447,14 +1462,15 @@ __global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_kernel(
     unsigned long long *__restrict__ const contenders = j.contenders, *__restrict__ const counters = j.counters;
     uint2 *__restrict__ const out = j.out;
     const WorkList declined = j.declined, whole_list = j.whole;
+    constexpr bool WIDE = true;
 #include "box_body.inc"
 }
 // One job per launch, plain by-value arguments.  The stepped instantiations sit at the register limit of their
 // occupancy target (96 VGPRs, 5 waves per SIMD): addressing the job through the kernel-argument pointer costs them
 // either 24 spilled VGPRs or one wave of occupancy (3-degree pair, level 0: 5.7 ms -> 7.6 / 6.6 ms), so their two
 // directions stay two launches of this form.
-template <bool COUNT, bool STEP, bool TR>
-__global__ __launch_bounds__(256, (STEP || TR) ? 5 : 6) void search3_box_single_kernel(
+template <bool COUNT, bool STEP, bool TR, bool WIDE>
+__global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void search3_box_single_kernel(
     CorrParams p, const uint8_t *__restrict__ img1, const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
     const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
     unsigned long long *__restrict__ contenders, uint2 *__restrict__ out, unsigned long long *__restrict__ counters,
@@ -1674,20 +1690,23 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
     auto launch_each = [&](auto kernel) { // the stepped instantiations: one launch per job (see search3_box_single_kernel)
         for (int i = 0; i < n; i++)
             if (job_active(jobs[i]))
-                hipLaunchKernelGGL(kernel, dim3(gx, gy, 1), dim3(256), 0, s, jobs[i].p, jobs[i].img1, jobs[i].img2, jobs[i].stats1,
-                                   jobs[i].stats1, jobs[i].stats2, (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out,
-                                   jobs[i].counters, jobs[i].declined, jobs[i].whole);
+                hipLaunchKernelGGL(kernel, dim3(gx, gy, 1), dim3(256),
+                                   search3_step_lds_bytes(jobs[i].p.box_pd, jobs[i].p.box_sh, jobs[i].p.box_wide != 0), s, jobs[i].p,
+                                   jobs[i].img1, jobs[i].img2, jobs[i].stats1, jobs[i].stats1, jobs[i].stats2,
+                                   (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out, jobs[i].counters, jobs[i].declined,
+                                   jobs[i].whole);
     };
+    const bool wide = jobs[0].p.box_wide != 0;
     const int variant = (jobs[0].counters ? 4 : 0) | (stepped_lines ? 2 : 0) | (transposed ? 1 : 0);
     switch (variant) {
     case 0: launch(search3_box_kernel<false, false, false>); break;
     case 1: launch(search3_box_kernel<false, false, true>); break;
-    case 2: launch_each(search3_box_single_kernel<false, true, false>); break;
-    case 3: launch_each(search3_box_single_kernel<false, true, true>); break;
+    case 2: wide ? launch_each(search3_box_single_kernel<false, true, false, true>) : launch_each(search3_box_single_kernel<false, true, false, false>); break;
+    case 3: wide ? launch_each(search3_box_single_kernel<false, true, true, true>) : launch_each(search3_box_single_kernel<false, true, true, false>); break;
     case 4: launch(search3_box_kernel<true, false, false>); break;
     case 5: launch(search3_box_kernel<true, false, true>); break;
-    case 6: launch_each(search3_box_single_kernel<true, true, false>); break;
-    default: launch_each(search3_box_single_kernel<true, true, true>); break;
+    case 6: wide ? launch_each(search3_box_single_kernel<true, true, false, true>) : launch_each(search3_box_single_kernel<true, true, false, false>); break;
+    default: wide ? launch_each(search3_box_single_kernel<true, true, true, true>) : launch_each(search3_box_single_kernel<true, true, true, false>); break;
     }
 }
 

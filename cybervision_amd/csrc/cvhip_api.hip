@@ -300,31 +300,35 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
     bool transposed = std::fabs(F[2]) > std::fabs(F[5]);
     const double f_major = transposed ? std::fabs(F[2]) : std::fabs(F[5]);
     double f_minor = transposed ? std::fabs(F[5]) : std::fabs(F[2]);
+    double slope = f_major > 0.0 ? f_minor / f_major : 0.0; // rows the lines climb per step along their major axis (<= 1)
     if (!affine_form) {
         // Perspective F: the line direction (l.x, l.y) = first two components of F*p is an affine function of the pixel,
-        // so "within 0.08 of one axis, on one side of it" at the four image corners holds for every pixel in between
-        // (an intersection of half-planes).  Then the per-pixel lines are near enough to one axis for the box walk, with
-        // per-step plane windows (the STEP instantiation).
+        // so "nearer to one axis than to the other, on one side of it" at the four image corners holds for every pixel
+        // in between (an intersection of half-planes).  Then every pixel's line has the same major axis and the box walk
+        // applies, with per-step plane windows (the STEP instantiation); its slope is largest at a corner.
         const double up = (double)(1u << k), xs[2] = {0.0, (double)(lw1 - 1) * up}, ys[2] = {0.0, (double)(lh1 - 1) * up};
         int along_x = 0, along_y = 0, sign_major = 0;
         bool same_side = true;
+        slope = 0.0;
         for (double cx : xs)
             for (double cy : ys) {
                 const double lx = (F[0] * cx + F[1] * cy) + F[2], ly = (F[3] * cx + F[4] * cy) + F[5];
                 if (!(std::isfinite(lx) && std::isfinite(ly))) same_side = false;
-                const bool row_major = std::fabs(lx) <= 0.08 * std::fabs(ly), col_major = std::fabs(ly) <= 0.08 * std::fabs(lx);
+                const bool row_major = std::fabs(lx) <= std::fabs(ly), col_major = std::fabs(ly) < std::fabs(lx);
                 along_x += row_major ? 1 : 0;
                 along_y += col_major ? 1 : 0;
-                const int sg = (row_major ? ly : lx) > 0.0 ? 1 : -1;
+                const double major = row_major ? ly : lx, minor = row_major ? lx : ly;
+                if (major != 0.0) slope = std::max(slope, std::fabs(minor / major));
+                const int sg = major > 0.0 ? 1 : -1;
                 if (sign_major == 0) sign_major = sg;
-                same_side = same_side && sg == sign_major;
+                same_side = same_side && sg == sign_major && major != 0.0;
             }
-        const bool near_axis = same_side && (along_x == 4 || along_y == 4);
+        const bool one_axis = same_side && (along_x == 4 || along_y == 4);
         transposed = along_y == 4;
         f_minor = 1.0; // lines differ per pixel: always the stepped instantiation
-        if (v3 && !c->force_box) v3 = near_axis;
+        if (v3 && !c->force_box) v3 = one_axis;
     } else if (v3 && !c->force_box) {
-        v3 = f_major > 0.0 && f_minor <= 0.08 * f_major;
+        v3 = f_major > 0.0;
     }
     // The first pass searches the whole line: its displacement boxes are wider than the box kernel's 61 steps, every
     // workgroup would decline - straight to the candidate filter (one launch less on the latency-bound coarsest level).
@@ -333,6 +337,17 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
         plan.kind = PassPlan::BOX;
         plan.stepped = f_minor != 0.0 || c->force_box; // exactly axis-parallel lines never step: the leaner instantiation
         plan.transposed = transposed;
+        if (plan.stepped) {
+            // LDS of the stepped launch, sized for displacement boxes of up to ~32 steps along lines of this slope: H
+            // rows of planes -> H + 3 rows of candidate statistics and H + 26 bytes of every target line (an odd number
+            // of dwords: consecutive lines then start in different LDS banks).  64 KB per workgroup at most.
+            const uint32_t wv = 2u * (uint32_t)c->corridor_size + 1u;
+            const uint32_t H = (uint32_t)std::ceil(std::min(slope, 1.0) * 32.0) + wv + 3u;
+            p.box_sh = std::min(H + 3u, 44u);
+            p.box_pd = std::min(((H + 26u + 3u) >> 2) | 1u, 39u);
+            // boxes up to 61 steps wide where that still leaves five workgroups per CU (160 KB of LDS), else up to 33
+            p.box_wide = 128u * p.box_pd * 4u + p.box_sh * 128u * 8u <= 32u * 1024u ? 1u : 0u;
+        }
     }
     return CVHIP_OK;
 }

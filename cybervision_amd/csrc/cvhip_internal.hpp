@@ -61,6 +61,9 @@ struct CorrParams {
     // level, mod.rs:311-316, and drops the reverse grid, mod.rs:208-215), so a pixel whose filter band holds ONE
     // contender clearly above the threshold is settled without the exact 121-term evaluation.
     int need_scores;
+    // stepped box launches (search3_box_*<.., STEP = true, ..>): dynamic LDS plan - dwords staged per target line
+    // (odd, so that consecutive lines fall into different banks) and rows of candidate statistics
+    uint32_t box_pd, box_sh, box_wide; // box_wide: the 128-line plan (shallow lines), else the 100-line plan
     // Affine F (first two columns zero): F*p = (F02, F12, .) for every finite pixel, so the epipolar line's direction
     // is one constant, evaluated once on the host with the reference's expression (mod.rs:397-408; IEEE division,
     // the same bits as on the device).  affine = 1: the |l.x| > |l.y| branch, aff_c = -F12/F02, aff_div = F02;

@@ -15,11 +15,10 @@ TILT = 0.0
 for a in sys.argv:
     if a.startswith("--tilt="):
         TILT = float(a.split("=")[1])
-img1, img2, _ = synth.make_pair(W, W, tilt_deg=TILT)  # displacement along the epipolar direction of F
+img1, img2, _ = synth.make_pair_torch(W, W, tilt_deg=TILT, device="cuda")  # displacement along the epipolar direction of F
 steps = synth.optimal_scale_steps(W, W)
-p1, p2 = synth.box_pyramid(img1, steps), synth.box_pyramid(img2, steps)
-d1 = [torch.from_numpy(p).cuda() for p in p1]
-d2 = [torch.from_numpy(p).cuda() for p in p2]
+d1, d2 = synth.box_pyramid_torch(img1, steps), synth.box_pyramid_torch(img2, steps)
+torch.cuda.synchronize()  # the device handle below submits to a stream of its own
 dev = correlation.create_gpu_context()
 F = synth.F_HORIZONTAL
 for a in sys.argv:
