@@ -213,6 +213,7 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
         if ((int)ds.k <= k)
             return fail(CVHIP_ERR_UNSUPPORTED, "scale must shrink by powers of two from level to level");
     }
+    if (dir == 1) c->rev_cross_check_pending = false; // the reverse grid is being replaced
     CorrParams &p = plan.job.p;
     std::memset(&p, 0, sizeof(p));
     for (int i = 0; i < 3; i++)
@@ -424,10 +425,27 @@ static int cross_check_pass(cvhip_ctx *c, int k, int dir)
         const uint32_t *r = dir == 0 ? c->band[k].cf : c->band[k].cr;
         r0 = std::min(r[0], own.lh);
         r1 = std::min(r[1], own.lh);
+    } else if (dir == 1 && k == 0) { // nothing reads the filtered reverse grid of the last level: deferred
+        c->rev_cross_check_pending = true;
+        return CVHIP_OK;
     }
     CVHIP_TRY(timed(c, cvhip_ctx::K_CROSS, [&] {
         launch_cross_check(own.cells[own.cur], other.cells[other.cur], own.lw, own.lh, other.lw, other.lh, r0, r1,
                            c->dev->d.stream);
+    }));
+    CVHIP_TRY_HIP(hipGetLastError());
+    return CVHIP_OK;
+}
+
+// the deferred reverse cross-check of the full-resolution level (cvhip_ctx::rev_cross_check_pending)
+static int flush_reverse_cross_check(cvhip_ctx *c)
+{
+    if (!c->rev_cross_check_pending) return CVHIP_OK;
+    c->rev_cross_check_pending = false;
+    DirState &own = c->dir[1], &other = c->dir[0];
+    if (!own.valid || !other.valid || own.k != 0 || other.k != 0) return CVHIP_OK;
+    CVHIP_TRY(timed(c, cvhip_ctx::K_CROSS, [&] {
+        launch_cross_check(own.cells[own.cur], other.cells[other.cur], own.lw, own.lh, other.lw, other.lh, 0, own.lh, c->dev->d.stream);
     }));
     CVHIP_TRY_HIP(hipGetLastError());
     return CVHIP_OK;
@@ -788,6 +806,9 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
             f1 = std::min(ctx->band[k].cf[1], df.lh);
             r0 = std::min(ctx->band[k].cr[0], dr.lh);
             r1 = std::min(ctx->band[k].cr[1], dr.lh);
+        } else if (k == 0) { // the reverse filter of the last level is deferred (cvhip_ctx::rev_cross_check_pending)
+            r0 = r1 = 0;
+            ctx->rev_cross_check_pending = true;
         }
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_CROSS, [&] {
             launch_cross_check_pair(df.cells[df.cur], dr.cells[dr.cur], df.lw, df.lh, dr.lw, dr.lh, f0, f1, r0, r1, s);
@@ -830,6 +851,7 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
     if (!ctx || !out_xy) return fail(CVHIP_ERR_INVALID, "null argument");
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
     CVHIP_TRY(set_device(ctx->dev));
+    if (dir == 1) CVHIP_TRY(flush_reverse_cross_check(ctx));
     hipStream_t s = ctx->dev->d.stream;
     DirState &ds = ctx->dir[dir];
     const size_t n = (size_t)ds.gw * ds.gh;
@@ -1048,6 +1070,10 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, ui
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
     DirState &ds = ctx->dir[dir];
     if (!ds.valid) return fail(CVHIP_ERR_INVALID, "no level computed yet");
+    if (dir == 1) {
+        CVHIP_TRY(set_device(ctx->dev));
+        CVHIP_TRY(flush_reverse_cross_check(ctx));
+    }
     if (cells) *cells = ds.cells[ds.cur];
     if (lw) *lw = ds.lw;
     if (lh) *lh = ds.lh;

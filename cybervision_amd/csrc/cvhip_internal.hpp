@@ -311,6 +311,10 @@ struct cvhip_ctx {
     uint2 *istats[2] = {nullptr, nullptr};
     // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,
     // 3 = displacement-plane box filter (falls back to 2 per workgroup) + exact re-evaluation
+    // The reverse cross-check of the full-resolution level (mod.rs:240) filters a grid nothing reads any more: no finer
+    // level follows scale 1 and complete() returns the forward grid (mod.rs:208-215).  It is therefore deferred and
+    // only runs if somebody does ask for the reverse grid (cvhip_complete_dir(.., 1, ..), cvhip_ctx_level_grid(.., 1, ..)).
+    bool rev_cross_check_pending = false;
     bool async_readback = false; // cvhip_ctx_set_async_readback
     bool exact_scores = false; // cvhip_ctx_set_exact_scores: every pass writes the reference's scores (tests)
     int search_version = 3;
