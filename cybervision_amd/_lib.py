@@ -70,6 +70,8 @@ SIGNATURES = {
     "cvhip_downsample_box": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
     "cvhip_resize_lanczos3": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),
     "cvhip_orb_extract": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32), PROGRESS_FN, _vp]),
+    "cvhip_orb_extract_batch": (C.c_int, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, PROGRESS_FN, _vp]),
+    "cvhip_orb_set_orientation_guard": (C.c_int, [_vp, C.c_double]),
     "cvhip_match_points": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cvhip_ransac_affine": (C.c_int, [_vp, _vp, _u32, C.c_uint64, _vp, C.POINTER(_u32), _vp]),
     "cvhip_ransac_perspective": (C.c_int, [_vp, _vp, _u32, C.c_double, C.c_uint64, _u32, _vp, C.POINTER(_u32), _vp]),

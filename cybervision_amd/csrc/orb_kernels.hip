@@ -353,7 +353,7 @@ __device__ __forceinline__ bool blur_valid(uint32_t w, uint32_t h, uint32_t x, u
 __global__ __launch_bounds__(64) void moments_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
                                                       const uint32_t *__restrict__ kp_xy,
                                                       const uint32_t *__restrict__ sorted_idx, uint32_t count,
-                                                      unsigned long long *__restrict__ out)
+                                                      unsigned long long *__restrict__ out, double *__restrict__ sincos)
 {
     const uint32_t r = blockIdx.x;
     if (r >= count) return;
@@ -398,6 +398,21 @@ __global__ __launch_bounds__(64) void moments_kernel(const double *__restrict__ 
         out[5 * (size_t)r + 2] = m01;
         out[5 * (size_t)r + 3] = ok ? 1ull : 0ull;
         out[5 * (size_t)r + 4] = (unsigned long long)x | ((unsigned long long)y << 32);
+        // The orientation (orb.rs:337-341, 365-366) with the DEVICE's atan2 / sin / cos: the same IEEE divisions and
+        // subtractions as the reference, then library functions that agree with glibc's to a few ulp.  brief_kernel
+        // uses them only where that cannot change a rounded sample offset (its `guard`); a keypoint where it could is
+        // redone with the host's libm.
+        double sn = 0.0, cs = 0.0;
+        if (ok) {
+            const double m00d = (double)m00;
+            const double centroid_x = (double)m10 / m00d, centroid_y = (double)m01 / m00d;
+            const double angle = atan2(centroid_y - (double)y, centroid_x - (double)x);
+            sn = sin(angle);
+            cs = cos(angle);
+        }
+        sincos[3 * (size_t)r + 0] = sn;
+        sincos[3 * (size_t)r + 1] = cs;
+        sincos[3 * (size_t)r + 2] = ok ? 1.0 : 0.0;
     }
 }
 
@@ -430,8 +445,13 @@ __global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ bl
                                                     const uint32_t *__restrict__ sorted_idx, uint32_t count,
                                                     const double *__restrict__ sincos,
                                                     const signed char *__restrict__ pattern,
-                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ flags)
+                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ flags, double guard,
+                                                    uint32_t *__restrict__ open_count)
 {
+    // guard > 0: sin / cos come from the device's math library (moments_kernel).  They - and the angle under them - may
+    // differ from glibc's by a few ulp, which moves a rotated offset o_y cos - o_x sin (|o| <= 15) by less than 1e-12:
+    // its rounding is the reference's unless the value lies within `guard` (1e-9) of a half-integer.  A keypoint with
+    // such a sample is counted in *open_count and the whole image is redone with host-computed orientations.
     const uint32_t r = blockIdx.x;
     if (r >= count) return;
     const uint32_t lane = threadIdx.x;
@@ -444,17 +464,23 @@ __global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ bl
         cy = kp_xy[2 * (size_t)src + 1];
     }
     const uint32_t bh = w; // blurred grid height (quirk)
-    bool fail = false;
+    bool fail = false, open = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int i = j * 64 + (int)lane;
         const double o1x = (double)pattern[4 * i + 0], o1y = (double)pattern[4 * i + 1];
         const double o2x = (double)pattern[4 * i + 2], o2y = (double)pattern[4 * i + 3];
         // x/y roles as in the reference (orb.rs:371-378)
-        const long long off1x = f64_to_i64_sat(round(o1y * angle_cos - o1x * angle_sin));
-        const long long off1y = f64_to_i64_sat(round(o1y * angle_sin + o1x * angle_cos));
-        const long long off2x = f64_to_i64_sat(round(o2y * angle_cos - o2x * angle_sin));
-        const long long off2y = f64_to_i64_sat(round(o2y * angle_sin + o2x * angle_cos));
+        const double v1x = o1y * angle_cos - o1x * angle_sin, v1y = o1y * angle_sin + o1x * angle_cos;
+        const double v2x = o2y * angle_cos - o2x * angle_sin, v2y = o2y * angle_sin + o2x * angle_cos;
+        if (guard > 0.0) {
+            const auto near_half = [guard](double v) { return fabs((v - floor(v)) - 0.5) < guard; };
+            open = open || near_half(v1x) || near_half(v1y) || near_half(v2x) || near_half(v2y);
+        }
+        const long long off1x = f64_to_i64_sat(round(v1x));
+        const long long off1y = f64_to_i64_sat(round(v1y));
+        const long long off2x = f64_to_i64_sat(round(v2x));
+        const long long off2y = f64_to_i64_sat(round(v2y));
         const unsigned long long p1x = sat_add_signed(cx, off1x), p1y = sat_add_signed(cy, off1y);
         const unsigned long long p2x = sat_add_signed(cx, off2x), p2y = sat_add_signed(cy, off2y);
         bool bad = p1x == 0 || p2x == 0 || p1x + 1 >= w || p2x + 1 >= w || p1y + 1 >= bh || p2y + 1 >= bh;
@@ -474,8 +500,11 @@ __global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ bl
             desc[8 * (size_t)r + 2 * j + 1] = (uint32_t)(bits >> 32);
         }
     }
-    const bool any_fail = __any(fail);
-    if (lane == 0) flags[r] = (ok && !any_fail) ? 1u : 0u;
+    const bool any_fail = __any(fail), any_open = __any(ok && open);
+    if (lane == 0) {
+        flags[r] = (ok && !any_fail) ? 1u : 0u;
+        if (any_open && open_count) atomicAdd(open_count, 1u);
+    }
 }
 
 // ordered compaction of <= 10240 ranked keypoints by flag (single block)
@@ -658,166 +687,276 @@ extern "C" int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint3
     return CVHIP_OK;
 }
 
-extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
-                                 uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n, cvhip_progress_fn progress, void *user)
+// orb::extract_points (orb.rs:50-84) for a BATCH of images in two stages, every stage enqueued for all images before
+// the host waits once: (A) contrast stretch, FAST, non-maximum suppression -> corner counts to the host (they size
+// everything that follows); (B) corner lists, Harris, ranking, blur, patch moments, orientation, descriptors, ordered
+// compaction -> results.  The reference computes atan2 / sin / cos with libm (orb.rs:337-341, 365-366), and a rotated
+// sample offset is round(o_y cos - o_x sin): the device's own f64 atan2 / sin / cos decide it identically unless the
+// value sits within 1e-9 of a half-integer (they agree with glibc's to a few ulp, |o| <= 15).  A keypoint where it does
+// is counted, and an image with such a keypoint takes the host path - moments out, libm on the host, orientations in,
+// descriptors again - so the result is always the libm result (test hook: cvhip_orb_set_orientation_guard widens the
+// band, or switches the device orientation off).  The reference extracts level after level and image after image
+// (reconstruction.rs:418-458); the levels of an image - or all images of a set - are independent, so one batch pays
+// the two host round trips once instead of once per extraction.
+namespace {
+struct OrbJob {
+    const uint8_t *img = nullptr;
+    uint32_t w = 0, h = 0, cap = 0;
+    uint32_t *out_xy = nullptr, *out_desc = nullptr, *out_n = nullptr;
+    size_t n = 0;
+    uint32_t nblocks = 0, n_fast = 0, count = 0, out_cap = 0;
+    uint8_t *d_img = nullptr, *d_adj = nullptr, *d_score = nullptr;
+    uint32_t *d_mm = nullptr, *d_counts = nullptr, *d_total = nullptr, *d_kp = nullptr, *d_idx_sorted = nullptr;
+    double *d_blur = nullptr, *d_sc = nullptr;
+    unsigned long long *d_mom = nullptr;
+    uint32_t *d_pack = nullptr, *d_desc = nullptr, *d_flags = nullptr;
+    bool xy_dev = false, desc_dev = false;
+    size_t mom_off = 0, sc_off = 0, pack_off = 0, mom_bytes = 0, sc_bytes = 0, pack_bytes = 0; // in the pinned staging
+};
+} // namespace
+
+extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, const uint8_t *const *imgs, const uint32_t *ws,
+                                       const uint32_t *hs, uint32_t cap, uint32_t *const *out_xy, uint32_t *const *out_desc,
+                                       uint32_t *out_n, cvhip_progress_fn progress, void *user)
 {
+    if (!dev || !imgs || !ws || !hs || !out_xy || !out_desc || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (n_images == 0) return CVHIP_OK;
+    if (n_images > 256) return fail(CVHIP_ERR_INVALID, "more than 256 images in one batch");
+    for (uint32_t i = 0; i < n_images; i++) {
+        if (!imgs[i] || !out_xy[i] || !out_desc[i]) return fail(CVHIP_ERR_INVALID, "null argument");
+        if (ws[i] < 2 * FAST_KERNEL_SIZE + 1 || hs[i] < 2 * FAST_KERNEL_SIZE + 1)
+            return fail(CVHIP_ERR_INVALID, "image smaller than the FAST ring");
+        if (ws[i] > 65535 || hs[i] > 65535) return fail(CVHIP_ERR_UNSUPPORTED, "image dimension above 65535");
+    }
     // ProgressListener::report_status at the reference's stage boundaries (orb.rs:60-66, 93-100, 112-118, 138-146, 358-363)
     const auto report = [&](float pos) {
         if (progress) progress(user, pos);
     };
-    if (!dev || !img || !out_xy || !out_desc || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
-    if (w < 2 * FAST_KERNEL_SIZE + 1 || h < 2 * FAST_KERNEL_SIZE + 1)
-        return fail(CVHIP_ERR_INVALID, "image smaller than the FAST ring");
-    if (w > 65535 || h > 65535) return fail(CVHIP_ERR_UNSUPPORTED, "image dimension above 65535");
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     hipStream_t s = dev->d.stream;
-    const size_t n = (size_t)w * h;
     DevAllocs mem(dev->d);
+    try {
+        std::vector<OrbJob> jobs(n_images);
 
-    uint8_t *d_img = nullptr, *d_adj = nullptr, *d_score = nullptr;
-    uint32_t *d_mm = nullptr, *d_counts = nullptr, *d_total = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_img, n + IMG_PAD));
-    CVHIP_TRY_HIP(mem.alloc(&d_adj, n + IMG_PAD));
-    CVHIP_TRY_HIP(mem.alloc(&d_score, n));
-    CVHIP_TRY_HIP(mem.alloc(&d_mm, 2));
-    const uint32_t nblocks = (uint32_t)((n + 255) / 256);
-    CVHIP_TRY_HIP(mem.alloc(&d_counts, nblocks));
-    CVHIP_TRY_HIP(mem.alloc(&d_total, 1));
-    CVHIP_TRY_HIP(hipMemcpyAsync(d_img, img, n, dev_ptr(img) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_mm), 255, 1, s)); // {min, max} = {255, 0}
-    CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_mm + 1), 0, 1, s));
+        // ---- stage A: contrast stretch, FAST score, NMS count -> corner totals
+        uint32_t *h_counts = static_cast<uint32_t *>(pinned_scratch(dev->d, 4096));
+        if (!h_counts) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
+        for (uint32_t i = 0; i < n_images; i++) {
+            OrbJob &j = jobs[i];
+            j.img = imgs[i];
+            j.w = ws[i];
+            j.h = hs[i];
+            j.cap = cap;
+            j.out_xy = out_xy[i];
+            j.out_desc = out_desc[i];
+            j.out_n = &out_n[i];
+            j.n = (size_t)j.w * j.h;
+            j.nblocks = (uint32_t)((j.n + 255) / 256);
+            CVHIP_TRY_HIP(mem.alloc(&j.d_img, j.n + IMG_PAD));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_adj, j.n + IMG_PAD));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_score, j.n));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_mm, 2));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_counts, j.nblocks));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_total, 1));
+            CVHIP_TRY_HIP(hipMemcpyAsync(j.d_img, j.img, j.n, dev_ptr(j.img) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+            CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(j.d_mm), 255, 1, s)); // {min, max} = {255, 0}
+            CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(j.d_mm + 1), 0, 1, s));
+            const unsigned rblocks = (unsigned)std::min<size_t>(2048, (j.n + 255) / 256);
+            hipLaunchKernelGGL(minmax_kernel, dim3(std::min(rblocks, 512u)), dim3(256), 0, s, j.d_img, j.n, j.d_mm);
+            hipLaunchKernelGGL(contrast_kernel, dim3(rblocks), dim3(256), 0, s, j.d_img, j.n, j.d_mm, j.d_adj);
+            dim3 grid2d((j.w + 63) / 64, (j.h + 3) / 4);
+            hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, j.d_adj, j.w, j.h, j.d_score);
+            hipLaunchKernelGGL(nms_count_kernel, dim3(j.nblocks), dim3(256), 0, s, j.d_score, j.w, j.h, j.d_counts);
+            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, j.d_counts, j.nblocks, j.d_total);
+            CVHIP_TRY_HIP(hipMemcpyAsync(h_counts + i, j.d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        }
+        report(0.20f);
+        CVHIP_TRY_HIP(hipStreamSynchronize(s));
+        CVHIP_TRY_HIP(hipGetLastError());
+        report(0.25f);
 
-    // 1. contrast stretch, FAST score, NMS, scan-ordered corner list
-    const unsigned rblocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
-    hipLaunchKernelGGL(minmax_kernel, dim3(std::min(rblocks, 512u)), dim3(256), 0, s, d_img, n, d_mm);
-    hipLaunchKernelGGL(contrast_kernel, dim3(rblocks), dim3(256), 0, s, d_img, n, d_mm, d_adj);
-    dim3 grid2d((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, d_adj, w, h, d_score);
-    report(0.20f);
-    hipLaunchKernelGGL(nms_count_kernel, dim3(nblocks), dim3(256), 0, s, d_score, w, h, d_counts);
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, nblocks, d_total);
-    uint32_t *h_n_fast = static_cast<uint32_t *>(pinned_scratch(dev->d, 4096));
-    if (!h_n_fast) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
-    CVHIP_TRY_HIP(hipMemcpyAsync(h_n_fast, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    CVHIP_TRY_HIP(hipStreamSynchronize(s));
-    CVHIP_TRY_HIP(hipGetLastError());
-    const uint32_t n_fast = *h_n_fast;
-    report(0.25f);
-    if (n_fast == 0) {
-        *out_n = 0;
+        // ---- stage B: corner lists, Harris on the original image, stable descending sort, top MAX_KEYPOINTS, blur of
+        // the original image, patch moments and the orientation from the device's math library, descriptors, ordered
+        // compaction -> results, and the number of keypoints whose descriptor could depend on the last bits of
+        // sin / cos (brief_kernel's guard).  No host round trip in between.
+        Taps7 k7;
+        gaussian_kernel_host(HARRIS_KERNEL_WIDTH, k7.k);
+        Taps11 k11;
+        gaussian_kernel_host(ORB_GAUSS_KERNEL_WIDTH, k11.k);
+        size_t stage_bytes = 0;
+        for (uint32_t i = 0; i < n_images; i++) {
+            OrbJob &j = jobs[i];
+            j.n_fast = h_counts[i];
+            j.count = std::min(j.n_fast, MAX_KEYPOINTS); // entries past the Some(...) ones carry idx = ~0
+            j.out_cap = std::min(j.cap, j.count);
+            // page-locked staging of this image: [moments + keypoint, 5 u64 per rank] [sin, cos, valid: 3 f64 per rank]
+            // (both only for the host-orientation path) [n_out, open count + outputs]
+            j.mom_bytes = (size_t)j.count * 5 * sizeof(unsigned long long);
+            j.sc_bytes = (size_t)j.count * 3 * sizeof(double);
+            j.pack_bytes = 256 + (size_t)j.out_cap * 10 * sizeof(uint32_t);
+            j.mom_off = stage_bytes;
+            j.sc_off = j.mom_off + j.mom_bytes;
+            j.pack_off = j.sc_off + j.sc_bytes;
+            stage_bytes = (j.pack_off + j.pack_bytes + 255) / 256 * 256;
+        }
+        // (pinned_scratch may move the block: h_counts is not used past this point)
+        char *stage = static_cast<char *>(pinned_scratch(dev->d, stage_bytes + 256));
+        if (!stage) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
+        if (!dev->d.orb_pattern) {
+            CVHIP_TRY_HIP(hipMalloc(&dev->d.orb_pattern, 1024));
+            CVHIP_TRY_HIP(hipMemcpyAsync(dev->d.orb_pattern, CVHIP_ORB_PATTERN, 1024, hipMemcpyHostToDevice, s));
+        }
+        const double guard = dev->d.orb_guard;
+        // descriptors of image j from the orientations in j.d_sc, results into the image's staging block
+        const auto describe = [&](OrbJob &j, double g) -> int {
+            uint32_t *d_out_n = j.d_pack, *d_out_xy = j.xy_dev ? j.out_xy : j.d_pack + 64,
+                     *d_out_desc = j.desc_dev ? j.out_desc : j.d_pack + 64 + (size_t)j.out_cap * 2;
+            CVHIP_TRY_HIP(hipMemsetAsync(j.d_pack, 0, 8, s)); // {n_out, open count}
+            hipLaunchKernelGGL(brief_kernel, dim3(j.count), dim3(64), 0, s, j.d_blur, j.w, j.h, j.d_kp, j.d_idx_sorted, j.count, j.d_sc,
+                               (const signed char *)dev->d.orb_pattern, j.d_desc, j.d_flags, g, j.d_pack + 1);
+            hipLaunchKernelGGL(final_compact_kernel, dim3(1), dim3(1024), 0, s, j.d_flags, j.d_kp, j.d_idx_sorted, j.d_desc, j.count,
+                               j.out_cap, d_out_xy, d_out_desc, d_out_n);
+            const size_t back = (j.xy_dev && j.desc_dev) ? 256 : j.pack_bytes;
+            CVHIP_TRY_HIP(hipMemcpyAsync(stage + j.pack_off, j.d_pack, back, hipMemcpyDeviceToHost, s));
+            return CVHIP_OK;
+        };
+        for (uint32_t i = 0; i < n_images; i++) {
+            OrbJob &j = jobs[i];
+            if (j.n_fast == 0) continue;
+            CVHIP_TRY_HIP(mem.alloc(&j.d_kp, (size_t)j.n_fast * 2));
+            hipLaunchKernelGGL(nms_write_kernel, dim3(j.nblocks), dim3(256), 0, s, j.d_score, j.w, j.h, j.d_counts, j.n_fast, j.d_kp);
+            unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
+            uint32_t *d_idx = nullptr;
+            CVHIP_TRY_HIP(mem.alloc(&d_keys, j.n_fast));
+            CVHIP_TRY_HIP(mem.alloc(&d_keys_sorted, j.n_fast));
+            CVHIP_TRY_HIP(mem.alloc(&d_idx, j.n_fast));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_idx_sorted, j.n_fast));
+            hipLaunchKernelGGL(harris_kernel, dim3((j.n_fast + 63) / 64), dim3(64), 0, s, j.d_img, j.w, j.h, j.d_kp, j.d_total, j.n_fast,
+                               k7, d_keys, d_idx);
+            size_t tmp_bytes = 0;
+            CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_idx, j.d_idx_sorted,
+                                                         (size_t)j.n_fast, 0u, 64u, s));
+            uint8_t *d_tmp = nullptr;
+            CVHIP_TRY_HIP(mem.alloc(&d_tmp, tmp_bytes));
+            CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx, j.d_idx_sorted,
+                                                         (size_t)j.n_fast, 0u, 64u, s));
+            double *d_blur_h = nullptr;
+            CVHIP_TRY_HIP(mem.alloc(&d_blur_h, j.n));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_blur, j.n));
+            dim3 grid2d((j.w + 63) / 64, (j.h + 3) / 4);
+            hipLaunchKernelGGL(blur_h_kernel, grid2d, dim3(256), 0, s, j.d_img, j.w, j.h, k11, d_blur_h);
+            hipLaunchKernelGGL(blur_v_kernel, grid2d, dim3(256), 0, s, d_blur_h, j.w, j.h, k11, j.d_blur);
+            CVHIP_TRY_HIP(mem.alloc(&j.d_mom, (size_t)j.count * 5));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_sc, (size_t)j.count * 3));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_desc, (size_t)j.count * 8));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_flags, j.count));
+            CVHIP_TRY_HIP(mem.alloc(&j.d_pack, j.pack_bytes / sizeof(uint32_t)));
+            j.xy_dev = dev_ptr(j.out_xy);
+            j.desc_dev = dev_ptr(j.out_desc);
+            hipLaunchKernelGGL(moments_kernel, dim3(j.count), dim3(64), 0, s, j.d_blur, j.w, j.h, j.d_kp, j.d_idx_sorted, j.count, j.d_mom,
+                               j.d_sc);
+            if (i == 0) report(0.35f);
+            if (guard > 0.0) {
+                CVHIP_TRY(describe(j, guard));
+            } else { // device orientations switched off (cvhip_orb_set_orientation_guard(dev, 0)): the host path for all
+                CVHIP_TRY_HIP(hipMemcpyAsync(stage + j.mom_off, j.d_mom, j.mom_bytes, hipMemcpyDeviceToHost, s));
+            }
+        }
+        report(0.70f);
+        CVHIP_TRY_HIP(hipStreamSynchronize(s));
+        CVHIP_TRY_HIP(hipGetLastError());
+
+        // ---- the images with a keypoint inside the guard band (rare), or all of them with the guard off: orientation
+        // on the host with libm, exactly as the reference (orb.rs:337-341, 365-366), and their descriptors again
+        std::vector<OrbJob *> redo;
+        for (OrbJob &j : jobs)
+            if (j.n_fast && (guard <= 0.0 || reinterpret_cast<const uint32_t *>(stage + j.pack_off)[1] != 0u)) redo.push_back(&j);
+        if (!redo.empty()) {
+            if (guard > 0.0) {
+                for (OrbJob *j : redo) CVHIP_TRY_HIP(hipMemcpyAsync(stage + j->mom_off, j->d_mom, j->mom_bytes, hipMemcpyDeviceToHost, s));
+                CVHIP_TRY_HIP(hipStreamSynchronize(s));
+            }
+            // (glibc's atan2 / sin / cos are ~70 ns each; the keypoints are independent, so a few host threads share them)
+            struct Span {
+                const unsigned long long *mom;
+                double *sc;
+                uint32_t r0, r1;
+            };
+            std::vector<Span> spans;
+            uint32_t total = 0;
+            for (const OrbJob *j : redo) total += j->count;
+            const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+            const uint32_t nthreads = std::min({8u, hw, total / 2048u + 1u});
+            const uint32_t per = std::max((total + nthreads - 1) / std::max(nthreads, 1u), 1u);
+            for (const OrbJob *j : redo)
+                for (uint32_t r0 = 0; r0 < j->count; r0 += per)
+                    spans.push_back(Span{reinterpret_cast<const unsigned long long *>(stage + j->mom_off),
+                                         reinterpret_cast<double *>(stage + j->sc_off), r0, std::min(j->count, r0 + per)});
+            const auto orient = [](const Span &sp) {
+                for (uint32_t r = sp.r0; r < sp.r1; r++) {
+                    const unsigned long long *m = sp.mom + 5 * (size_t)r;
+                    double *o = sp.sc + 3 * (size_t)r;
+                    o[0] = o[1] = o[2] = 0.0;
+                    if (!m[3]) continue; // (an entry past the Some(...) ones has no valid patch either)
+                    const double x = (double)(uint32_t)m[4], y = (double)(uint32_t)(m[4] >> 32);
+                    const double m00 = (double)m[0];
+                    const double centroid_x = (double)m[1] / m00;
+                    const double centroid_y = (double)m[2] / m00;
+                    const double angle = std::atan2(centroid_y - y, centroid_x - x);
+                    o[0] = std::sin(angle);
+                    o[1] = std::cos(angle);
+                    o[2] = 1.0;
+                }
+            };
+            std::vector<std::thread> pool;
+            size_t next = 1;
+            try {
+                for (; next < spans.size(); next++) pool.emplace_back(orient, spans[next]);
+            } catch (const std::system_error &) { // no more threads: the caller's thread does what was not handed out
+                for (size_t k = next; k < spans.size(); k++) orient(spans[k]);
+            }
+            if (!spans.empty()) orient(spans[0]);
+            for (auto &th : pool) th.join();
+            for (OrbJob *j : redo) {
+                CVHIP_TRY_HIP(hipMemcpyAsync(j->d_sc, stage + j->sc_off, j->sc_bytes, hipMemcpyHostToDevice, s));
+                CVHIP_TRY(describe(*j, 0.0));
+            }
+            CVHIP_TRY_HIP(hipStreamSynchronize(s));
+            CVHIP_TRY_HIP(hipGetLastError());
+        }
+        for (uint32_t i = 0; i < n_images; i++) {
+            OrbJob &j = jobs[i];
+            if (j.n_fast == 0) {
+                *j.out_n = 0;
+                continue;
+            }
+            const char *h_pack = stage + j.pack_off;
+            const uint32_t n_out = *reinterpret_cast<const uint32_t *>(h_pack);
+            if (!j.xy_dev && n_out) std::memcpy(j.out_xy, h_pack + 256, (size_t)n_out * 2 * sizeof(uint32_t));
+            if (!j.desc_dev && n_out)
+                std::memcpy(j.out_desc, h_pack + 256 + (size_t)j.out_cap * 2 * sizeof(uint32_t), (size_t)n_out * 8 * sizeof(uint32_t));
+            *j.out_n = n_out;
+        }
         report(1.0f);
         return CVHIP_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of host memory");
     }
-    uint32_t *d_kp = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_kp, (size_t)n_fast * 2));
-    hipLaunchKernelGGL(nms_write_kernel, dim3(nblocks), dim3(256), 0, s, d_score, w, h, d_counts, n_fast, d_kp);
-    report(0.35f);
+}
 
-    // 2. Harris on the original image, stable descending sort, top MAX_KEYPOINTS
-    Taps7 k7;
-    gaussian_kernel_host(HARRIS_KERNEL_WIDTH, k7.k);
-    unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
-    uint32_t *d_idx = nullptr, *d_idx_sorted = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_keys, n_fast));
-    CVHIP_TRY_HIP(mem.alloc(&d_keys_sorted, n_fast));
-    CVHIP_TRY_HIP(mem.alloc(&d_idx, n_fast));
-    CVHIP_TRY_HIP(mem.alloc(&d_idx_sorted, n_fast));
-    hipLaunchKernelGGL(harris_kernel, dim3((n_fast + 63) / 64), dim3(64), 0, s, d_img, w, h, d_kp, d_total, n_fast, k7,
-                       d_keys, d_idx);
-    size_t tmp_bytes = 0;
-    CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx_sorted,
-                                                 (size_t)n_fast, 0u, 64u, s));
-    uint8_t *d_tmp = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_tmp, tmp_bytes));
-    CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(d_tmp, tmp_bytes, d_keys, d_keys_sorted, d_idx, d_idx_sorted,
-                                                 (size_t)n_fast, 0u, 64u, s));
-    const uint32_t count = std::min(n_fast, MAX_KEYPOINTS); // entries past the Some(...) ones carry idx = ~0
-    report(0.70f);
-
-    // 3. blur of the original image, patch moments
-    Taps11 k11;
-    gaussian_kernel_host(ORB_GAUSS_KERNEL_WIDTH, k11.k);
-    double *d_blur_h = nullptr, *d_blur = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_blur_h, n));
-    CVHIP_TRY_HIP(mem.alloc(&d_blur, n));
-    hipLaunchKernelGGL(blur_h_kernel, grid2d, dim3(256), 0, s, d_img, w, h, k11, d_blur_h);
-    hipLaunchKernelGGL(blur_v_kernel, grid2d, dim3(256), 0, s, d_blur_h, w, h, k11, d_blur);
-    unsigned long long *d_mom = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_mom, (size_t)count * 5));
-    hipLaunchKernelGGL(moments_kernel, dim3(count), dim3(64), 0, s, d_blur, w, h, d_kp, d_idx_sorted, count, d_mom);
-    // one page-locked staging area for everything that crosses the bus from here on:
-    // [moments + keypoint, 5 u64 per rank] [sin, cos, valid: 3 f64 per rank] [n_out + outputs]
-    const uint32_t out_cap = std::min(cap, count);
-    const size_t mom_bytes = (size_t)count * 5 * sizeof(unsigned long long), sc_bytes = (size_t)count * 3 * sizeof(double);
-    const size_t pack_bytes = 256 + (size_t)out_cap * 10 * sizeof(uint32_t);
-    char *stage = static_cast<char *>(pinned_scratch(dev->d, mom_bytes + sc_bytes + pack_bytes));
-    if (!stage) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
-    const unsigned long long *h_mom = reinterpret_cast<const unsigned long long *>(stage);
-    double *h_sc = reinterpret_cast<double *>(stage + mom_bytes);
-    char *h_pack = stage + mom_bytes + sc_bytes;
-    CVHIP_TRY_HIP(hipMemcpyAsync(stage, d_mom, mom_bytes, hipMemcpyDeviceToHost, s));
-    CVHIP_TRY_HIP(hipStreamSynchronize(s));
-    CVHIP_TRY_HIP(hipGetLastError());
-
-    // 4. orientation on the host with libm, exactly as the reference (orb.rs:337-341, 365-366)
-    // (glibc's atan2 / sin / cos are ~70 ns per keypoint; the keypoints are independent, so a few host threads share them)
-    const auto orient = [&](uint32_t r0, uint32_t r1) {
-        for (uint32_t r = r0; r < r1; r++) {
-            h_sc[3 * (size_t)r + 0] = h_sc[3 * (size_t)r + 1] = h_sc[3 * (size_t)r + 2] = 0.0;
-            if (!h_mom[5 * (size_t)r + 3]) continue; // (an entry past the Some(...) ones has no valid patch either)
-            const double x = (double)(uint32_t)h_mom[5 * (size_t)r + 4], y = (double)(uint32_t)(h_mom[5 * (size_t)r + 4] >> 32);
-            const double m00 = (double)h_mom[5 * (size_t)r + 0];
-            const double centroid_x = (double)h_mom[5 * (size_t)r + 1] / m00;
-            const double centroid_y = (double)h_mom[5 * (size_t)r + 2] / m00;
-            const double angle = std::atan2(centroid_y - y, centroid_x - x);
-            h_sc[3 * (size_t)r + 0] = std::sin(angle);
-            h_sc[3 * (size_t)r + 1] = std::cos(angle);
-            h_sc[3 * (size_t)r + 2] = 1.0;
-        }
-    };
-    {
-        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t nthreads = std::min({4u, hw, count / 2048u + 1u});
-        std::vector<std::thread> pool;
-        const uint32_t per = (count + nthreads - 1) / nthreads;
-        try {
-            for (uint32_t k = 1; k < nthreads; k++)
-                pool.emplace_back(orient, std::min(count, k * per), std::min(count, (k + 1) * per));
-        } catch (const std::system_error &) { // no more threads: the caller's thread does what was not handed out
-            orient(std::min(count, (uint32_t)(pool.size() + 1) * per), count);
-        }
-        orient(0, std::min(count, per));
-        for (auto &th : pool) th.join();
-    }
-
-    // 5. descriptors + ordered compaction; host destinations are filled through ONE copy of {n, xy, desc}
-    double *d_sc = nullptr;
-    uint32_t *d_desc = nullptr, *d_flags = nullptr, *d_pack = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_sc, (size_t)count * 3));
-    CVHIP_TRY_HIP(mem.alloc(&d_desc, (size_t)count * 8));
-    CVHIP_TRY_HIP(mem.alloc(&d_flags, count));
-    CVHIP_TRY_HIP(mem.alloc(&d_pack, pack_bytes / sizeof(uint32_t)));
-    if (!dev->d.orb_pattern) {
-        CVHIP_TRY_HIP(hipMalloc(&dev->d.orb_pattern, 1024));
-        CVHIP_TRY_HIP(hipMemcpyAsync(dev->d.orb_pattern, CVHIP_ORB_PATTERN, 1024, hipMemcpyHostToDevice, s));
-    }
-    const bool xy_dev = dev_ptr(out_xy), desc_dev = dev_ptr(out_desc);
-    uint32_t *d_out_n = d_pack, *d_out_xy = xy_dev ? out_xy : d_pack + 64, *d_out_desc = desc_dev ? out_desc : d_pack + 64 + (size_t)out_cap * 2;
-    CVHIP_TRY_HIP(hipMemcpyAsync(d_sc, h_sc, sc_bytes, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(brief_kernel, dim3(count), dim3(64), 0, s, d_blur, w, h, d_kp, d_idx_sorted, count, d_sc,
-                       (const signed char *)dev->d.orb_pattern, d_desc, d_flags);
-    hipLaunchKernelGGL(final_compact_kernel, dim3(1), dim3(1024), 0, s, d_flags, d_kp, d_idx_sorted, d_desc, count,
-                       out_cap, d_out_xy, d_out_desc, d_out_n);
-    const size_t back = (xy_dev && desc_dev) ? 256 : pack_bytes;
-    CVHIP_TRY_HIP(hipMemcpyAsync(h_pack, d_pack, back, hipMemcpyDeviceToHost, s));
-    CVHIP_TRY_HIP(hipStreamSynchronize(s));
-    CVHIP_TRY_HIP(hipGetLastError());
-    const uint32_t n_out = *reinterpret_cast<const uint32_t *>(h_pack);
-    if (!xy_dev && n_out) std::memcpy(out_xy, h_pack + 256, (size_t)n_out * 2 * sizeof(uint32_t));
-    if (!desc_dev && n_out) std::memcpy(out_desc, h_pack + 256 + (size_t)out_cap * 2 * sizeof(uint32_t), (size_t)n_out * 8 * sizeof(uint32_t));
-    *out_n = n_out;
-    report(1.0f);
+extern "C" int cvhip_orb_set_orientation_guard(cvhip_device *dev, double guard)
+{
+    if (!dev) return fail(CVHIP_ERR_INVALID, "dev is null");
+    if (!(guard >= 0.0) || guard > 1.0) return fail(CVHIP_ERR_INVALID, "guard must be in [0, 1]");
+    dev->d.orb_guard = guard;
     return CVHIP_OK;
+}
+
+extern "C" int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
+                                 uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n, cvhip_progress_fn progress, void *user)
+{
+    if (!dev || !img || !out_xy || !out_desc || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
+    return cvhip_orb_extract_batch(dev, 1, &img, &w, &h, cap, &out_xy, &out_desc, out_n, progress, user);
 }
 
 extern "C" int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const uint32_t *desc1, uint32_t n1,

@@ -37,6 +37,14 @@ class ImageReconstruction:
         steps = orb.optimal_scale_steps(*dims)
         return self._timed("orb", lambda: orb.extract_points_multiscale(self.device, pyramid[:steps + 1]))
 
+    # the same for every image of the set in ONE batched call (all levels of all images: cvhip_orb_extract_batch)
+    def extract_keypoints_set(self, pyramids):
+        trimmed = []
+        for pyramid in pyramids:
+            dims = (int(pyramid[0].shape[1]), int(pyramid[0].shape[0]))
+            trimmed.append(pyramid[:orb.optimal_scale_steps(*dims) + 1])
+        return self._timed("orb", lambda: orb.extract_points_multiscale_set(self.device, trimmed))
+
     # reconstruction.rs:400-500
     def match_keypoints(self, keypoints1, keypoints2):
         thr = (pointmatching.THRESHOLD_PERSPECTIVE if self.projection_mode == ProjectionMode.Perspective
@@ -90,7 +98,7 @@ def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = Projec
     -> dict: keypoints [n], pairs {(i, j): {matches, f, inliers, (xy, corr)}}, timings_ms per stage."""
     rec = ImageReconstruction(device, projection_mode)
     n = len(pyramids)
-    keypoints = [rec.extract_keypoints(p) for p in pyramids]
+    keypoints = rec.extract_keypoints_set(pyramids)
     pairs = {}
     for i in range(n - 1):
         for j in range(i + 1, n):

@@ -297,6 +297,21 @@ int cvhip_resize_lanczos3(cvhip_device *dev, const uint8_t *src, uint32_t w, uin
  * ---------------------------------------------------------------------------------------- */
 int cvhip_orb_extract(cvhip_device *dev, const uint8_t *img, uint32_t w, uint32_t h, uint32_t cap,
                       uint32_t *out_xy, uint32_t *out_desc, uint32_t *out_n, cvhip_progress_fn progress, void *user);
+/* The same for n_images independent images in one call - the pyramid levels of an image, as match_keypoints' per-image
+ * loop extracts them (reconstruction.rs:418-458), or the images of a set.  An extraction has three host round trips
+ * (corner counts; results - and, for an image with a keypoint inside the orientation guard band, patch moments out /
+ * libm orientations in); the batch enqueues every image's work of a stage before it waits, so it pays them once.  Results per image are exactly cvhip_orb_extract's.  imgs / ws / hs / out_xy / out_desc: n_images entries
+ * (each out_xy[i]: 2*cap u32, out_desc[i]: 8*cap u32); out_n: n_images counts. */
+/* Test hook of the orientation step.  The reference computes atan2 / sin / cos with libm (orb.rs:337-341, 365-366); the
+ * extraction uses the device's f64 functions wherever that provably gives the same rounded sample offsets - every
+ * round(o_y cos - o_x sin) farther than `guard` from a half-integer - and redoes an image with the host's libm
+ * otherwise.  Default 1e-9 (the functions agree to a few ulp: offsets move by < 1e-12).  A larger guard sends more
+ * images down the host path, 0 switches the device orientation off (every image takes the host path).  Results are
+ * identical for every setting. */
+int cvhip_orb_set_orientation_guard(cvhip_device *dev, double guard);
+int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, const uint8_t *const *imgs, const uint32_t *ws,
+                            const uint32_t *hs, uint32_t cap, uint32_t *const *out_xy, uint32_t *const *out_desc,
+                            uint32_t *out_n, cvhip_progress_fn progress, void *user);
 
 /* ------------------------------------------------------------------------------------------
  * Keypoint matcher — replaces KeypointMatching::match_points (pointmatching.rs:43-77).

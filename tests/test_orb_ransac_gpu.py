@@ -484,3 +484,49 @@ def test_progress_listeners_of_orb_and_ransac(gpu_device):
     fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Affine, 2000.0).find_ransac(gpu_device, ma, seed=7, progress_listener=pl)
     assert 1 <= len(pl.status) <= 20 and pl.status == sorted(pl.status)   # early exit above 1000 inliers (:135-141)
     assert pl.matches == sorted(pl.matches) and pl.matches[-1] > 1000
+
+
+def test_orb_batch_equals_single_extractions(gpu_device, oracle):
+    """cvhip_orb_extract_batch: several images of different sizes in one call - among them one without any corner and
+    one above the keypoint cap - give exactly what one cvhip_orb_extract per image gives (and so the oracle's
+    keypoints); likewise the multi-scale drivers built on it."""
+    imgs = [orb_image(400, 300, seed=3), np.full((80, 120), 9, dtype=np.uint8), orb_image(1024, 768, seed=5, blocks=2500),
+            orb_image(97, 131, seed=6)]
+    single = [orb.extract_points(gpu_device, im) for im in imgs]
+    pos = []
+    batch = orb.extract_points_batch(gpu_device, imgs, progress=pos.append)
+    assert [round(p, 2) for p in pos] == [0.20, 0.25, 0.35, 0.70, 1.0]
+    for (xy_a, d_a), (xy_b, d_b) in zip(single, batch):
+        assert xy_a.shape == xy_b.shape and (xy_a == xy_b).all() and (d_a == d_b).all()
+    assert len(batch[1][0]) == 0 and len(batch[2][0]) > 5000
+    want_xy, want_desc = oracle.orb_extract(imgs[0])
+    assert (batch[0][0] == want_xy).all() and (batch[0][1] == want_desc).all()
+    import torch
+    dev_imgs = [torch.from_numpy(im).cuda() for im in imgs]
+    for (xy_a, d_a), (xy_b, d_b) in zip(single, orb.extract_points_batch(gpu_device, dev_imgs)):
+        assert (xy_a == xy_b).all() and (d_a == d_b).all()
+    base = orb_image(1100, 900, seed=8, blocks=900)
+    steps = orb.optimal_scale_steps(1100, 900)
+    pyr = synth.box_pyramid(base, steps)
+    a = orb.extract_points_multiscale(gpu_device, pyr, batched=False)
+    b = orb.extract_points_multiscale(gpu_device, pyr, batched=True)
+    c = orb.extract_points_multiscale_set(gpu_device, [pyr, pyr[1:]])
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (c[0][0] == a[0]).all() and (c[0][1] == a[1]).all()
+    assert len(c[1][0]) > 100
+
+
+def test_orb_orientation_guard_settings_agree(gpu_device, oracle):
+    """The orientation step: device atan2 / sin / cos where every rounded sample offset is provably the libm one, the
+    host's libm otherwise (cvhip_orb_set_orientation_guard).  Default guard, a guard so wide that most images take the
+    host path, every image forced through it, and the guard off must all give the oracle's keypoints and descriptors
+    (the oracle calls libm)."""
+    imgs = [orb_image(640, 480, seed=21), orb_image(333, 517, seed=22, blocks=300)]
+    want = [oracle.orb_extract(im) for im in imgs]
+    try:
+        for guard in (1e-9, 0.02, 0.5, 0.0):
+            orb.set_orientation_guard(gpu_device, guard)
+            got = orb.extract_points_batch(gpu_device, imgs)
+            for (xy, desc), (wxy, wdesc) in zip(got, want):
+                assert xy.shape == wxy.shape and (xy == wxy).all() and (desc == wdesc).all(), f"guard {guard}"
+    finally:
+        orb.set_orientation_guard(gpu_device, 1e-9)
