@@ -800,24 +800,31 @@ __global__ __launch_bounds__(1024) void ransac_tied_sum_kernel(const double *__r
     }
 }
 
+// The live slots of a round's hypothesis buffer, in slot order (count, scan, scatter).  Depends on the hypotheses only,
+// so the device loops run it on the GENERATOR's stream right behind the generation - off the scoring chain.
+// scratch: ceil(H / 1024) words.
+static void launch_ransac_live(const double *F, uint32_t H, uint32_t *live, uint32_t *n_live, uint32_t *scratch, hipStream_t s)
+{
+    const uint32_t nblocks = (H + 1023) / 1024;
+    hipLaunchKernelGGL(ransac_live_count_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, scratch);
+    launch_scan_u32(scratch, nblocks, n_live, s);
+    hipLaunchKernelGGL(ransac_live_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, (const uint32_t *)scratch, live);
+}
+
+// tied: [2 + TIED_CAP] words (number, slots, the maximum itself); coord_max: one word (ransac_coord_max_kernel);
+// live_ready: the live list was already built (launch_ransac_live)
 static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, const float4 *matches_f32,
-                                      uint32_t N, double t, uint32_t *live, uint32_t *n_live, uint32_t min_count, RansacBest *best,
+                                      uint32_t N, double t, uint32_t *live, uint32_t *n_live, uint32_t *tied,
+                                      const uint32_t *coord_max, bool live_ready, uint32_t min_count, RansacBest *best,
                                       uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
-    // scratch: the per-block counts live in out_err_sum's first words until the count kernel overwrites them; the
-    // round maximum sits behind the live count
-    uint32_t *block_counts = reinterpret_cast<uint32_t *>(out_err_sum);
-    uint32_t *tied = n_live + 1; // [2 + TIED_CAP]: number, slots, the maximum itself; then one word: the largest coordinate
-    const uint32_t nblocks = (H + 1023) / 1024;
     const uint4 *m4 = reinterpret_cast<const uint4 *>(matches);
     (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(ransac_live_count_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, block_counts);
-    launch_scan_u32(block_counts, nblocks, n_live, s);
-    hipLaunchKernelGGL(ransac_live_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, F, H, (const uint32_t *)block_counts, live);
+    // (scratch of the compaction: out_err_sum's first words, until the count kernel overwrites them)
+    if (!live_ready) launch_ransac_live(F, H, live, n_live, reinterpret_cast<uint32_t *>(out_err_sum), s);
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
     hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 3) / 4), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
-                       (const uint32_t *)n_live, min_count, (const RansacBest *)best, (const uint32_t *)(n_live + 3 + TIED_CAP),
-                       matches_f32, out_count, out_err_sum);
+                       (const uint32_t *)n_live, min_count, (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum);
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
     hipLaunchKernelGGL(ransac_tied_sum_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied,
@@ -1357,14 +1364,34 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_kernel(const double *__
     __shared__ uint32_t s_idx[1024];
     uint32_t bc = 0, bi = 0xFFFFFFFFu;
     double be = __builtin_inf();
-    for (uint32_t h = threadIdx.x; h < H; h += 1024) {
-        const uint32_t c = counts[h];
-        if (c < min_count) continue; // :218-220
-        const double e = err_sums[h] / (double)c;
-        if (bi == 0xFFFFFFFFu || ransac_better(c, e, bc, be)) {
-            bc = c;
-            be = e;
-            bi = h;
+    // Equal (count, error): the smaller slot, whatever order the candidates are visited in (the full scan visits them
+    // in slot order, the round's maximum list is in the order its atomics landed).
+    const auto better_slot = [](uint32_t ca, double ea, uint32_t ia, uint32_t cb, double eb, uint32_t ib) {
+        return ransac_better(ca, ea, cb, eb) || (!ransac_better(cb, eb, ca, ea) && ia < ib);
+    };
+    const bool listed = tied != nullptr && tied[0] <= TIED_CAP;
+    if (listed) {
+        // the round's best hypothesis is one with the round's largest count: only those need looking at (a handful)
+        for (uint32_t k = threadIdx.x; k < tied[0]; k += 1024) {
+            const uint32_t h = tied[1 + k], c = counts[h];
+            if (c < min_count) continue; // :218-220
+            const double e = err_sums[h] / (double)c;
+            if (bi == 0xFFFFFFFFu || better_slot(c, e, h, bc, be, bi)) {
+                bc = c;
+                be = e;
+                bi = h;
+            }
+        }
+    } else {
+        for (uint32_t h = threadIdx.x; h < H; h += 1024) {
+            const uint32_t c = counts[h];
+            if (c < min_count) continue; // :218-220
+            const double e = err_sums[h] / (double)c;
+            if (bi == 0xFFFFFFFFu || ransac_better(c, e, bc, be)) {
+                bc = c;
+                be = e;
+                bi = h;
+            }
         }
     }
     s_cnt[threadIdx.x] = bc;
@@ -1375,7 +1402,8 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_kernel(const double *__
         if (threadIdx.x < s) {
             const uint32_t o = threadIdx.x + s;
             if (s_idx[o] != 0xFFFFFFFFu &&
-                (s_idx[threadIdx.x] == 0xFFFFFFFFu || ransac_better(s_cnt[o], s_err[o], s_cnt[threadIdx.x], s_err[threadIdx.x]))) {
+                (s_idx[threadIdx.x] == 0xFFFFFFFFu ||
+                 better_slot(s_cnt[o], s_err[o], s_idx[o], s_cnt[threadIdx.x], s_err[threadIdx.x], s_idx[threadIdx.x]))) {
                 s_cnt[threadIdx.x] = s_cnt[o];
                 s_err[threadIdx.x] = s_err[o];
                 s_idx[threadIdx.x] = s_idx[o];
@@ -1496,7 +1524,8 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     CVHIP_TRY_HIP(mem.alloc(&d_mf, std::max(N, 1u)));
     hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
                        d_live + H + 3 + TIED_CAP, d_mf);
-    launch_ransac_score_round(d_F, H, d_m, d_mf, N, t, d_live, d_live + H, 0u, d_best, d_cnt, d_err, s);
+    launch_ransac_score_round(d_F, H, d_m, d_mf, N, t, d_live, d_live + H, d_live + H + 1, d_live + H + 3 + TIED_CAP, false, 0u, d_best,
+                              d_cnt, d_err, s);
     CVHIP_TRY_HIP(hipGetLastError());
     CVHIP_TRY_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)H * sizeof(uint32_t), dev_ptr(out_count) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     CVHIP_TRY_HIP(hipMemcpyAsync(out_err_sum, d_err, (size_t)H * sizeof(double), dev_ptr(out_err_sum) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -1562,7 +1591,8 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
         hipLaunchKernelGGL(ransac_generate_affine_kernel, dim3((CHECK_INTERVAL + 63) / 64), dim3(64), 0, s, m4,
                            std::min(N, TOP_INLIERS), RANSAC_T, (unsigned long long)seed, round, CHECK_INTERVAL,
                            (const uint32_t *)nullptr, d_F);
-        launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, d_mf, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL, RANSAC_D + RANSAC_N, d_best,
+        launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, d_mf, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL,
+                                  d_live + CHECK_INTERVAL + 1, d_live + CHECK_INTERVAL + 3 + TIED_CAP, false, RANSAC_D + RANSAC_N, d_best,
                                   d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, CHECK_INTERVAL,
                            RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best);
@@ -1621,8 +1651,12 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = mem.alloc(&d_err, (size_t)H);
     if (e == hipSuccess) e = mem.alloc(&d_best, 1);
     if (e == hipSuccess) e = mem.alloc(&d_mask, N);
+    // per hypothesis buffer: the live list [H], its length [1] and the compaction's scratch; then the round's maximum list
+    // [2 + TIED_CAP] and the largest coordinate [1]
+    const size_t live_words = (size_t)H + 1 + (H + 1023) / 1024;
     uint32_t *d_live = nullptr;
-    if (e == hipSuccess) e = mem.alloc(&d_live, (size_t)H + 4 + TIED_CAP);
+    if (e == hipSuccess) e = mem.alloc(&d_live, GEN_DEPTH * live_words + 3 + TIED_CAP);
+    uint32_t *const d_tied = d_live + GEN_DEPTH * live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
     float4 *d_mf = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_mf, N);
     if (e == hipSuccess)
@@ -1630,7 +1664,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     if (e == hipSuccess) // the scale of the counting kernel's f32 screen: one word behind the round's maximum list
         hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
-                           d_live + H + 3 + TIED_CAP, d_mf);
+                           d_coord_max, d_mf);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
@@ -1662,6 +1696,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         hipError_t ge = r >= GEN_DEPTH ? hipStreamWaitEvent(gs, scored[b], 0) : hipSuccess;
         if (ge != hipSuccess) return ge;
         generate(m4, r, (int)b, d_F + (size_t)b * H * 9, gs);
+        // the buffer's live list, right behind its generation: three small launches less on the scoring chain
+        uint32_t *lv = d_live + (size_t)b * live_words;
+        launch_ransac_live(d_F + (size_t)b * H * 9, H, lv, lv + H, lv + H + 1, gs);
         return hipEventRecord(ready[b], gs);
     };
     for (uint32_t r = 0; r + 1 < GEN_DEPTH && r < rounds && e == hipSuccess; r++) e = generate_round(r);
@@ -1670,9 +1707,10 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         double *F_round = d_F + (size_t)b * H * 9;
         if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
-        launch_ransac_score_round(F_round, H, d_m, d_mf, N, t, d_live, d_live + H, min_count, d_best, d_cnt, d_err, s);
+        uint32_t *lv = d_live + (size_t)b * live_words;
+        launch_ransac_score_round(F_round, H, d_m, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, min_count, d_best, d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, F_round, d_cnt, d_err, H, min_count,
-                           (const uint32_t *)(d_live + H + 1), d_best);
+                           (const uint32_t *)d_tied, d_best);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(scored[b], s);
         if (!may_exit_early && !g_listener.wants_counts() && round + 1 < rounds) {
