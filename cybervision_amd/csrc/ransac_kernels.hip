@@ -110,7 +110,8 @@ __host__ __device__ CVHIP_LM_INLINE double residual_of(const double (&M)[9], con
     return top * top / (mp1[0] * mp1[0] + mp1[1] * mp1[1] + mtp2[0] * mtp2[0] + mtp2[1] * mtp2[1]);
 }
 
-__host__ __device__ CVHIP_LM_INLINE void gradient_of(const double (&M)[9], const Obs &o, double *out7) // f_jacobian, :473-512
+// f_jacobian (:473-512) in two pieces: the terms every element of a row shares, and one element
+__host__ __device__ CVHIP_LM_INLINE double gradient_terms(const double (&M)[9], const Obs &o) // -> c (= d)
 {
     double mp1[3], mtp2[3];
     for (int i = 0; i < 3; i++) {
@@ -118,18 +119,25 @@ __host__ __device__ CVHIP_LM_INLINE void gradient_of(const double (&M)[9], const
         mp1[i] = chain3(row, o.p1);
     }
     for (int i = 0; i < 3; i++) mtp2[i] = (M[i] * o.p2[0] + M[3 + i] * o.p2[1]) + M[6 + i] * o.p2[2];
-    const double c = mp1[0] + mp1[1] + mtp2[0] + mtp2[1], d = c;
-    for (int e = 0; e < 7; e++) {
-        const int r = e / 3, k = e % 3;
-        const double a = o.p2[r] * o.p1[k]; // p2' E_rk p1: the other eight products are exact zeros
-        double rest[9];
-        for (int i = 0; i < 9; i++) rest[i] = M[i];
-        rest[3 * r + k] = 0.0;
-        double rv[3];
-        row_times(o.p2, rest, rv);
-        const double b = chain3(rv, o.p1), x = M[3 * r + k];
-        out7[e] = 2.0 * (a * x + b) * (a * d - b * c * c * x) / (c * c * x * x + d);
-    }
+    return mp1[0] + mp1[1] + mtp2[0] + mtp2[1];
+}
+__host__ __device__ CVHIP_LM_INLINE double gradient_element(const double (&M)[9], const Obs &o, double c, int e)
+{
+    const double d = c;
+    const int r = e / 3, k = e % 3;
+    const double a = o.p2[r] * o.p1[k]; // p2' E_rk p1: the other eight products are exact zeros
+    double rest[9];
+    for (int i = 0; i < 9; i++) rest[i] = M[i];
+    rest[3 * r + k] = 0.0;
+    double rv[3];
+    row_times(o.p2, rest, rv);
+    const double b = chain3(rv, o.p1), x = M[3 * r + k];
+    return 2.0 * (a * x + b) * (a * d - b * c * c * x) / (c * c * x * x + d);
+}
+__host__ __device__ CVHIP_LM_INLINE void gradient_of(const double (&M)[9], const Obs &o, double *out7) // f_jacobian, :473-512
+{
+    const double c = gradient_terms(M, o);
+    for (int e = 0; e < 7; e++) out7[e] = gradient_element(M, o, c, e);
 }
 
 // (J'J + mu I) x = g, nalgebra's LU::new + LU::solve; false = "Failed to compute delta vector".  Every index below
@@ -800,6 +808,177 @@ __global__ __launch_bounds__(1024) void ransac_tied_sum_kernel(const double *__r
     }
 }
 
+__device__ __forceinline__ bool ransac_better(uint32_t ca, double ea, uint32_t cb, double eb); // Ord, defined below
+
+// ---- the device loops' form of the tie-break: parallel sums first, the ordered fold only where it decides ----------
+// Ord (:623-649) compares the MEAN ERRORS of two hypotheses only when their counts are equal, and all that matters is
+// which of the two serial sums is smaller.  A parallel sum S' of the same non-negative terms (each thread its strided
+// share, then a fixed tree) and the reference's left-to-right sum S both lie within n u S (n = 29 000 terms, u = 2^-53:
+// 3.3e-12 relative) of the exact sum, so S'_a < S'_b (1 - 1e-10) implies S_a < S_b.  ransac_tied_approx_kernel computes
+// S' for the hypotheses at the round's maximum count (and for the carried best where it ties with them) with the whole
+// GPU instead of one thread's 29 000 dependent additions; ransac_pick_best_approx_kernel orders them by S' and computes
+// the reference's ordered fold - block_ordered_sum, the same fold as ransac_tied_sum_kernel - only for candidates whose
+// S' lie within 1e-10 of the smallest (exact duplicates of a sample, in practice).
+__device__ double block_parallel_sum(const double (&f)[9], const uint4 *__restrict__ matches, uint32_t N, double t, double *scratch16)
+{
+    const double t_hi = t * (1.0 + 0x1p-40);
+    double part = 0.0;
+    for (uint32_t i = threadIdx.x; i < N; i += 1024) {
+        double err = 0.0;
+        if (match_fits(f, matches[i], t, t_hi, err)) part += err;
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_down(part, sft, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch16[threadIdx.x >> 6] = part;
+    __syncthreads();
+    double total = 0.0;
+    for (int w = 0; w < 16; w++) total += scratch16[w];
+    return total; // (every thread returns the same value)
+}
+// the reference's fold (errors in parallel, added left to right by one thread); every thread returns the sum
+__device__ double block_ordered_sum(const double (&f)[9], const uint4 *__restrict__ matches, uint32_t N, double t, double *errs1024,
+                                    double *result)
+{
+    const double t_hi = t * (1.0 + 0x1p-40);
+    double sum = 0.0;
+    for (uint32_t base = 0; base < N; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        double err = 0.0;
+        const bool in = i < N && match_fits(f, matches[i], t, t_hi, err);
+        __syncthreads();
+        errs1024[threadIdx.x] = in ? err : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (uint32_t q = 0; q < 1024; q++) sum += errs1024[q];
+        }
+    }
+    if (threadIdx.x == 0) *result = sum;
+    __syncthreads();
+    return *result;
+}
+
+__global__ __launch_bounds__(1024) void ransac_tied_approx_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                                   uint32_t N, double t, const uint32_t *__restrict__ tied,
+                                                                   RansacBest *best, double *__restrict__ out_err_sum)
+{
+    __shared__ double scratch[16];
+    if (tied[0] == 0u || tied[0] > TIED_CAP || !ransac_round_needs_errors(tied, best)) return;
+    const uint32_t n_items = tied[0], top = tied[1 + TIED_CAP];
+    const uint32_t n_all = n_items + ((best->valid && top == best->matches_count && !best->err_known) ? 1u : 0u);
+    for (uint32_t b = blockIdx.x; b < n_all; b += gridDim.x) {
+        const bool carried = b == n_items;
+        const uint32_t h = carried ? 0u : tied[1 + b];
+        double f[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) f[i] = carried ? best->f[i] : F[(size_t)h * 9 + i];
+        const double sum = block_parallel_sum(f, matches, N, t, scratch);
+        if (threadIdx.x == 0) {
+            if (carried) {
+                best->best_error = sum / (double)best->matches_count;
+                best->err_known = 1u; // 1 = from a parallel sum, 2 = the reference's ordered fold
+            } else {
+                out_err_sum[h] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                                        uint32_t N, double t, const uint32_t *__restrict__ counts,
+                                                                        double *__restrict__ err_sums, uint32_t min_count,
+                                                                        const uint32_t *__restrict__ tied, RansacBest *best)
+{
+    __shared__ double errs[1024];
+    __shared__ double s_result;
+    __shared__ uint32_t s_close[64]; // candidates within the margin of the smallest parallel sum (slots; ~0u = the carried best)
+    __shared__ uint32_t s_nclose, s_winner, s_exact;
+    __shared__ double s_winner_err;
+    const uint32_t n = tied[0], top = tied[1 + TIED_CAP];
+    if (n == 0u || n > TIED_CAP || top < min_count) return; // (more than TIED_CAP ties: never seen; the round is then skipped)
+    const bool errors = ransac_round_needs_errors(tied, best); // were this round's sums computed?
+    const bool carried_ties = best->valid && top == best->matches_count;
+    constexpr double MARGIN = 1e-10;
+    if (threadIdx.x == 0) {
+        // smallest parallel sum among the round's candidates (smaller slot first among equals)
+        uint32_t bi = 0xFFFFFFFFu;
+        double be = 0.0;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t h = tied[1 + k];
+            const double e = errors ? err_sums[h] / (double)top : 0.0;
+            const bool ef = fabs(e) < __builtin_inf(), bf = fabs(be) < __builtin_inf();
+            if (bi == 0xFFFFFFFFu || (ef && !bf) || (ef == bf && (e < be || (e == be && h < bi)))) {
+                bi = h;
+                be = e;
+            }
+        }
+        s_winner = bi;
+        s_winner_err = be;
+        s_exact = 0u;
+        uint32_t nc = 0;
+        if (errors) {
+            // who else is within the margin of it - the other candidates of the round, and the carried best
+            const double lim = be + MARGIN * fabs(be);
+            for (uint32_t k = 0; k < n && nc < 63u; k++) {
+                const uint32_t h = tied[1 + k];
+                if (h != bi && err_sums[h] / (double)top <= lim) s_close[nc++] = h;
+            }
+            if (carried_ties && fabs(best->best_error - be) <= MARGIN * fmax(fabs(best->best_error), fabs(be)) && best->err_known != 2u)
+                s_close[nc++] = 0xFFFFFFFFu;
+            if (nc > 0) s_close[nc++] = bi; // the winner itself needs its ordered sum too
+        }
+        s_nclose = nc;
+    }
+    __syncthreads();
+    if (s_nclose > 0) { // (rare) the reference's ordered fold for everybody inside the margin
+        for (uint32_t k = 0; k < s_nclose; k++) {
+            const uint32_t h = s_close[k];
+            double f[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) f[i] = h == 0xFFFFFFFFu ? best->f[i] : F[(size_t)h * 9 + i];
+            const double sum = block_ordered_sum(f, matches, N, t, errs, &s_result);
+            if (threadIdx.x == 0) {
+                if (h == 0xFFFFFFFFu) {
+                    best->best_error = sum / (double)best->matches_count;
+                    best->err_known = 2u;
+                } else {
+                    err_sums[h] = sum;
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { // the winner among them by the ordered sums
+            uint32_t bi = 0xFFFFFFFFu;
+            double be = 0.0;
+            for (uint32_t k = 0; k < s_nclose; k++) {
+                const uint32_t h = s_close[k];
+                if (h == 0xFFFFFFFFu) continue;
+                const double e = err_sums[h] / (double)top;
+                if (bi == 0xFFFFFFFFu || e < be || (e == be && h < bi)) {
+                    bi = h;
+                    be = e;
+                }
+            }
+            s_winner = bi;
+            s_winner_err = be;
+            s_exact = 1u;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t w = s_winner;
+        if (!best->valid || ransac_better(top, s_winner_err, best->matches_count, best->best_error)) {
+            for (int i = 0; i < 9; i++) best->f[i] = F[(size_t)w * 9 + i];
+            best->matches_count = top;
+            best->best_error = s_winner_err;
+            best->valid = 1;
+            best->err_known = errors ? (s_exact ? 2u : 1u) : 0u;
+        }
+    }
+}
+
 // The live slots of a round's hypothesis buffer, in slot order (count, scan, scatter).  Depends on the hypotheses only,
 // so the device loops run it on the GENERATOR's stream right behind the generation - off the scoring chain.
 // scratch: ceil(H / 1024) words.
@@ -815,8 +994,8 @@ static void launch_ransac_live(const double *F, uint32_t H, uint32_t *live, uint
 // live_ready: the live list was already built (launch_ransac_live)
 static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, const float4 *matches_f32,
                                       uint32_t N, double t, uint32_t *live, uint32_t *n_live, uint32_t *tied,
-                                      const uint32_t *coord_max, bool live_ready, uint32_t min_count, RansacBest *best,
-                                      uint32_t *out_count, double *out_err_sum, hipStream_t s)
+                                      const uint32_t *coord_max, bool live_ready, bool approx_sums, uint32_t min_count,
+                                      RansacBest *best, uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
     const uint4 *m4 = reinterpret_cast<const uint4 *>(matches);
     (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
@@ -827,8 +1006,11 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
                        (const uint32_t *)n_live, min_count, (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum);
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
-    hipLaunchKernelGGL(ransac_tied_sum_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied,
-                       (const uint32_t *)out_count, (const uint32_t *)live, (const uint32_t *)n_live, best, out_err_sum);
+    if (approx_sums) // the device loops: parallel sums now, the ordered fold inside ransac_pick_best_approx_kernel where it decides
+        hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied, best, out_err_sum);
+    else
+        hipLaunchKernelGGL(ransac_tied_sum_kernel, dim3(16), dim3(1024), 0, s, F, m4, N, t, (const uint32_t *)tied,
+                           (const uint32_t *)out_count, (const uint32_t *)live, (const uint32_t *)n_live, best, out_err_sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1299,28 +1481,139 @@ __global__ __launch_bounds__(64) void ransac_perspective_root_kernel(const Persp
     for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = (ok || queued) ? f[i] : nan;
 }
 
-// The queued roots: least_squares in full (lm::levenberg_marquardt, the same code the host refit runs), then the
-// same acceptance tail.  One thread per queued root; the slot's first seven doubles hold the start parameters.
+// The queued roots: least_squares in full, then the same acceptance tail.  One WAVE per queued root (a persistent
+// grid strides over the queue).  A scalar thread running lm::levenberg_marquardt<7> spends ~12 000 dependent cycles per
+// iteration, and the kernel lasted as long as the round's longest loop (hundreds of iterations: ~1 ms, which made the
+// generator the critical path of the rounds).  Here everything that loop computes element by element - the 7
+// residuals, the 49 Jacobian entries, the 49 entries of J'J, the 7 entries of J'r - is computed by one lane per
+// element, with lm's own functions (same operations, same order: the values are the scalar loop's), and made
+// wave-uniform through LDS; the short serial parts (the 7x7 LU, norms, control flow) run redundantly in every lane on
+// uniform values.  J'J is kept (in LDS) while steps are rejected (J does not change then).  ~1 500 cycles per iteration.
 __global__ __launch_bounds__(64) void ransac_perspective_lm_kernel(const PerspPencil *__restrict__ pencils, double t,
                                                                     double *__restrict__ F, const uint32_t *__restrict__ queue)
 {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= queue[0]) return;
-    const uint32_t g = queue[1u + i];
-    const PerspPencil &pc = pencils[g / 3u];
-    uint4 sm[7];
-    lm::Obs obs[7];
-    double q[7], f[9];
+    __shared__ double sJ[49], sA[49], sV[8];
+    const uint32_t lane = threadIdx.x, n_queued = queue[0];
+    const int k = lane < 49u ? (int)(lane / 7u) : 6, e = lane < 49u ? (int)(lane % 7u) : 6; // this lane's observation / parameter
+    for (uint32_t item = blockIdx.x; item < n_queued; item += gridDim.x) {
+        const uint32_t g = queue[1u + item];
+        const PerspPencil &pc = pencils[g / 3u];
+        uint4 sm[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        sm[k] = pc.sm[k];
-        obs[k] = lm::make_obs(sm[k].x, sm[k].y, sm[k].z, sm[k].w);
-        q[k] = F[(size_t)g * 9 + k];
+        for (int kk = 0; kk < 7; kk++) sm[kk] = pc.sm[kk];
+        const uint4 mine = pc.sm[k];
+        const lm::Obs ob = lm::make_obs(mine.x, mine.y, mine.z, mine.w);
+        double q[7], r[7], gv[7], M[9];
+#pragma unroll
+        for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
+        __syncthreads(); // (the previous item's LDS reads are done)
+
+        // r = residuals at `at` (lane (k, 0) computes r_k), uniform in every lane afterwards
+        const auto evaluate = [&](const double (&at)[7], double (&into)[7]) {
+            lm::matrix_of(at, M);
+            const double rk = lm::residual_of(M, ob);
+            __syncthreads();
+            if (lane < 49u && e == 0) sV[k] = rk;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 7; j++) into[j] = sV[j];
+        };
+        // J at `at` -> sJ (lane (k, e) computes J[k][e]); g = J'res (lane j computes g_j: long_dot's order for n = 7,
+        // 0 + J_0j res_0 + J_1j res_1 + ...), uniform; AJ = J'J (lane (i, j): the same serial order), uniform
+        const auto linearise = [&](const double (&at)[7], const double (&res)[7]) {
+            lm::matrix_of(at, M);
+            const double c = lm::gradient_terms(M, ob);
+            const double jke = lm::gradient_element(M, ob, c, e);
+            __syncthreads();
+            if (lane < 49u) sJ[k * 7 + e] = jke;
+            __syncthreads();
+            double gj = 0.0, a = 0.0;
+            if (lane < 49u) {
+#pragma unroll
+                for (int kk = 0; kk < 7; kk++) a += sJ[kk * 7 + k] * sJ[kk * 7 + e]; // (k, e) = (row, column) of J'J here
+            }
+            if (lane < 7u) {
+#pragma unroll
+                for (int kk = 0; kk < 7; kk++) gj += sJ[kk * 7 + (int)lane] * res[kk];
+            }
+            if (lane < 49u) sA[lane] = a;
+            if (lane < 7u) sV[lane] = gj;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 7; j++) gv[j] = sV[j]; // (J'J stays in sA until the next linearise)
+        };
+        const auto largest = [](const double (&v)[7]) {
+            double m = v[0];
+#pragma unroll
+            for (int j = 1; j < 7; j++)
+                if (m < v[j]) m = v[j];
+            return m;
+        };
+        const auto norm7 = [](const double (&v)[7]) { return sqrt(lm::long_dot(v, 1, v, 1, 7)); };
+
+        // ---- least_squares (:515-621), statement for statement as lm::levenberg_marquardt<7>
+        int status = 0; // 0 = running, 1 = Ok, 2 = Err
+        evaluate(q, r);
+        linearise(q, r);
+        if (fabs(largest(gv)) <= 1e-12) status = 1;
+        double mu = 0.0, nu = 2.0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const double djj = sA[j * 7 + j];
+            if (j == 0 || djj >= mu) mu = djj;
+        }
+        mu *= 1e-3;
+        for (int iteration = 0; status == 0 && iteration < 1000; iteration++) {
+            double A[49], step[7];
+#pragma unroll
+            for (int m = 0; m < 49; m++) A[m] = sA[m];
+#pragma unroll
+            for (int i = 0; i < 7; i++) A[i * 7 + i] += mu;
+#pragma unroll
+            for (int j = 0; j < 7; j++) step[j] = gv[j];
+            if (!lm::solve7(A, step)) {
+                status = 2;
+                break;
+            }
+            if (norm7(step) <= 1e-12 * (norm7(q) + 1e-12)) {
+                status = 1;
+                break;
+            }
+            double trial[7], damped[7], r_new[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) trial[j] = q[j] + step[j];
+            evaluate(trial, r_new);
+            const double before = lm::long_dot(r, 1, r, 1, 7);
+            const double after = lm::long_dot(r_new, 1, r_new, 1, 7);
+#pragma unroll
+            for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + gv[j];
+            const double rho = (before - after) / lm::long_dot(step, 1, damped, 1, 7);
+            if (rho > 0.0) {
+                const bool converged = sqrt(before) - sqrt(after) < 0.0 * sqrt(before);
+#pragma unroll
+                for (int j = 0; j < 7; j++) {
+                    r[j] = r_new[j];
+                    q[j] = trial[j];
+                }
+                linearise(q, r);
+                if (converged || fabs(largest(gv)) <= 1e-12) {
+                    status = 1;
+                    break;
+                }
+                const double w = 2.0 * rho - 1.0, shrink = 1.0 - w * w * w;
+                mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
+                nu = 2.0;
+            } else {
+                mu *= nu;
+                nu *= 2.0;
+            }
+            if (sqrt(lm::long_dot(r, 1, r, 1, 7)) <= 1e-12) status = 1;
+        }
+        double f[9];
+        const bool ok = status == 1 && perspective_root_accept(q, sm, t, f);
+        const double nan = __builtin_nan("");
+        if (lane < 9u) F[(size_t)g * 9 + lane] = ok ? f[lane] : nan;
     }
-    const bool ok = lm::levenberg_marquardt7(q, obs) && perspective_root_accept(q, sm, t, f);
-    const double nan = __builtin_nan("");
-#pragma unroll
-    for (int k = 0; k < 9; k++) F[(size_t)g * 9 + k] = ok ? f[k] : nan;
 }
 
 // queue: 1 + 3 H words
@@ -1333,8 +1626,8 @@ static void launch_generate_perspective(const uint4 *m4, uint32_t limit, double 
                        pencils);
     hipLaunchKernelGGL(ransac_perspective_root_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, H, t,
                        d_F, queue);
-    // sized for the worst case (every root queued); blocks beyond the count return at once
-    hipLaunchKernelGGL(ransac_perspective_lm_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, t, d_F,
+    // a persistent grid of waves strides over the queue (one wave per queued root)
+    hipLaunchKernelGGL(ransac_perspective_lm_kernel, dim3(std::min<uint32_t>(3 * H, 4096u)), dim3(64), 0, s, (const PerspPencil *)pencils, t, d_F,
                        (const uint32_t *)queue);
 }
 
@@ -1524,7 +1817,7 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     CVHIP_TRY_HIP(mem.alloc(&d_mf, std::max(N, 1u)));
     hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
                        d_live + H + 3 + TIED_CAP, d_mf);
-    launch_ransac_score_round(d_F, H, d_m, d_mf, N, t, d_live, d_live + H, d_live + H + 1, d_live + H + 3 + TIED_CAP, false, 0u, d_best,
+    launch_ransac_score_round(d_F, H, d_m, d_mf, N, t, d_live, d_live + H, d_live + H + 1, d_live + H + 3 + TIED_CAP, false, false, 0u, d_best,
                               d_cnt, d_err, s);
     CVHIP_TRY_HIP(hipGetLastError());
     CVHIP_TRY_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)H * sizeof(uint32_t), dev_ptr(out_count) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -1592,9 +1885,9 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
                            std::min(N, TOP_INLIERS), RANSAC_T, (unsigned long long)seed, round, CHECK_INTERVAL,
                            (const uint32_t *)nullptr, d_F);
         launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, d_mf, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL,
-                                  d_live + CHECK_INTERVAL + 1, d_live + CHECK_INTERVAL + 3 + TIED_CAP, false, RANSAC_D + RANSAC_N, d_best,
+                                  d_live + CHECK_INTERVAL + 1, d_live + CHECK_INTERVAL + 3 + TIED_CAP, false, true, RANSAC_D + RANSAC_N, d_best,
                                   d_cnt, d_err, s);
-        hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, d_F, d_cnt, d_err, CHECK_INTERVAL,
+        hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, d_F, m4, N, RANSAC_T, (const uint32_t *)d_cnt, d_err,
                            RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
@@ -1708,9 +2001,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
         uint32_t *lv = d_live + (size_t)b * live_words;
-        launch_ransac_score_round(F_round, H, d_m, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, min_count, d_best, d_cnt, d_err, s);
-        hipLaunchKernelGGL(ransac_pick_best_kernel, dim3(1), dim3(1024), 0, s, F_round, d_cnt, d_err, H, min_count,
-                           (const uint32_t *)d_tied, d_best);
+        launch_ransac_score_round(F_round, H, d_m, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err, s);
+        hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)d_cnt, d_err,
+                           min_count, (const uint32_t *)d_tied, d_best);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(scored[b], s);
         if (!may_exit_early && !g_listener.wants_counts() && round + 1 < rounds) {
