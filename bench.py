@@ -333,7 +333,7 @@ def main():
         band_mode = pc.set_row_band(rank, world)   # independent bands + halo, one final gather ...
         if comm is not None:
             if band_mode:
-                final_gather = lambda cells, nbytes, n, d: pc.gather_bands_rccl(comm, 0)  # noqa: E731
+                final_gather = lambda cells, nbytes, n, d: pc.gather_bands_rccl(comm, 0) if d == 0 else None  # noqa: E731 (both planes in one call)
             else:
                 pc.set_row_shard_rccl(comm)        # ... or, for non-row-local geometry, an all-gather per sharded pass
         else:
@@ -362,7 +362,8 @@ def main():
                 l0_events.append((e0, e1))
         if final_gather is not None:  # the single RCCL gather: forward bands of the full-resolution level
             g = pc.level_grid(correlation.CorrelationDirection.Forward)
-            final_gather(g["cells"], g["rows_per_shard"] * g["lw"] * 8, world, 0)
+            final_gather(g["cells"], g["rows_per_shard"] * g["lw"] * 4, world, 0)   # match plane
+            final_gather(g["scores"], g["rows_per_shard"] * g["lw"] * 4, world, 2)  # score plane
         pc.complete(out_xy=out_xy, out_corr=out_corr)
 
     def fence():

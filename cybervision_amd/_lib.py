@@ -55,7 +55,7 @@ SIGNATURES = {
     "cvhip_rccl_gather": (C.c_int, [_vp, _vp, C.c_uint64, _u32]),
     "cvhip_ctx_set_row_shard_rccl": (C.c_int, [_vp, _vp]),
     "cvhip_ctx_gather_bands_rccl": (C.c_int, [_vp, _vp, C.c_int]),
-    "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32),
+    "cvhip_ctx_level_grid": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_u32),
                                        C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "cvhip_ctx_set_profiling": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cvhip_ctx_get_profile": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(C.c_double), C.POINTER(C.c_uint64),

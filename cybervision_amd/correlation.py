@@ -271,11 +271,13 @@ class PointCorrelations:
         return True
 
     def level_grid(self, direction: CorrelationDirection):
-        cells = C.c_void_p()
+        """-> cells / scores: device pointers of the level grid's two planes (u32 match words, f32 scores; 4 bytes per
+        level pixel each), lw, lh, this shard's rows, rows_per_shard."""
+        cells, scores = C.c_void_p(), C.c_void_p()
         lw, lh, r0, r1, rps = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        _lib.check(_lib.lib().cvhip_ctx_level_grid(self._h, int(direction), C.byref(cells), C.byref(lw), C.byref(lh),
+        _lib.check(_lib.lib().cvhip_ctx_level_grid(self._h, int(direction), C.byref(cells), C.byref(scores), C.byref(lw), C.byref(lh),
                                                    C.byref(r0), C.byref(r1), C.byref(rps)), "cvhip_ctx_level_grid")
-        return {"cells": cells.value, "lw": lw.value, "lh": lh.value, "row0": r0.value, "row1": r1.value,
+        return {"cells": cells.value, "scores": scores.value, "lw": lw.value, "lh": lh.value, "row0": r0.value, "row1": r1.value,
                 "rows_per_shard": rps.value}
 
     def close(self):

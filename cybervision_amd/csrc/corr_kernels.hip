@@ -379,7 +379,7 @@ __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x,
 // clamping included — so the neighbour statistics are computed once and shared; each pixel then applies
 // its own validity tests and corridor bounds.  (Pixels of one block on different corridor axes, possible
 // only for perspective geometry, each get their own axis' statistics.)
-__device__ __forceinline__ void search_range_body(const CorrParams &p, const uint2 *__restrict__ prev,
+__device__ __forceinline__ void search_range_body(const CorrParams &p, const uint32_t *__restrict__ prev,
                                                   uint32_t *__restrict__ range, int mode)
 {
     // chain path: raw cells of the tile's window (+ slack for the predicated row reads);
@@ -421,7 +421,7 @@ __device__ __forceinline__ void search_range_body(const CorrParams &p, const uin
         const uint32_t r = u / SRF_W, c = u - r * SRF_W;
         const int gx = tile_bx0 - SRF_LEFT + (int)c, gy = tile_by0 - SRF_LEFT + (int)r;
         const bool in = u < (uint32_t)(SRF_H * SRF_W) && gx >= 0 && gy >= 0 && (uint32_t)gx < p.pw && (uint32_t)gy < p.ph;
-        return in ? prev[(size_t)gy * p.pw + (uint32_t)gx].x : CELL_NONE;
+        return in ? prev[(size_t)gy * p.pw + (uint32_t)gx] : CELL_NONE;
     };
     uint32_t early[SRF_PER_THREAD] = {};
     if (quick && sums_ok) {
@@ -528,7 +528,7 @@ __device__ __forceinline__ void search_range_body(const CorrParams &p, const uin
         if (staged) {
             for (uint32_t u = threadIdx.x; u < tw * th; u += 256) {
                 const uint32_t r = u / tw, c = u - r * tw;
-                cells[r * SR_TILE_W + c] = prev[(size_t)(ty0 + r) * p.pw + (tx0 + c)].x;
+                cells[r * SR_TILE_W + c] = prev[(size_t)(ty0 + r) * p.pw + (tx0 + c)];
             }
         }
         __syncthreads();
@@ -543,7 +543,7 @@ __device__ __forceinline__ void search_range_body(const CorrParams &p, const uin
         const uint32_t ash = a ? 16u : 0u;
         const uint32_t up = p.pk - p.k; // corridor_pos = coordinate << up, an integer
         auto cell_at = [&](uint32_t xx, uint32_t yy) -> uint32_t {
-            return staged ? cells[(yy - ty0) * SR_TILE_W + (xx - tx0)] : prev[(size_t)yy * p.pw + xx].x;
+            return staged ? cells[(yy - ty0) * SR_TILE_W + (xx - tx0)] : prev[(size_t)yy * p.pw + xx];
         };
         unsigned long long isum = 0;
         uint32_t neighbor_count = 0;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
                                                       const uint2 *__restrict__ stats1,
                                                       const uint2 *__restrict__ stats2,
                                                       const uint32_t *__restrict__ range,
-                                                      uint2 *__restrict__ out,
+                                                      uint32_t *__restrict__ out, float *__restrict__ out_score,
                                                       unsigned long long *__restrict__ cand_counter)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -826,7 +826,10 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
             }
         }
     }
-    if (in_image) out[(size_t)y * p.w1 + x] = make_uint2(best_xy, __float_as_uint(best_corr));
+    if (in_image) {
+        out[(size_t)y * p.w1 + x] = best_xy;
+        out_score[(size_t)y * p.w1 + x] = best_corr;
+    }
     if (cand_counter) {
         // wave-level sum, one atomic per wave
         uint32_t v = evaluated;
@@ -837,12 +840,12 @@ __global__ __launch_bounds__(256) void search_kernel(CorrParams p, const uint8_t
 }
 
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                   const uint2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
-                   hipStream_t s)
+                   const uint2 *stats2, const uint32_t *range, uint32_t *out, float *out_score,
+                   unsigned long long *cand_counter, hipStream_t s)
 {
     if (p.row1 <= p.row0) return;
     dim3 grid((p.w1 + 63) / 64, (p.row1 - p.row0 + 3) / 4);
-    hipLaunchKernelGGL(search_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, stats2, range, out, cand_counter);
+    hipLaunchKernelGGL(search_kernel, grid, dim3(256), 0, s, p, img1, img2, stats1, stats2, range, out, out_score, cand_counter);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -969,6 +972,15 @@ __device__ __forceinline__ bool pixel_setup(const CorrParams &p, uint32_t x, uin
     return ps.r0 < ps.r1;
 }
 
+// a settled pixel's result: the match plane always, the score plane only where the pass's scores are the reference's
+// (CorrParams::need_scores - the planes of other passes are never read, complete() reports NaN for them)
+__device__ __forceinline__ void store_cell(const CorrParams &p, uint32_t *__restrict__ out, float *__restrict__ out_score, size_t i,
+                                           uint2 cell)
+{
+    out[i] = cell.x;
+    if (p.need_scores) out_score[i] = __uint_as_float(cell.y);
+}
+
 // ---- kernel A: filter ---------------------------------------------------------------------------------
 // One tile: `width` (<= 64) pixels from x0 in the four rows of row tile `ytile`.
 // Returns (uniformly for the workgroup) whether the tile holds whole-corridor pixels; only then are its contender
@@ -978,7 +990,8 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
                                                     const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
                                                     const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2,
                                                     const uint32_t *__restrict__ range,
-                                                    unsigned long long *__restrict__ contenders, uint2 *__restrict__ out,
+                                                    unsigned long long *__restrict__ contenders, uint32_t *__restrict__ out,
+                                                    float *__restrict__ out_score,
                                                     unsigned long long *__restrict__ counters, int only_fallback,
                                                     PixTile tl, WorkList whole_list, uint8_t *__restrict__ tile,
                                                     uint32_t lds_bytes)
@@ -1310,7 +1323,7 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
     const int any_whole = __syncthreads_or(whole ? 1 : 0); // every thread of the workgroup is still here
     if (mine) {
         if (any_whole) contenders[(size_t)y * p.w1 + x] = word;
-        if (!whole) out[(size_t)y * p.w1 + x] = cell;
+        if (!whole) store_cell(p, out, out_score, (size_t)y * p.w1 + x, cell);
     }
     if (counters) {
         uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = whole;
@@ -1339,7 +1352,7 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(SearchJob ja, Se
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     const SearchJob &j = this_job();
     const TileId tid = xcd_tile();
-    (void)search2_filter_tile<COUNT>(j.p, j.img1, j.img2, j.stats1, j.stats1, j.stats2, j.range, j.contenders, j.out,
+    (void)search2_filter_tile<COUNT>(j.p, j.img1, j.img2, j.stats1, j.stats1, j.stats2, j.range, j.contenders, j.out, j.out_score,
                                      j.counters, 0, PixTile{tid.x * 64u, j.p.row0 + tid.y * 4u, 64u, false}, j.whole,
                                      dyn_lds, lds_bytes);
 }
@@ -1460,7 +1473,8 @@ __global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void s
     const uint2 *__restrict__ const stats1 = j.stats1, *__restrict__ const istats1 = j.stats1, *__restrict__ const istats2 = j.stats2;
     const uint32_t *__restrict__ const range = j.range;
     unsigned long long *__restrict__ const contenders = j.contenders, *__restrict__ const counters = j.counters;
-    uint2 *__restrict__ const out = j.out;
+    uint32_t *__restrict__ const out = j.out;
+    float *__restrict__ const out_score = j.out_score;
     const WorkList declined = j.declined, whole_list = j.whole;
     constexpr bool WIDE = true;
 #include "box_body.inc"
@@ -1473,8 +1487,8 @@ template <bool COUNT, bool STEP, bool TR, bool WIDE>
 __global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void search3_box_single_kernel(
     CorrParams p, const uint8_t *__restrict__ img1, const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
     const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
-    unsigned long long *__restrict__ contenders, uint2 *__restrict__ out, unsigned long long *__restrict__ counters,
-    WorkList declined, WorkList whole_list)
+    unsigned long long *__restrict__ contenders, uint32_t *__restrict__ out, float *__restrict__ out_score,
+    unsigned long long *__restrict__ counters, WorkList declined, WorkList whole_list)
 {
 #include "box_body.inc"
 }
@@ -1484,8 +1498,8 @@ __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const ui
                                                    const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
                                                    const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
                                                    const unsigned long long *__restrict__ contenders,
-                                                   uint2 *__restrict__ out, unsigned long long *__restrict__ counters,
-                                                   PixTile tl)
+                                                   uint32_t *__restrict__ out, float *__restrict__ out_score,
+                                                   unsigned long long *__restrict__ counters, PixTile tl)
 {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t x, y;
@@ -1584,7 +1598,7 @@ __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const ui
         }
         if (have) cell = make_uint2(bx | (by << 16), __float_as_uint(bcorr));
     }
-    if (in_image && count == (uint32_t)CW_WHOLE) out[(size_t)y * p.w1 + x] = cell; // everything else was settled by the filter kernel
+    if (in_image && count == (uint32_t)CW_WHOLE) store_cell(p, out, out_score, (size_t)y * p.w1 + x, cell); // everything else was settled by the filter kernel
     if (counters) {
         uint32_t v0 = evaluated, v1 = exact_evals;
 #pragma unroll
@@ -1613,14 +1627,14 @@ __global__ __launch_bounds__(256, 2) void search3_fallback_kernel(SearchJob ja, 
     for (uint32_t t = blockIdx.x; t < nd; t += gridDim.x) {
         const PixTile tl = tile_of_entry(j.declined.items[t], p.row0);
         const bool any_whole = search2_filter_tile<COUNT>(p, j.img1, j.img2, j.stats1, j.stats1, j.stats2, j.range, j.contenders,
-                                                          j.out, j.counters, 1, tl, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
+                                                          j.out, j.out_score, j.counters, 1, tl, WorkList{nullptr, nullptr}, dyn_lds, lds_bytes);
         __syncthreads(); // the tile's LDS is reused by the next one
         if (!skip_exact && any_whole)
-            search2_exact_tile(p, j.img1, j.img2, j.stats1, j.stats2, j.range, j.contenders, j.out, j.counters, tl);
+            search2_exact_tile(p, j.img1, j.img2, j.stats1, j.stats2, j.range, j.contenders, j.out, j.out_score, j.counters, tl);
     }
     if (skip_exact) return;
     for (uint32_t t = blockIdx.x; t < nw; t += gridDim.x)
-        search2_exact_tile(p, j.img1, j.img2, j.stats1, j.stats2, j.range, j.contenders, j.out, j.counters,
+        search2_exact_tile(p, j.img1, j.img2, j.stats1, j.stats2, j.range, j.contenders, j.out, j.out_score, j.counters,
                            tile_of_entry(j.whole.items[t], p.row0));
 }
 
@@ -1693,8 +1707,8 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
                 hipLaunchKernelGGL(kernel, dim3(gx, gy, 1), dim3(256),
                                    search3_step_lds_bytes(jobs[i].p.box_pd, jobs[i].p.box_sh, jobs[i].p.box_wide != 0), s, jobs[i].p,
                                    jobs[i].img1, jobs[i].img2, jobs[i].stats1, jobs[i].stats1, jobs[i].stats2,
-                                   (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out, jobs[i].counters, jobs[i].declined,
-                                   jobs[i].whole);
+                                   (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out, jobs[i].out_score, jobs[i].counters,
+                                   jobs[i].declined, jobs[i].whole);
     };
     const bool wide = jobs[0].p.box_wide != 0;
     const int variant = (jobs[0].counters ? 4 : 0) | (stepped_lines ? 2 : 0) | (transposed ? 1 : 0);
@@ -1726,9 +1740,9 @@ size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h)
 // ---------------------------------------------------------------------------------------------
 constexpr int CC_ROWS = 1; // rows per thread (more than one only lengthens the chain of dependent round trips)
 
-struct CrossJob { // one direction's cross-check: `own` is filtered against `other`
-    uint2 *own;
-    const uint2 *other;
+struct CrossJob { // one direction's cross-check: `own` is filtered against `other` (match planes)
+    uint32_t *own;
+    const uint32_t *other;
     uint32_t ow, oh, rw, rh, row0; // oh = end of the row range handled, row0 its start
 };
 
@@ -1738,8 +1752,8 @@ struct CrossJob { // one direction's cross-check: `own` is filtered against `oth
 __global__ __launch_bounds__(256) void cross_check_kernel(CrossJob ja, CrossJob jb)
 {
     const CrossJob &job = blockIdx.z == 0 ? ja : jb;
-    uint2 *__restrict__ own = job.own;
-    const uint2 *__restrict__ other = job.other;
+    uint32_t *__restrict__ own = job.own;
+    const uint32_t *__restrict__ other = job.other;
     const uint32_t ow = job.ow, oh = job.oh, rw = job.rw, rh = job.rh, row0 = job.row0;
     // oh = end of the row range handled by this launch, row0 its start
     const TileId tid = xcd_tile();
@@ -1749,14 +1763,14 @@ __global__ __launch_bounds__(256) void cross_check_kernel(CrossJob ja, CrossJob 
     const uint32_t sa = CROSS_CHECK_SEARCH_AREA;
     uint32_t cell[CC_ROWS], probe[CC_ROWS];
 #pragma unroll
-    for (int j = 0; j < CC_ROWS; j++) cell[j] = y0 + j < oh ? own[(size_t)(y0 + j) * ow + x].x : CELL_NONE;
+    for (int j = 0; j < CC_ROWS; j++) cell[j] = y0 + j < oh ? own[(size_t)(y0 + j) * ow + x] : CELL_NONE;
     // The result is an existence test (mod.rs:613-623 returns true at the first hit), so the scan
     // order is free: probe the window centre first — a consistent pair of matches points straight
     // back — and fall back to the full row-major scan only when that fails.
 #pragma unroll
     for (int j = 0; j < CC_ROWS; j++) {
         const uint32_t mx = cell[j] & 0xFFFFu, my = cell[j] >> 16;
-        probe[j] = (cell[j] != CELL_NONE && mx < rw && my < rh) ? other[(size_t)my * rw + mx].x : CELL_NONE;
+        probe[j] = (cell[j] != CELL_NONE && mx < rw && my < rh) ? other[(size_t)my * rw + mx] : CELL_NONE;
     }
 #pragma unroll
     for (int j = 0; j < CC_ROWS; j++) {
@@ -1780,20 +1794,20 @@ __global__ __launch_bounds__(256) void cross_check_kernel(CrossJob ja, CrossJob 
             uint32_t cellsr[CCB][CCW];
 #pragma unroll
             for (uint32_t b = 0; b < CCB; b++) {
-                const uint2 *row = other + (size_t)min(sy + b, max_y - 1u) * rw;
+                const uint32_t *row = other + (size_t)min(sy + b, max_y - 1u) * rw;
 #pragma unroll
-                for (uint32_t t = 0; t < CCW; t++) cellsr[b][t] = (sy + b < max_y && min_x + t < max_x) ? row[min_x + t].x : CELL_NONE;
+                for (uint32_t t = 0; t < CCW; t++) cellsr[b][t] = (sy + b < max_y && min_x + t < max_x) ? row[min_x + t] : CELL_NONE;
             }
 #pragma unroll
             for (uint32_t b = 0; b < CCB; b++)
 #pragma unroll
                 for (uint32_t t = 0; t < CCW; t++) found = found || points_back(cellsr[b][t]);
         }
-        if (!found) own[(size_t)y * ow + x] = make_uint2(CELL_NONE, 0x7FC00000u);
+        if (!found) own[(size_t)y * ow + x] = CELL_NONE; // (the score of a None cell is never looked at)
     }
 }
 
-void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
+void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s)
 {
     row1 = min(row1, oh);
@@ -1804,7 +1818,7 @@ void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh
 }
 
 // forward and reverse cross-check of a level in one launch
-void launch_cross_check_pair(uint2 *fwd, uint2 *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
+void launch_cross_check_pair(uint32_t *fwd, uint32_t *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
                              uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s)
 {
     f_row1 = f_row1 < fh ? f_row1 : fh;
@@ -1824,7 +1838,8 @@ void launch_cross_check_pair(uint2 *fwd, uint2 *rev, uint32_t fw, uint32_t fh, u
 // once at complete(): full-res cell (x << k, y << k) = level cell (x, y) with the match scaled
 // back by round(x2 / scale) = x2 << k.  All other full-res cells are None.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void expand_grid_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+__global__ __launch_bounds__(256) void expand_grid_kernel(const uint32_t *__restrict__ cells, const float *__restrict__ scores,
+                                                           uint32_t lw, uint32_t lh,
                                                            uint32_t k, uint32_t gw, uint32_t gh,
                                                            int32_t *__restrict__ out_xy, float *__restrict__ out_corr)
 {
@@ -1837,11 +1852,11 @@ __global__ __launch_bounds__(256) void expand_grid_kernel(const uint2 *__restric
     if ((gx & mask) == 0 && (gy & mask) == 0) {
         const uint32_t lx = gx >> k, ly = gy >> k;
         if (lx < lw && ly < lh) {
-            const uint2 c = cells[(size_t)ly * lw + lx];
-            if (c.x != CELL_NONE) {
-                ox = (int32_t)((c.x & 0xFFFFu) << k);
-                oy = (int32_t)((c.x >> 16) << k);
-                oc = __uint_as_float(c.y);
+            const uint32_t c = cells[(size_t)ly * lw + lx];
+            if (c != CELL_NONE) {
+                ox = (int32_t)((c & 0xFFFFu) << k);
+                oy = (int32_t)((c >> 16) << k);
+                if (scores) oc = scores[(size_t)ly * lw + lx];
             }
         }
     }
@@ -1850,11 +1865,11 @@ __global__ __launch_bounds__(256) void expand_grid_kernel(const uint2 *__restric
     if (out_corr) out_corr[o] = oc;
 }
 
-void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+void launch_expand_grid(const uint32_t *cells, const float *scores, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                         int32_t *out_xy, float *out_corr, hipStream_t s)
 {
     dim3 grid((gw + 63) / 64, (gh + 3) / 4);
-    hipLaunchKernelGGL(expand_grid_kernel, grid, dim3(256), 0, s, cells, lw, lh, k, gw, gh, out_xy, out_corr);
+    hipLaunchKernelGGL(expand_grid_kernel, grid, dim3(256), 0, s, cells, scores, lw, lh, k, gw, gh, out_xy, out_corr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1863,7 +1878,7 @@ void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k
 // scan of the block counts, then an ordered write of (x, y, sqrt(dx^2 + dy^2)) per track.
 // dx^2 + dy^2 is an exact integer in f64; sqrt is the correctly rounded f64 square root.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tri_count_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+__global__ __launch_bounds__(256) void tri_count_kernel(const uint32_t *__restrict__ cells, uint32_t lw, uint32_t lh,
                                                          uint32_t k, uint32_t gw, uint32_t gh,
                                                          uint32_t *__restrict__ block_counts)
 {
@@ -1907,7 +1922,7 @@ __global__ __launch_bounds__(1024) void tri_scan_kernel(uint32_t *__restrict__ d
     if (threadIdx.x == 0) *total = carry_s;
 }
 
-__global__ __launch_bounds__(256) void tri_write_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+__global__ __launch_bounds__(256) void tri_write_kernel(const uint32_t *__restrict__ cells, uint32_t lw, uint32_t lh,
                                                          uint32_t k, uint32_t gw, uint32_t gh,
                                                          const uint32_t *__restrict__ block_offsets,
                                                          unsigned long long cap, double *__restrict__ out_points3d,
@@ -1939,7 +1954,7 @@ __global__ __launch_bounds__(256) void tri_write_kernel(const uint2 *__restrict_
     }
 }
 
-void launch_triangulate_affine(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+void launch_triangulate_affine(const uint32_t *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                                uint32_t *block_counts, uint32_t *total, double *out_points3d, uint32_t *out_p2,
                                unsigned long long cap, hipStream_t s)
 {

@@ -62,6 +62,7 @@ static void free_buffer_set(CtxBuffers &b)
     for (int d = 0; d < 2; d++) {
         for (int i = 0; i < 2; i++)
             if (b.cells[d][i]) (void)hipFree(b.cells[d][i]);
+        if (b.scores[d]) (void)hipFree(b.scores[d]);
         if (b.img[d]) (void)hipFree(b.img[d]);
         if (b.istats[d]) (void)hipFree(b.istats[d]);
     }
@@ -89,6 +90,9 @@ static void release_ctx_buffers(cvhip_ctx *c, bool park)
             complete = complete && b.cells[d][i];
             c->dir[d].cells[i] = nullptr;
         }
+        b.scores[d] = c->dir[d].scores;
+        complete = complete && b.scores[d];
+        c->dir[d].scores = nullptr;
         b.img[d] = c->img[d];
         b.istats[d] = c->istats[d];
         complete = complete && b.img[d] && b.istats[d];
@@ -277,6 +281,7 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
     j.range = dir == 0 ? c->range : c->range_rev;
     j.contenders = dir == 0 ? c->contenders : c->contenders_rev;
     j.out = ds.cells[plan.next];
+    j.out_score = ds.scores;
     j.counters = c->count_candidates ? c->d_cand : nullptr;
     // the search kernel -> one persistent fallback kernel over the tiles the box filter declined and the tiles with
     // whole-corridor pixels (work lists filled by the producers)
@@ -370,7 +375,7 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
         if (pl.kind == PassPlan::EXACT_V1) {
             CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                 launch_search(p, pl.job.img1, pl.job.img2, pl.job.stats1, pl.job.stats2, pl.job.range, pl.job.out,
-                              pl.job.counters, s);
+                              pl.job.out_score, pl.job.counters, s);
             }, s));
         } else if (!(p.debug & 2)) {
             // both directions' work-list counts are zeroed once per level by the statistics kernel of
@@ -398,6 +403,7 @@ static void commit_pass(cvhip_ctx *c, const PassPlan &plan)
     DirState &ds = c->dir[plan.dir];
     ds.cur = plan.next;
     ds.valid = true;
+    ds.scores_valid = plan.job.p.need_scores != 0 || plan.kind == PassPlan::EXACT_V1; // (the plain kernel scores every pixel)
     ds.lw = plan.lw;
     ds.lh = plan.lh;
     ds.k = plan.k;
@@ -632,6 +638,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         if (b.w1 != w1 || b.h1 != h1 || b.w2 != w2 || b.h2 != h2) continue;
         for (int d = 0; d < 2; d++) {
             for (int k = 0; k < 2; k++) c->dir[d].cells[k] = b.cells[d][k];
+            c->dir[d].scores = b.scores[d];
             c->img[d] = b.img[d];
             c->istats[d] = b.istats[d];
         }
@@ -646,7 +653,8 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     }
     for (int d = 0; d < 2 && e == hipSuccess && !reused; d++) {
         const size_t ge = grid_elems(c->dir[d].gw, c->dir[d].gh);
-        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint2));
+        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->dir[d].scores, ge * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
         if (e == hipSuccess) e = hipMalloc(&c->istats[d], c->max_px * sizeof(uint2));
     }
@@ -772,10 +780,14 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     const bool fence_hook = sharded && !ctx->gather_on_stream && ctx->dev->d.owns_stream;
     const auto run_gather = [&](int dir) -> int {
         const DirState &ds = ctx->dir[dir];
-        const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint2);
+        // (only the match plane travels between passes: nothing reads another rank's scores before the final gather)
+        const uint64_t shard_bytes = (uint64_t)((ds.lh + den - 1) / den) * ds.lw * sizeof(uint32_t);
         if (fence_hook) CVHIP_TRY_HIP(hipStreamSynchronize(s));
         if (ctx->gather(ctx->gather_user, ds.cells[ds.cur], shard_bytes, den, dir) != 0)
             return fail(CVHIP_ERR_DEVICE, dir == 0 ? "all-gather hook failed (forward grid)" : "all-gather hook failed (reverse grid)");
+        // the forward SCORES of the last level are the only ones complete() reports: every rank gets the other bands' too
+        if (dir == 0 && k == 0 && ctx->gather(ctx->gather_user, ds.scores, shard_bytes, den, 2) != 0)
+            return fail(CVHIP_ERR_DEVICE, "all-gather hook failed (forward scores)");
         if (fence_hook) CVHIP_TRY_HIP(hipDeviceSynchronize());
         return CVHIP_OK;
     };
@@ -874,7 +886,10 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
     }
     if (ds.valid) {
         (void)timed(ctx, cvhip_ctx::K_EXPAND,
-                    [&] { launch_expand_grid(ds.cells[ds.cur], ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy, d_corr, s); });
+                    [&] {
+                        launch_expand_grid(ds.cells[ds.cur], ds.scores_valid ? ds.scores : nullptr, ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy,
+                                           d_corr, s);
+                    });
     } else { // nothing computed: all None, like a fresh Grid (mod.rs:183-184)
         launch_fill_u32(reinterpret_cast<uint32_t *>(d_xy), 0xFFFFFFFFu, n * 2, s);
         if (d_corr) launch_fill_u32(reinterpret_cast<uint32_t *>(d_corr), 0x7FC00000u, n, s);
@@ -1063,7 +1078,7 @@ int cvhip_ctx_set_row_band(cvhip_ctx *ctx, uint32_t num, uint32_t den)
     return CVHIP_OK;
 }
 
-int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, uint32_t *lh, uint32_t *row0,
+int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, void **scores, uint32_t *lw, uint32_t *lh, uint32_t *row0,
                          uint32_t *row1, uint32_t *rows_per_shard)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
@@ -1075,6 +1090,7 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, ui
         CVHIP_TRY(flush_reverse_cross_check(ctx));
     }
     if (cells) *cells = ds.cells[ds.cur];
+    if (scores) *scores = ds.scores;
     if (lw) *lw = ds.lw;
     if (lh) *lh = ds.lh;
     uint32_t r0, r1;

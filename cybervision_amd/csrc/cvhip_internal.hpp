@@ -37,7 +37,9 @@ constexpr int KERNEL_POINT_COUNT = 121;
 constexpr int NEIGHBOR_DISTANCE = 10;
 constexpr int CROSS_CHECK_SEARCH_AREA = 4;
 
-// Level-grid cell = uint2 {x | y << 16 in LEVEL coordinates (or CELL_NONE), f32 score bits}.
+// Level grids are two planes: the match plane, one u32 per level pixel = x | y << 16 in LEVEL coordinates (or
+// CELL_NONE) - all that the search range, the cross-checks and the dense consumers read - and the score plane (f32),
+// which only complete() reads.
 constexpr uint32_t CELL_NONE = 0xFFFFFFFFu;
 constexpr uint32_t RANGE_NONE = 0xFFFFFFFFu; // packed corridor range: start | end << 16, or None
 constexpr size_t IMG_PAD = 64;               // bytes readable past the end of every image buffer
@@ -92,54 +94,56 @@ struct SearchJob {
     CorrParams p;
     const uint8_t *img1, *img2; // searched / target level image
     const uint2 *stats1, *stats2; // their statistics words
-    const uint2 *prev;            // this direction's previous-level grid (search range)
+    const uint32_t *prev;         // this direction's previous-level match plane (search range)
     uint32_t *range;              // search interval per searched pixel
     unsigned long long *contenders;
-    uint2 *out;                   // this level's grid
+    uint32_t *out;                // this level's match plane
+    float *out_score;             // ... and score plane
     unsigned long long *counters; // device counters or nullptr
     WorkList declined, whole;
 };
 void launch_search_range(const SearchJob *jobs, int n, int mode, hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
-                   const uint2 *stats2, const uint32_t *range, uint2 *out, unsigned long long *cand_counter,
-                   hipStream_t s);
+                   const uint2 *stats2, const uint32_t *range, uint32_t *out, float *out_score,
+                   unsigned long long *cand_counter, hipStream_t s);
 void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s);
 void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s);
 void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, hipStream_t s);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
-void launch_cross_check(uint2 *own, const uint2 *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
+void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
-void launch_cross_check_pair(uint2 *fwd, uint2 *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
+void launch_cross_check_pair(uint32_t *fwd, uint32_t *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
                              uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s);
-void launch_expand_grid(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+// scores == nullptr: the level's scores were not computed (CorrParams::need_scores): NaN everywhere
+void launch_expand_grid(const uint32_t *cells, const float *scores, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                         int32_t *out_xy, float *out_corr, hipStream_t s);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 // tracks of the affine dense consumer; block_counts must hold ceil(gw*gh/256) u32, total is one u32
-void launch_triangulate_affine(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+void launch_triangulate_affine(const uint32_t *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                                uint32_t *block_counts, uint32_t *total, double *out_points3d, uint32_t *out_p2,
                                unsigned long long cap, hipStream_t s);
 
 // single-block exclusive scan of n u32 in place, total to *total
 void launch_scan_u32(uint32_t *data, uint32_t n, uint32_t *total, hipStream_t s);
 // Triangulation::extend_tracks on the forward grid (track_kernels.hip)
-void launch_extend_tracks_match(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+void launch_extend_tracks_match(const uint32_t *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                                 const int2 *track_p1, unsigned long long n_tracks, uint32_t radius, int2 *out_p2,
                                 uint8_t *removed, uint32_t *oob, hipStream_t s);
-void launch_extend_tracks_new(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+void launch_extend_tracks_new(const uint32_t *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                               const uint8_t *removed, uint32_t *block_counts, uint32_t *total, uint32_t *out_new_p1,
                               uint32_t *out_new_p2, unsigned long long cap, hipStream_t s);
 
 #ifdef __HIPCC__
 // the match stored for full-resolution cell (gx, gy), if any: level cell (gx >> k, gy >> k) when both are multiples
 // of 2^k (the scatter of mod.rs:311-316), scaled back by 2^k (mod.rs:459-462)
-__device__ __forceinline__ bool full_res_match(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh, uint32_t k,
+__device__ __forceinline__ bool full_res_match(const uint32_t *__restrict__ cells, uint32_t lw, uint32_t lh, uint32_t k,
                                                uint32_t gx, uint32_t gy, uint32_t &mx, uint32_t &my)
 {
     const uint32_t mask = (1u << k) - 1u;
     if ((gx & mask) || (gy & mask)) return false;
     const uint32_t lx = gx >> k, ly = gy >> k;
     if (lx >= lw || ly >= lh) return false;
-    const uint32_t c = cells[(size_t)ly * lw + lx].x;
+    const uint32_t c = cells[(size_t)ly * lw + lx];
     if (c == CELL_NONE) return false;
     mx = (c & 0xFFFFu) << k;
     my = (c >> 16) << k;
@@ -154,7 +158,8 @@ __device__ __forceinline__ bool full_res_match(const uint2 *__restrict__ cells, 
 // pairs of equally sized images: hipMalloc / hipFree of ~1 GB per pair cost more than a 2048^2 correlation itself).
 struct CtxBuffers {
     uint32_t w1 = 0, h1 = 0, w2 = 0, h2 = 0;
-    uint2 *cells[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t *cells[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float *scores[2] = {nullptr, nullptr};
     uint8_t *img[2] = {nullptr, nullptr};
     uint2 *istats[2] = {nullptr, nullptr};
     uint32_t *range = nullptr, *range_rev = nullptr;
@@ -277,7 +282,9 @@ struct DevAllocs {
 };
 
 struct DirState {
-    uint2 *cells[2] = {nullptr, nullptr}; // ping-pong compact level grids
+    uint32_t *cells[2] = {nullptr, nullptr}; // ping-pong compact match planes (the previous level's is read by the search range)
+    float *scores = nullptr;                 // score plane of the most recent level (nothing reads an older one)
+    bool scores_valid = false;               // ... which holds the reference's scores (CorrParams::need_scores)
     int cur = 0;        // index of the grid holding the most recent level
     bool valid = false; // a level has been computed
     uint32_t lw = 0, lh = 0, k = 0;

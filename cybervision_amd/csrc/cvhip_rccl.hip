@@ -201,13 +201,18 @@ int cvhip_ctx_gather_bands_rccl(cvhip_ctx *ctx, cvhip_rccl *comm, int root)
     if (ctx->dev != comm->dev) return fail(CVHIP_ERR_INVALID, "context and communicator belong to different device handles");
     if (ctx->shard_den != comm->world || ctx->shard_num != comm->rank)
         return fail(CVHIP_ERR_INVALID, "the context's shard is not the communicator's rank");
-    void *cells = nullptr;
+    void *cells = nullptr, *scores = nullptr;
     uint32_t lw = 0, lh = 0, rps = 0;
-    CVHIP_TRY(cvhip_ctx_level_grid(ctx, 0, &cells, &lw, &lh, nullptr, nullptr, &rps));
-    const uint64_t shard_bytes = (uint64_t)rps * lw * sizeof(uint2);
+    CVHIP_TRY(cvhip_ctx_level_grid(ctx, 0, &cells, &scores, &lw, &lh, nullptr, nullptr, &rps));
+    // the two planes of the forward grid: matches (u32) and scores (f32), 4 + 4 bytes per level pixel
+    const uint64_t shard_bytes = (uint64_t)rps * lw * sizeof(uint32_t);
     if (root >= (int)comm->world) return fail(CVHIP_ERR_INVALID, "root out of range");
-    if (root < 0) return cvhip_rccl_allgather(comm, cells, shard_bytes);
-    return cvhip_rccl_gather(comm, cells, shard_bytes, (uint32_t)root);
+    if (root < 0) {
+        CVHIP_TRY(cvhip_rccl_allgather(comm, cells, shard_bytes));
+        return cvhip_rccl_allgather(comm, scores, shard_bytes);
+    }
+    CVHIP_TRY(cvhip_rccl_gather(comm, cells, shard_bytes, (uint32_t)root));
+    return cvhip_rccl_gather(comm, scores, shard_bytes, (uint32_t)root);
 }
 
 } // extern "C"

@@ -12,7 +12,7 @@
 
 namespace cvhip {
 
-__global__ __launch_bounds__(256) void extend_tracks_match_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+__global__ __launch_bounds__(256) void extend_tracks_match_kernel(const uint32_t *__restrict__ cells, uint32_t lw, uint32_t lh,
                                                                    uint32_t k, uint32_t gw, uint32_t gh,
                                                                    const int2 *__restrict__ track_p1,
                                                                    unsigned long long n_tracks, uint32_t radius,
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void extend_tracks_match_kernel(const uint2 *_
     out_p2[t] = res;
 }
 
-__device__ __forceinline__ bool remaining_cell(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh, uint32_t k,
+__device__ __forceinline__ bool remaining_cell(const uint32_t *__restrict__ cells, uint32_t lw, uint32_t lh, uint32_t k,
                                                uint32_t gw, uint32_t gh, const uint8_t *__restrict__ removed, size_t i,
                                                uint32_t &gx, uint32_t &gy, uint32_t &mx, uint32_t &my)
 {
@@ -62,7 +62,7 @@ __device__ __forceinline__ bool remaining_cell(const uint2 *__restrict__ cells, 
     return full_res_match(cells, lw, lh, k, gx, gy, mx, my) && !removed[i];
 }
 
-__global__ __launch_bounds__(256) void extend_tracks_count_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+__global__ __launch_bounds__(256) void extend_tracks_count_kernel(const uint32_t *__restrict__ cells, uint32_t lw, uint32_t lh,
                                                                    uint32_t k, uint32_t gw, uint32_t gh,
                                                                    const uint8_t *__restrict__ removed,
                                                                    uint32_t *__restrict__ block_counts)
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void extend_tracks_count_kernel(const uint2 *_
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void extend_tracks_write_kernel(const uint2 *__restrict__ cells, uint32_t lw, uint32_t lh,
+__global__ __launch_bounds__(256) void extend_tracks_write_kernel(const uint32_t *__restrict__ cells, uint32_t lw, uint32_t lh,
                                                                    uint32_t k, uint32_t gw, uint32_t gh,
                                                                    const uint8_t *__restrict__ removed,
                                                                    const uint32_t *__restrict__ block_offsets,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void extend_tracks_write_kernel(const uint2 *_
     }
 }
 
-void launch_extend_tracks_match(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+void launch_extend_tracks_match(const uint32_t *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                                 const int2 *track_p1, unsigned long long n_tracks, uint32_t radius, int2 *out_p2,
                                 uint8_t *removed, uint32_t *oob, hipStream_t s)
 {
@@ -110,7 +110,7 @@ void launch_extend_tracks_match(const uint2 *cells, uint32_t lw, uint32_t lh, ui
                        gw, gh, track_p1, n_tracks, radius, out_p2, removed, oob);
 }
 
-void launch_extend_tracks_new(const uint2 *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
+void launch_extend_tracks_new(const uint32_t *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                               const uint8_t *removed, uint32_t *block_counts, uint32_t *total, uint32_t *out_new_p1,
                               uint32_t *out_new_p2, unsigned long long cap, hipStream_t s)
 {

@@ -49,6 +49,20 @@ def alias_bytes(ptr: int, nbytes: int, device: bool):
     return torch.from_numpy(np.ctypeslib.as_array(buf))
 
 
+CELL_BYTES = 4  # bytes per level pixel of EACH plane of a level grid (u32 match word / f32 score)
+
+
+def copy_rows(dst_grid, src_grid, r0: int, r1: int, scores: bool = True):
+    """Rows [r0, r1) of src_grid's planes -> the same rows of dst_grid (both from PointCorrelations.level_grid, on the
+    same GPU): what a gather of one band does.  scores=False: the match plane only."""
+    lw = src_grid["lw"]
+    nbytes = (r1 - r0) * lw * CELL_BYTES
+    if nbytes <= 0:
+        return
+    for key in ("cells", "scores") if scores else ("cells",):
+        alias_bytes(dst_grid[key] + r0 * lw * CELL_BYTES, nbytes, True).copy_(alias_bytes(src_grid[key] + r0 * lw * CELL_BYTES, nbytes, True))
+
+
 def make_allgather(rank: int, world: int, group=None, device: bool = True):
     """gather(cells_ptr, shard_bytes, n_shards, direction) for PointCorrelations.set_row_shard."""
     import torch.distributed as dist

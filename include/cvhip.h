@@ -125,10 +125,12 @@ int cvhip_ctx_set_async_readback(cvhip_ctx *ctx, int enable);
 int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr);
 
 /* All-gather hook for row sharding: called by cvhip_correlate_level after each sharded search
- * pass, on the calling thread.  `cells` is the device pointer of the level grid of direction
- * `dir`; shard r (0 <= r < n_shards) owns bytes [r*shard_bytes, (r+1)*shard_bytes).  The hook
+ * pass, on the calling thread.  `cells` is the device pointer of the level grid's match plane (4 bytes per level pixel)
+ * of direction `dir`; shard r (0 <= r < n_shards) owns bytes [r*shard_bytes, (r+1)*shard_bytes).  The hook
  * must all-gather in place (e.g. ncclAllGather / torch.distributed.all_gather_into_tensor on
- * the stream given to cvhip_device_create_on_stream) and return 0, or non-zero to abort.
+ * the stream given to cvhip_device_create_on_stream) and return 0, or non-zero to abort.  dir = 0 / 1: the match plane
+ * of that direction (after each sharded search pass); dir = 2: the forward SCORE plane, once, after the forward pass at
+ * scale 1 (same geometry; the only scores cvhip_complete reports).
  * Stream ordering: with a device handle created by cvhip_device_create_on_stream the hook MUST enqueue its collective
  * on that stream (the search pass before it and the cross-checks after it are submitted there).  With a handle that
  * owns a private stream (cvhip_device_create) the library fences both sides of the hook itself (stream synchronise
@@ -205,11 +207,13 @@ int cvhip_ctx_set_row_shard_rccl(cvhip_ctx *ctx, cvhip_rccl *comm);
  * forward level grid's bands go to `root` (root < 0: to every rank) before cvhip_complete. */
 int cvhip_ctx_gather_bands_rccl(cvhip_ctx *ctx, cvhip_rccl *comm, int root);
 
-/* Device pointer + geometry of direction `dir`'s current level grid, for the host's
- * collectives.  One 8-byte cell per level pixel, row-major lw x lh: u32 x | y << 16 in LEVEL
- * coordinates (0xFFFFFFFF = None) followed by the f32 score.  The buffer always has room for
- * den * rows_per_shard rows, so bands can be gathered in equal chunks. */
-int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, uint32_t *lw, uint32_t *lh, uint32_t *row0,
+/* Device pointers + geometry of direction `dir`'s current level grid, for the host's collectives.  Two planes of one
+ * 4-byte word per level pixel, row-major lw x lh: `cells` = the match plane, u32 x | y << 16 in LEVEL coordinates
+ * (0xFFFFFFFF = None) - everything the search range and the cross-checks of other ranks read, i.e. all that has to
+ * travel between passes; `scores` (may be NULL) = the f32 score plane, which only cvhip_complete reads (the single
+ * final gather moves both).  Each plane always has room for den * rows_per_shard rows, so bands can be gathered in
+ * equal chunks. */
+int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, void **scores, uint32_t *lw, uint32_t *lh, uint32_t *row0,
                          uint32_t *row1, uint32_t *rows_per_shard);
 
 /* Use device-resident level images where they are instead of copying them into the context's own padded
@@ -256,8 +260,9 @@ int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
  * 588-624).  By default (all_passes = 0) the forward pass at scale 1 evaluates every recorded contender with the
  * reference's serial f32 chain, as before, and every other pass does so only where it decides something (several
  * contenders inside the filter's band, or one within the band of the threshold); a cell settled without it holds the
- * filter's estimate of its score (within 2.5e-5 of the reference's).  all_passes = 1: the reference's bits in every
- * cell of every pass - for tests that read coarser levels or the reverse grid through cvhip_complete_dir. */
+ * filter's estimate internally, its score plane is not written, and cvhip_complete_dir reports NaN scores for such a
+ * grid.  all_passes = 1: the reference's bits in every cell of every pass - for tests that read coarser levels or the
+ * reverse grid through cvhip_complete_dir. */
 int cvhip_ctx_set_exact_scores(cvhip_ctx *ctx, int all_passes);
 /* Test hook of the search-range kernel (estimate_search_range, mod.rs:468-540): 0 (default) = integer box sums with the
  * reference's f64 chain only where the rounding of `len` is open, 1 = the chain for every pixel, 2 / 3 = every third

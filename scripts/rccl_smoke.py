@@ -29,12 +29,12 @@ for i in range(steps + 1):
     k = steps - i
     pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
 g = pc.level_grid(correlation.CorrelationDirection.Forward)
-before = sharding.alias_bytes(g["cells"], g["rows_per_shard"] * g["lw"] * 8, device=True).clone()
+before = sharding.alias_bytes(g["cells"], g["rows_per_shard"] * g["lw"] * 4, device=True).clone()
 gather = sharding.make_allgather(0, 1)
-gather(g["cells"], g["rows_per_shard"] * g["lw"] * 8, 1, 0)
+gather(g["cells"], g["rows_per_shard"] * g["lw"] * 4, 1, 0)
 dist.barrier()
 torch.cuda.synchronize()
-after = sharding.alias_bytes(g["cells"], g["rows_per_shard"] * g["lw"] * 8, device=True)
+after = sharding.alias_bytes(g["cells"], g["rows_per_shard"] * g["lw"] * 4, device=True)
 assert torch.equal(before, after)
 xy, corr = pc.complete()
 print("rccl smoke ok:", int((xy[..., 0] >= 0).sum()), "matches")
@@ -51,7 +51,7 @@ for i in range(steps + 1):
     k = steps - i
     pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
 g = pc.level_grid(correlation.CorrelationDirection.Forward)
-nbytes = g["rows_per_shard"] * g["lw"] * 8
+nbytes = g["rows_per_shard"] * g["lw"] * 4
 dev2.synchronize()
 before = sharding.alias_bytes(g["cells"], nbytes, device=True).clone()
 comm.allgather(g["cells"], nbytes)

@@ -47,11 +47,13 @@ def main():
         before = len(calls)
         pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
         expect = (not band) and sharding.level_is_sharded(d1[k].shape[0], d2[k].shape[0], world)
-        assert (len(calls) - before) == (2 if expect else 0), (k, calls[before:])
+        # a sharded level: the two match planes, and at scale 1 the forward score plane too
+        assert (len(calls) - before) == ((3 if k == 0 else 2) if expect else 0), (k, calls[before:])
         sharded_levels += int(expect)
     if band:  # the single final gather of the forward bands
         lg = pc.level_grid(correlation.CorrelationDirection.Forward)
-        inner(lg["cells"], lg["rows_per_shard"] * lg["lw"] * 8, world, 0)
+        inner(lg["cells"], lg["rows_per_shard"] * lg["lw"] * 4, world, 0)   # match plane
+        inner(lg["scores"], lg["rows_per_shard"] * lg["lw"] * 4, world, 2)  # score plane
     else:
         assert sharded_levels >= 1, "test case too small to exercise the collective"
     xy, corr = pc.complete()

@@ -43,11 +43,7 @@ for it in range(N):
         for r in range(1, den):
             g = grids[r]
             r0, r1 = sharding.shard_rows(g["lh"], r, den)
-            nbytes = (r1 - r0) * g["lw"] * 8
-            if nbytes:
-                src = sharding.alias_bytes(g["cells"] + r0 * g["lw"] * 8, nbytes, device=True)
-                dst = sharding.alias_bytes(grids[0]["cells"] + r0 * g["lw"] * 8, nbytes, device=True)
-                dst.copy_(src)
+            sharding.copy_rows(grids[0], g, r0, r1)
         torch.cuda.synchronize()
         got = ctxs[0].complete(Fdir)
         v = want[0][..., 0] >= 0
