@@ -1256,7 +1256,12 @@ __device__ int perspective_pencil(const uint4 (&sm)[7], double (&n1)[9], double 
             for (int r = k; r < 9; r++) M[r][c] -= dot * M[r][k];
         }
     }
-    // null space of A = last two columns of Q = H0 H1 ... H6 applied to e7, e8
+    // null space of A = last two columns of Q = H0 H1 ... H6 applied to e7, e8.
+    // DELIBERATE DEVIATION from fundamentalmatrix.rs:309-322 as written: the reference takes rows nrows-2, nrows-1 of
+    // nalgebra's v_t, which for a 7x9 matrix is 7x9 (DimMinimum<R, C> x C) - the singular vectors of the two smallest of
+    // the seven singular values, not the null space; its pencil only fits the sample after validate_f's LM.  Those rows
+    // cannot be reproduced from the crate's published interface (the rank test :362-366 depends on the sign the
+    // decomposition gives each vector); the 7-point algorithm's own null space is used instead.  DESIGN.md section 2.
 #pragma unroll
     for (int r = 0; r < 9; r++) {
         n1[r] = r == 7 ? 1.0 : 0.0;

@@ -351,7 +351,9 @@ int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, 
 
 /* Perspective RANSAC on the device — FundamentalMatrix::new(Perspective, max_dimension).find_ransac
  * (fundamentalmatrix.rs:72-147, 155-229, 289-389): per sample the 7-point model (null space of the 7x9
- * system, the determinant cubic, the reference's rank and sign-consistency checks, up to three roots),
+ * system - the one documented deviation from the reference as written, which takes the last two rows of nalgebra's
+ * 7x9 thin v_t, DESIGN.md section 2 - the determinant cubic, the reference's rank and sign-consistency checks, up to
+ * three roots),
  * every surviving root scored against ALL matches, best = most inliers then smallest mean error, early
  * exit above 50 000 inliers; t = 0.01 * max_dimension.  `rounds` = number of 50 000-sample rounds (0 or
  * more than 20 = the reference's 20).  validate_f's per-hypothesis optimize_perspective_f (:201-205: the LM

@@ -86,6 +86,10 @@ def calculate_model_perspective(sample):
     p1, p2 = _h(sample)
     x1, y1, x2, y2 = p1[:, 0], p1[:, 1], p2[:, 0], p2[:, 1]
     A = np.stack([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, np.ones(7)], axis=1)
+    # DELIBERATE DEVIATION from :309-322 as written (shared with the device generator): the
+    # reference takes v_t.row(nrows - 2), v_t.row(nrows - 1) of nalgebra's svd(false, true), whose v_t is 7 x 9 for a
+    # 7 x 9 matrix - rows 5 and 6, the singular vectors of the two smallest of the SEVEN singular values, not the null
+    # space.  The true null space (rows 7 and 8 of the full V') is used here: the 7-point algorithm as published.
     _, _, vt = np.linalg.svd(A, full_matrices=True)
     f1, f2 = vt[7].reshape(3, 3), vt[8].reshape(3, 3)
     ff = (f1, f2)
