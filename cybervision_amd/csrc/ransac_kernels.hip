@@ -592,15 +592,29 @@ __device__ __forceinline__ bool match_fits(const double (&f)[9], uint4 m, double
 // Largest coordinate of the match list (one word, once per call): the scale of the f32 screen's error bounds.
 // Also writes the match list once as f32 (exact below 2^24; a larger coordinate switches the screen off through W), so
 // that the counting kernel's screen does not convert the same 29 000 matches for every one of 25 000 hypotheses.
+// The f32 copy is laid out for the counting kernel's packed arithmetic: matches go in groups of 128, lane l of a wave
+// handles matches 128 g + l and 128 g + 64 + l as the two halves of a packed pair, so plane c (x1, y1, x2, y2) holds
+// float2 {c of match 128 g + l, c of match 128 g + 64 + l} at index 64 g + l: four 8-byte loads per lane and step land
+// directly in the registers of the packed operands.  Padded with zeros to a whole group.
+__host__ __device__ inline uint32_t ransac_padded(uint32_t N) { return (N + 127u) / 128u * 128u; }
 __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__restrict__ matches, uint32_t N,
                                                                  uint32_t *__restrict__ out, float4 *__restrict__ matches_f32)
 {
     __shared__ uint32_t wmax[16];
     uint32_t m = 1u;
-    for (uint32_t i = threadIdx.x; i < N; i += 1024) {
-        const uint4 v = matches[i];
-        m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
-        matches_f32[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+    const uint32_t np = ransac_padded(N);
+    float *planes = reinterpret_cast<float *>(matches_f32); // 4 planes of np floats
+    for (uint32_t i = threadIdx.x; i < np; i += 1024) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < N) {
+            v = matches[i];
+            m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
+        }
+        const uint32_t g = i >> 7, r = i & 127u, slot = 2u * (64u * g + (r & 63u)) + (r >> 6);
+        planes[slot] = (float)v.x;
+        planes[np + slot] = (float)v.y;
+        planes[2u * np + slot] = (float)v.z;
+        planes[3u * np + slot] = (float)v.w;
     }
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_down(m, sft, 64));
@@ -628,6 +642,14 @@ __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__r
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// COUNT_K live hypotheses per wave.  Measured on one box (config 5's RANSAC stage, ms): one hypothesis per wave 45.7,
+// two 42.6, four 46.6 - and 38 instead of 56 vector instructions per step changed nothing at one per wave: the kernel
+// is bound neither by the arithmetic alone nor by the match list alone (a wave streams its 464 KB from L2 for every
+// hypothesis: ~9 GB per round), two per wave is where registers (90 VGPRs, 5 waves per SIMD) and list traffic balance.
+// Everything per hypothesis is wave-uniform and - the wave index being made a SCALAR with readfirstlane - lives in
+// scalar registers: coefficients, bounds, the running count, the alive flag; the loop's branches are scalar branches
+// and the lane masks of the tests stay SGPR pairs.
+constexpr int COUNT_K = 2;
 __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
                                                             uint32_t N, double t, const uint32_t *__restrict__ live,
                                                             const uint32_t *__restrict__ n_live, uint32_t min_count,
@@ -638,77 +660,105 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
                                                             double *__restrict__ out_err_sum)
 {
     const uint32_t n_hyp = *n_live, lane = threadIdx.x & 63;
-    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); // one wave per live hypothesis
-    if (j >= n_hyp) return;
-    const uint32_t h = live[j];
-    double f[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) f[i] = F[(size_t)h * 9 + i];
+    const uint32_t j0 = (blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * COUNT_K;
+    if (j0 >= n_hyp) return;
     const uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
     const double t_hi = t * (1.0 + 0x1p-40);
-    // the screen's constants (wave-uniform)
     const double W = (double)*coord_max, u = 0x1p-24;
-    double af[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) af[i] = fabs(f[i]);
-    const double Tr0 = (af[0] + af[3]) * W + af[6], Tr1 = (af[1] + af[4]) * W + af[7], Tr2 = (af[2] + af[5]) * W + af[8];
-    const double Ta0 = (af[0] + af[1]) * W + af[2], Ta1 = (af[3] + af[4]) * W + af[5];
-    const double Tmax = fmax(fmax(Tr0, Tr1), fmax(Ta0, Ta1)), Emax = 4.0 * u * Tmax;
-    const double En_d = 1.001 * 7.0 * u * (Tr0 * W + Tr1 * W + Tr2), Eden_d = 1.001 * (8.0 * Emax * Tmax + 4.0 * Emax * Emax);
-    // (as f32, rounded up by one more 2^-20; a bound beyond f32's comfortable range switches the screen off)
-    const float En = (float)(En_d * (1.0 + 0x1p-20)), Eden = (float)(Eden_d * (1.0 + 0x1p-20));
-    // the screen runs only where every bound and every product it is compared with stays a NORMAL f32 number
-    // (E_den >= 32u Tmax^2 >= 2e-18, times t >= 1e-6; squares below 1e31); false for NaN / inf coefficients too
-    const bool screen = Tmax >= 1e-6 && Tmax * W <= 1e12 && Tr2 <= 1e12 && t >= 1e-6 && t <= 1e12 && W < 16777216.0;
     const float T_out = (float)(t * (1.0 + 0x1p-18)), T_in = (float)(t * (1.0 - 0x1p-18));
-    float ff[9];
+    // per hypothesis of the group (all wave-uniform)
+    float ff[COUNT_K][9], En[COUNT_K], Eden[COUNT_K];
+    bool screen[COUNT_K], alive[COUNT_K];
+    uint32_t slot[COUNT_K], count[COUNT_K];
 #pragma unroll
-    for (int i = 0; i < 9; i++) ff[i] = (float)f[i];
+    for (int k = 0; k < COUNT_K; k++) {
+        alive[k] = j0 + k < n_hyp;
+        slot[k] = live[alive[k] ? j0 + k : j0];
+        count[k] = 0;
+        double af[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const double fi = F[(size_t)slot[k] * 9 + i];
+            af[i] = fabs(fi);
+            ff[k][i] = (float)fi;
+        }
+        // the screen's constants (derivation above)
+        const double Tr0 = (af[0] + af[3]) * W + af[6], Tr1 = (af[1] + af[4]) * W + af[7], Tr2 = (af[2] + af[5]) * W + af[8];
+        const double Ta0 = (af[0] + af[1]) * W + af[2], Ta1 = (af[3] + af[4]) * W + af[5];
+        const double Tmax = fmax(fmax(Tr0, Tr1), fmax(Ta0, Ta1)), Emax = 4.0 * u * Tmax;
+        const double En_d = 1.001 * 7.0 * u * (Tr0 * W + Tr1 * W + Tr2), Eden_d = 1.001 * (8.0 * Emax * Tmax + 4.0 * Emax * Emax);
+        // (as f32, rounded up by one more 2^-20; a bound beyond f32's comfortable range switches the screen off)
+        En[k] = (float)(En_d * (1.0 + 0x1p-20));
+        Eden[k] = (float)(Eden_d * (1.0 + 0x1p-20));
+        // the screen runs only where every bound and every product it is compared with stays a NORMAL f32 number
+        // (E_den >= 32u Tmax^2 >= 2e-18, times t >= 1e-6; squares below 1e31); false for NaN / inf coefficients too
+        screen[k] = Tmax >= 1e-6 && Tmax * W <= 1e12 && Tr2 <= 1e12 && t >= 1e-6 && t <= 1e12 && W < 16777216.0;
+    }
     const auto bc = [](float v) { return v2f{v, v}; };
-
-    uint32_t count = 0;
-    bool alive = true;
+    const uint32_t np = ransac_padded(N);
+    const v2f *const px1 = reinterpret_cast<const v2f *>(matches_f32), *const py1 = px1 + np / 2, *const px2 = px1 + np,
+                    *const py2 = px1 + 3 * (np / 2);
     for (uint32_t base = 0; base < N; base += 128) {
-        if (count + (N - base) < bound) { // this hypothesis is out, whatever the remaining matches do
-            alive = false;
-            break;
+        bool any_alive = false;
+#pragma unroll
+        for (int k = 0; k < COUNT_K; k++) {
+            // a hypothesis that cannot reach the bound any more is out, whatever the remaining matches do
+            alive[k] = alive[k] && !(count[k] + (N - base) < bound);
+            any_alive = any_alive || alive[k];
         }
-        const uint32_t ia = base + lane, ib = base + 64 + lane;
-        const bool va = ia < N, vb = ib < N;
-        bool in_a = false, in_b = false, open_a = va, open_b = vb;
-        if (screen) {
-            const float4 fa = matches_f32[va ? ia : 0u], fb = matches_f32[vb ? ib : 0u];
-            const v2f p1x = {fa.x, fb.x}, p1y = {fa.y, fb.y}, p2x = {fa.z, fb.z}, p2y = {fa.w, fb.w};
-            const v2f r0 = pk_fma(p2x, bc(ff[0]), pk_fma(p2y, bc(ff[3]), bc(ff[6])));
-            const v2f r1 = pk_fma(p2x, bc(ff[1]), pk_fma(p2y, bc(ff[4]), bc(ff[7])));
-            const v2f r2 = pk_fma(p2x, bc(ff[2]), pk_fma(p2y, bc(ff[5]), bc(ff[8])));
-            const v2f nn = pk_fma(r0, p1x, pk_fma(r1, p1y, r2));
-            const v2f a0 = pk_fma(p1x, bc(ff[0]), pk_fma(p1y, bc(ff[1]), bc(ff[2])));
-            const v2f a1 = pk_fma(p1x, bc(ff[3]), pk_fma(p1y, bc(ff[4]), bc(ff[5])));
-            const v2f den = pk_fma(a0, a0, pk_fma(a1, a1, pk_fma(r0, r0, r1 * r1)));
-            const v2f an = __builtin_elementwise_abs(nn);
-            const v2f lo = __builtin_elementwise_max(an - bc(En), bc(0.0f)), hi = an + bc(En);
-            const v2f lhs_out = lo * lo, rhs_out = bc(T_out) * (den + bc(Eden));
-            const v2f den_lo = den - bc(Eden);
-            const v2f lhs_in = hi * hi, rhs_in = bc(T_in) * den_lo;
-            // (comparisons with NaN are false: such a pair stays open)
-            const bool out_a = lhs_out.x > rhs_out.x, out_b = lhs_out.y > rhs_out.y;
-            const bool sure_a = den_lo.x > 0.0f && lhs_in.x <= rhs_in.x, sure_b = den_lo.y > 0.0f && lhs_in.y <= rhs_in.y;
-            in_a = va && sure_a;
-            in_b = vb && sure_b;
-            open_a = va && !sure_a && !out_a;
-            open_b = vb && !sure_b && !out_b;
+        if (!any_alive) break;
+        const uint32_t ia = base + lane, ib = base + 64 + lane, q = (base >> 1) + lane;
+        const v2f p1x = px1[q], p1y = py1[q], p2x = px2[q], p2y = py2[q];
+        // the ragged last group: lanes past the end count for nothing
+        unsigned long long va = ~0ull, vb = ~0ull;
+        if (base + 128 > N) {
+            va = N - base >= 64u ? ~0ull : (1ull << (N - base)) - 1ull;
+            vb = N - base <= 64u ? 0ull : (N - base >= 128u ? ~0ull : (1ull << (N - base - 64u)) - 1ull);
         }
-        if (__builtin_amdgcn_ballot_w64(open_a || open_b) != 0ull) { // rare (never, when the screen is off: always)
-            double err;
-            if (open_a) in_a = match_fits(f, matches[ia], t, t_hi, err);
-            if (open_b) in_b = match_fits(f, matches[ib], t, t_hi, err);
+#pragma unroll
+        for (int k = 0; k < COUNT_K; k++) {
+            if (!alive[k]) continue; // (scalar)
+            // lane masks (scalar registers) of the two halves: certainly in, still open
+            unsigned long long in_a = 0ull, in_b = 0ull, open_a = va, open_b = vb;
+            if (screen[k]) {
+                const float *c = ff[k];
+                const v2f r0 = pk_fma(p2x, bc(c[0]), pk_fma(p2y, bc(c[3]), bc(c[6])));
+                const v2f r1 = pk_fma(p2x, bc(c[1]), pk_fma(p2y, bc(c[4]), bc(c[7])));
+                const v2f r2 = pk_fma(p2x, bc(c[2]), pk_fma(p2y, bc(c[5]), bc(c[8])));
+                const v2f nn = pk_fma(r0, p1x, pk_fma(r1, p1y, r2));
+                const v2f a0 = pk_fma(p1x, bc(c[0]), pk_fma(p1y, bc(c[1]), bc(c[2])));
+                const v2f a1 = pk_fma(p1x, bc(c[3]), pk_fma(p1y, bc(c[4]), bc(c[5])));
+                const v2f den = pk_fma(a0, a0, pk_fma(a1, a1, pk_fma(r0, r0, r1 * r1)));
+                const v2f an = __builtin_elementwise_abs(nn);
+                const v2f lo = __builtin_elementwise_max(an - bc(En[k]), bc(0.0f)), hi = an + bc(En[k]);
+                const v2f lhs_out = lo * lo, rhs_out = bc(T_out) * (den + bc(Eden[k]));
+                const v2f lhs_in = hi * hi, rhs_in = bc(T_in) * (den - bc(Eden[k]));
+                // (comparisons with NaN are false: such a pair stays open.  "certainly in" needs no separate den - E_den > 0
+                // test: hi = |n| + E_n > 0, so hi^2 <= T_in (den - E_den) cannot hold for a non-positive right side)
+                in_a = __builtin_amdgcn_ballot_w64(lhs_in.x <= rhs_in.x) & va;
+                in_b = __builtin_amdgcn_ballot_w64(lhs_in.y <= rhs_in.y) & vb;
+                open_a = ~(in_a | __builtin_amdgcn_ballot_w64(lhs_out.x > rhs_out.x)) & va;
+                open_b = ~(in_b | __builtin_amdgcn_ballot_w64(lhs_out.y > rhs_out.y)) & vb;
+            }
+            count[k] += (uint32_t)__popcll(in_a) + (uint32_t)__popcll(in_b);
+            if ((open_a | open_b) != 0ull) { // rare (never, when the screen is off: always): the reference's f64 expression
+                double f[9], err;
+#pragma unroll
+                for (int i = 0; i < 9; i++) f[i] = F[(size_t)slot[k] * 9 + i];
+                bool fa = false, fb = false;
+                if ((open_a >> lane) & 1ull) fa = match_fits(f, matches[ia], t, t_hi, err);
+                if ((open_b >> lane) & 1ull) fb = match_fits(f, matches[ib], t, t_hi, err);
+                count[k] += (uint32_t)__popcll(__ballot(fa)) + (uint32_t)__popcll(__ballot(fb));
+            }
         }
-        count += (uint32_t)__popcll(__ballot(in_a)) + (uint32_t)__popcll(__ballot(in_b));
     }
     if (lane == 0) {
-        out_count[h] = alive ? count : 0u;
-        out_err_sum[h] = 0.0;
+#pragma unroll
+        for (int k = 0; k < COUNT_K; k++)
+            if (j0 + k < n_hyp) {
+                out_count[slot[k]] = alive[k] ? count[k] : 0u;
+                out_err_sum[slot[k]] = 0.0;
+            }
     }
 }
 
@@ -1002,7 +1052,7 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     // (scratch of the compaction: out_err_sum's first words, until the count kernel overwrites them)
     if (!live_ready) launch_ransac_live(F, H, live, n_live, reinterpret_cast<uint32_t *>(out_err_sum), s);
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
-    hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 3) / 4), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 4 * COUNT_K - 1) / (4 * COUNT_K)), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum);
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
@@ -1819,7 +1869,7 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     CVHIP_TRY_HIP(hipMemsetAsync(d_best, 0, sizeof(RansacBest), s));
     CVHIP_TRY_HIP(hipMemsetAsync(d_err, 0, std::max<size_t>(H, 64) * sizeof(double), s));
     float4 *d_mf = nullptr;
-    CVHIP_TRY_HIP(mem.alloc(&d_mf, std::max(N, 1u)));
+    CVHIP_TRY_HIP(mem.alloc(&d_mf, ransac_padded(std::max(N, 1u))));
     hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
                        d_live + H + 3 + TIED_CAP, d_mf);
     launch_ransac_score_round(d_F, H, d_m, d_mf, N, t, d_live, d_live + H, d_live + H + 1, d_live + H + 3 + TIED_CAP, false, false, 0u, d_best,
@@ -1878,7 +1928,7 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     float4 *d_mf = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&d_mf, (size_t)N * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&d_mf, (size_t)ransac_padded(N) * sizeof(float4));
     if (e == hipSuccess)
         hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
                            d_live + CHECK_INTERVAL + 3 + TIED_CAP, d_mf);
@@ -1956,7 +2006,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = mem.alloc(&d_live, GEN_DEPTH * live_words + 3 + TIED_CAP);
     uint32_t *const d_tied = d_live + GEN_DEPTH * live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
     float4 *d_mf = nullptr;
-    if (e == hipSuccess) e = mem.alloc(&d_mf, N);
+    if (e == hipSuccess) e = mem.alloc(&d_mf, ransac_padded(N));
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
