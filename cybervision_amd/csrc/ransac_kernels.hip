@@ -627,7 +627,7 @@ __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__r
 }
 
 // The counting kernel decides most (hypothesis, match) pairs in PACKED f32 - two matches per lane and instruction,
-// fused multiply-adds allowed because nothing here is a result: the f32 value of n and of the denominator come with
+// fused multiply-adds allowed because nothing here is a result: the f32 values of n and of the denominator come with
 // rigorous error bounds (below), "certainly an inlier" / "certainly not" are decided against those, and only a pair
 // that falls inside the guard band (~1e-4 of them) is evaluated with the reference's f64 expression (match_fits).
 // The count is therefore exactly the f64 count.
@@ -635,17 +635,27 @@ __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__r
 //   r_j, a_j: three terms, two fmas + the coefficient rounding: |error| <= 4u * T_j,  T_j = (|f|+|f|) W + |f| >= |value|
 //   n = r0 x + r1 y + r2: the operands' errors times W plus three roundings: E_n = 7u (T_r0 W + T_r1 W + T_r2)
 //   den = a0^2 + a1^2 + r0^2 + r1^2 (non-negative terms): |t^2 - t_exact^2| <= E_t (2|t| + E_t) per term,
-//     E_den = 8 E_max T_max + 4 E_max^2 absolute, plus 5u relative (roundings of a positive sum) - the relative part,
-//     the roundings of the comparison itself and the f64 expression's own 2^-53 errors sit inside the 2^-18 shave of t
-//     and the 0.1 % inflation of E_n, E_den.
+//     E_den = 8 E_max T_max + 4 E_max^2 absolute, plus 5u relative (roundings of a positive sum).
+// The decision is taken on q = n^2 - t den (inlier <=> q <= 0; one multiplication, one fma):
+//   |q_f32 - q_exact| <= u |q_f32| + E_n (2|n| + E_n) + t E_den + 8u t den
+//     (the fma's rounding; n's error through the square; den's absolute error; den's relative error and the roundings of
+//     t and of t den), and the margin the kernel compares |q| with is
+//   m = 2^-18 (t den) + 2 E_n |n| + (E_n^2 + t E_den), constants inflated by 2^-20 and by the 0.1 % of E_n, E_den:
+//     2^-18 against 8u = 2^-21 leaves room for the roundings of m itself, for u |q| and for the f64 expression's own 2^-50.
+//   |q| > m, q < 0: certainly an inlier (then t den > t E_den: the exact denominator is positive and err is finite);
+//   |q| > m, q > 0: certainly none; otherwise (and for NaN, which compares false) the f64 expression decides.
 // A hypothesis with non-finite, tiny or huge coefficients is not screened at all (its pairs all take the f64 path).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float wave_uniform(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
 // COUNT_K live hypotheses per wave.  Measured on one box (config 5's RANSAC stage, ms): one hypothesis per wave 45.7,
-// two 42.6, four 46.6 - and 38 instead of 56 vector instructions per step changed nothing at one per wave: the kernel
-// is bound neither by the arithmetic alone nor by the match list alone (a wave streams its 464 KB from L2 for every
-// hypothesis: ~9 GB per round), two per wave is where registers (90 VGPRs, 5 waves per SIMD) and list traffic balance.
+// two 42.6, four 46.6 (registers: 90 VGPRs and 5 waves per SIMD at two).  The counters say the vector ALU is what
+// the kernel waits for most (busy 0.66 of the time), the rest is the latency of the match list's loads (a wave streams
+// its 464 KB from L2 for every pair of hypotheses): the list is therefore loaded one step AHEAD of the arithmetic.
 // Everything per hypothesis is wave-uniform and - the wave index being made a SCALAR with readfirstlane - lives in
 // scalar registers: coefficients, bounds, the running count, the alive flag; the loop's branches are scalar branches
 // and the lane masks of the tests stay SGPR pairs.
@@ -661,13 +671,13 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
 {
     const uint32_t n_hyp = *n_live, lane = threadIdx.x & 63;
     const uint32_t j0 = (blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * COUNT_K;
-    if (j0 >= n_hyp) return;
+    if (j0 >= n_hyp || N == 0) return; // (an empty list: the counts stay at the zeros they were cleared to)
     const uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
     const double t_hi = t * (1.0 + 0x1p-40);
     const double W = (double)*coord_max, u = 0x1p-24;
-    const float T_out = (float)(t * (1.0 + 0x1p-18)), T_in = (float)(t * (1.0 - 0x1p-18));
+    const float T_f = wave_uniform((float)t);
     // per hypothesis of the group (all wave-uniform)
-    float ff[COUNT_K][9], En[COUNT_K], Eden[COUNT_K];
+    float ff[COUNT_K][9], En2[COUNT_K], C0[COUNT_K];
     bool screen[COUNT_K], alive[COUNT_K];
     uint32_t slot[COUNT_K], count[COUNT_K];
 #pragma unroll
@@ -680,16 +690,16 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
         for (int i = 0; i < 9; i++) {
             const double fi = F[(size_t)slot[k] * 9 + i];
             af[i] = fabs(fi);
-            ff[k][i] = (float)fi;
+            ff[k][i] = wave_uniform((float)fi);
         }
         // the screen's constants (derivation above)
         const double Tr0 = (af[0] + af[3]) * W + af[6], Tr1 = (af[1] + af[4]) * W + af[7], Tr2 = (af[2] + af[5]) * W + af[8];
         const double Ta0 = (af[0] + af[1]) * W + af[2], Ta1 = (af[3] + af[4]) * W + af[5];
         const double Tmax = fmax(fmax(Tr0, Tr1), fmax(Ta0, Ta1)), Emax = 4.0 * u * Tmax;
         const double En_d = 1.001 * 7.0 * u * (Tr0 * W + Tr1 * W + Tr2), Eden_d = 1.001 * (8.0 * Emax * Tmax + 4.0 * Emax * Emax);
-        // (as f32, rounded up by one more 2^-20; a bound beyond f32's comfortable range switches the screen off)
-        En[k] = (float)(En_d * (1.0 + 0x1p-20));
-        Eden[k] = (float)(Eden_d * (1.0 + 0x1p-20));
+        // (as f32, rounded up by one more 2^-20)
+        En2[k] = wave_uniform((float)(2.0 * En_d * (1.0 + 0x1p-20)));
+        C0[k] = wave_uniform((float)((En_d * En_d + t * Eden_d) * (1.0 + 0x1p-20)));
         // the screen runs only where every bound and every product it is compared with stays a NORMAL f32 number
         // (E_den >= 32u Tmax^2 >= 2e-18, times t >= 1e-6; squares below 1e31); false for NaN / inf coefficients too
         screen[k] = Tmax >= 1e-6 && Tmax * W <= 1e12 && Tr2 <= 1e12 && t >= 1e-6 && t <= 1e12 && W < 16777216.0;
@@ -698,6 +708,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     const uint32_t np = ransac_padded(N);
     const v2f *const px1 = reinterpret_cast<const v2f *>(matches_f32), *const py1 = px1 + np / 2, *const px2 = px1 + np,
                     *const py2 = px1 + 3 * (np / 2);
+    v2f p1x = px1[lane], p1y = py1[lane], p2x = px2[lane], p2y = py2[lane]; // the first step's matches
     for (uint32_t base = 0; base < N; base += 128) {
         bool any_alive = false;
 #pragma unroll
@@ -707,8 +718,11 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
             any_alive = any_alive || alive[k];
         }
         if (!any_alive) break;
-        const uint32_t ia = base + lane, ib = base + 64 + lane, q = (base >> 1) + lane;
-        const v2f p1x = px1[q], p1y = py1[q], p2x = px2[q], p2y = py2[q];
+        // the next step's matches are on their way while this step's are tested
+        // (the last step loads itself again: no branch, nothing read past the end)
+        const uint32_t qn = ((base + 128 < N ? base + 128 : base) >> 1) + lane;
+        const v2f n1x = px1[qn], n1y = py1[qn], n2x = px2[qn], n2y = py2[qn];
+        const uint32_t ia = base + lane, ib = base + 64 + lane;
         // the ragged last group: lanes past the end count for nothing
         unsigned long long va = ~0ull, vb = ~0ull;
         if (base + 128 > N) {
@@ -729,16 +743,13 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
                 const v2f a0 = pk_fma(p1x, bc(c[0]), pk_fma(p1y, bc(c[1]), bc(c[2])));
                 const v2f a1 = pk_fma(p1x, bc(c[3]), pk_fma(p1y, bc(c[4]), bc(c[5])));
                 const v2f den = pk_fma(a0, a0, pk_fma(a1, a1, pk_fma(r0, r0, r1 * r1)));
-                const v2f an = __builtin_elementwise_abs(nn);
-                const v2f lo = __builtin_elementwise_max(an - bc(En[k]), bc(0.0f)), hi = an + bc(En[k]);
-                const v2f lhs_out = lo * lo, rhs_out = bc(T_out) * (den + bc(Eden[k]));
-                const v2f lhs_in = hi * hi, rhs_in = bc(T_in) * (den - bc(Eden[k]));
-                // (comparisons with NaN are false: such a pair stays open.  "certainly in" needs no separate den - E_den > 0
-                // test: hi = |n| + E_n > 0, so hi^2 <= T_in (den - E_den) cannot hold for a non-positive right side)
-                in_a = __builtin_amdgcn_ballot_w64(lhs_in.x <= rhs_in.x) & va;
-                in_b = __builtin_amdgcn_ballot_w64(lhs_in.y <= rhs_in.y) & vb;
-                open_a = ~(in_a | __builtin_amdgcn_ballot_w64(lhs_out.x > rhs_out.x)) & va;
-                open_b = ~(in_b | __builtin_amdgcn_ballot_w64(lhs_out.y > rhs_out.y)) & vb;
+                const v2f d = bc(T_f) * den;
+                const v2f q = pk_fma(nn, nn, -d);
+                const v2f m = pk_fma(d, bc(0x1p-18f), pk_fma(__builtin_elementwise_max(nn, -nn), bc(En2[k]), bc(C0[k])));
+                in_a = __builtin_amdgcn_ballot_w64(q.x < -m.x) & va;
+                in_b = __builtin_amdgcn_ballot_w64(q.y < -m.y) & vb;
+                open_a = ~(in_a | __builtin_amdgcn_ballot_w64(q.x > m.x)) & va;
+                open_b = ~(in_b | __builtin_amdgcn_ballot_w64(q.y > m.y)) & vb;
             }
             count[k] += (uint32_t)__popcll(in_a) + (uint32_t)__popcll(in_b);
             if ((open_a | open_b) != 0ull) { // rare (never, when the screen is off: always): the reference's f64 expression
@@ -751,6 +762,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
                 count[k] += (uint32_t)__popcll(__ballot(fa)) + (uint32_t)__popcll(__ballot(fb));
             }
         }
+        p1x = n1x, p1y = n1y, p2x = n2x, p2y = n2y;
     }
     if (lane == 0) {
 #pragma unroll
@@ -936,12 +948,61 @@ __global__ __launch_bounds__(1024) void ransac_tied_approx_kernel(const double *
     }
 }
 
+// The counting kernel's copy of the match list, reordered whenever the best hypothesis changes: the matches the best
+// hypothesis REJECTS first, then the ones it accepts.  Counting is order-free, and a hypothesis is abandoned as soon as
+// its misses exceed N - (best count) - with the list in the matcher's order a hypothesis that is nearly as good as
+// the best one (most are: an epipolar constraint that is roughly right accepts most true correspondences) collects those
+// misses over ~3/4 of the list; with the best hypothesis' outliers in front, which nearly every hypothesis misses, it has
+// used up its allowance right behind them.  The winner and every hypothesis that ties it are never abandoned, so the
+// round's result is unchanged; the tie-break sums run over the list in its original order.
+// One workgroup of 1024 threads; scratch: 17 words of LDS.
+__device__ void ransac_reorder_matches(const double *best_f, const uint4 *__restrict__ matches, uint32_t N, double t,
+                                       uint4 *__restrict__ order_u32, float *__restrict__ order_planes, uint32_t *scratch)
+{
+    const double t_hi = t * (1.0 + 0x1p-40);
+    double f[9], err;
+#pragma unroll
+    for (int i = 0; i < 9; i++) f[i] = best_f[i];
+    const uint32_t chunk = (N + 1023u) / 1024u, i0 = min(threadIdx.x * chunk, N), i1 = min(i0 + chunk, N);
+    uint32_t rejected = 0;
+    for (uint32_t i = i0; i < i1; i++) rejected += match_fits(f, matches[i], t, t_hi, err) ? 0u : 1u;
+    // exclusive scan of `rejected` over the block: inside the wave, then over the 16 wave totals
+    uint32_t incl = rejected;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, sft, 64);
+        if ((threadIdx.x & 63) >= (uint32_t)sft) incl += v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) scratch[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - rejected, total = 0;
+    for (uint32_t w = 0; w < 16; w++) {
+        if (w < (threadIdx.x >> 6)) before += scratch[w];
+        total += scratch[w];
+    }
+    const uint32_t np = ransac_padded(N);
+    uint32_t out_pos = before, in_pos = total + (i0 - before);
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint4 v = matches[i];
+        const uint32_t pos = match_fits(f, v, t, t_hi, err) ? in_pos++ : out_pos++;
+        order_u32[pos] = v;
+        const uint32_t g = pos >> 7, r = pos & 127u, slot = 2u * (64u * g + (r & 63u)) + (r >> 6);
+        order_planes[slot] = (float)v.x;
+        order_planes[np + slot] = (float)v.y;
+        order_planes[2u * np + slot] = (float)v.z;
+        order_planes[3u * np + slot] = (float)v.w;
+    }
+}
+
 __global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
                                                                         uint32_t N, double t, const uint32_t *__restrict__ counts,
                                                                         double *__restrict__ err_sums, uint32_t min_count,
-                                                                        const uint32_t *__restrict__ tied, RansacBest *best)
+                                                                        const uint32_t *__restrict__ tied, RansacBest *best,
+                                                                        uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
 {
     __shared__ double errs[1024];
+    __shared__ uint32_t s_replaced;
     __shared__ double s_result;
     __shared__ uint32_t s_close[64]; // candidates within the margin of the smallest parallel sum (slots; ~0u = the carried best)
     __shared__ uint32_t s_nclose, s_winner, s_exact;
@@ -1019,14 +1080,18 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const dou
     }
     if (threadIdx.x == 0) {
         const uint32_t w = s_winner;
+        s_replaced = 0u;
         if (!best->valid || ransac_better(top, s_winner_err, best->matches_count, best->best_error)) {
             for (int i = 0; i < 9; i++) best->f[i] = F[(size_t)w * 9 + i];
             best->matches_count = top;
             best->best_error = s_winner_err;
             best->valid = 1;
             best->err_known = errors ? (s_exact ? 2u : 1u) : 0u;
+            s_replaced = 1u;
         }
     }
+    __syncthreads();
+    if (s_replaced && order_u32) ransac_reorder_matches(best->f, matches, N, t, order_u32, order_planes, reinterpret_cast<uint32_t *>(errs));
 }
 
 // The live slots of a round's hypothesis buffer, in slot order (count, scan, scatter).  Depends on the hypotheses only,
@@ -1042,7 +1107,7 @@ static void launch_ransac_live(const double *F, uint32_t H, uint32_t *live, uint
 
 // tied: [2 + TIED_CAP] words (number, slots, the maximum itself); coord_max: one word (ransac_coord_max_kernel);
 // live_ready: the live list was already built (launch_ransac_live)
-static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, const float4 *matches_f32,
+static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, const uint32_t *count_matches, const float4 *matches_f32,
                                       uint32_t N, double t, uint32_t *live, uint32_t *n_live, uint32_t *tied,
                                       const uint32_t *coord_max, bool live_ready, bool approx_sums, uint32_t min_count,
                                       RansacBest *best, uint32_t *out_count, double *out_err_sum, hipStream_t s)
@@ -1052,7 +1117,8 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     // (scratch of the compaction: out_err_sum's first words, until the count kernel overwrites them)
     if (!live_ready) launch_ransac_live(F, H, live, n_live, reinterpret_cast<uint32_t *>(out_err_sum), s);
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
-    hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 4 * COUNT_K - 1) / (4 * COUNT_K)), dim3(256), 0, s, F, m4, N, t, (const uint32_t *)live,
+    // (count_matches / matches_f32: the counting kernel's own copy of the list - same matches, any order)
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 4 * COUNT_K - 1) / (4 * COUNT_K)), dim3(256), 0, s, F, reinterpret_cast<const uint4 *>(count_matches), N, t, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum);
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
@@ -1872,7 +1938,7 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     CVHIP_TRY_HIP(mem.alloc(&d_mf, ransac_padded(std::max(N, 1u))));
     hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
                        d_live + H + 3 + TIED_CAP, d_mf);
-    launch_ransac_score_round(d_F, H, d_m, d_mf, N, t, d_live, d_live + H, d_live + H + 1, d_live + H + 3 + TIED_CAP, false, false, 0u, d_best,
+    launch_ransac_score_round(d_F, H, d_m, d_m, d_mf, N, t, d_live, d_live + H, d_live + H + 1, d_live + H + 3 + TIED_CAP, false, false, 0u, d_best,
                               d_cnt, d_err, s);
     CVHIP_TRY_HIP(hipGetLastError());
     CVHIP_TRY_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)H * sizeof(uint32_t), dev_ptr(out_count) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -1939,11 +2005,11 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
         hipLaunchKernelGGL(ransac_generate_affine_kernel, dim3((CHECK_INTERVAL + 63) / 64), dim3(64), 0, s, m4,
                            std::min(N, TOP_INLIERS), RANSAC_T, (unsigned long long)seed, round, CHECK_INTERVAL,
                            (const uint32_t *)nullptr, d_F);
-        launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, d_mf, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL,
+        launch_ransac_score_round(d_F, CHECK_INTERVAL, d_m, d_m, d_mf, N, RANSAC_T, d_live, d_live + CHECK_INTERVAL,
                                   d_live + CHECK_INTERVAL + 1, d_live + CHECK_INTERVAL + 3 + TIED_CAP, false, true, RANSAC_D + RANSAC_N, d_best,
                                   d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, d_F, m4, N, RANSAC_T, (const uint32_t *)d_cnt, d_err,
-                           RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best);
+                           RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best, (uint4 *)nullptr, (float *)nullptr);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -2005,14 +2071,17 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     uint32_t *d_live = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_live, GEN_DEPTH * live_words + 3 + TIED_CAP);
     uint32_t *const d_tied = d_live + GEN_DEPTH * live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
-    float4 *d_mf = nullptr;
+    float4 *d_mf = nullptr; // the counting kernel's copy of the list (f32 planes + u32), reordered as the best hypothesis changes
+    uint32_t *d_mo = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_mf, ransac_padded(N));
+    if (e == hipSuccess) e = mem.alloc(&d_mo, (size_t)N * 4);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     if (e == hipSuccess) // the scale of the counting kernel's f32 screen: one word behind the round's maximum list
         hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
                            d_coord_max, d_mf);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_mo, d_m, (size_t)N * 16, hipMemcpyDeviceToDevice, s);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
@@ -2056,9 +2125,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
         uint32_t *lv = d_live + (size_t)b * live_words;
-        launch_ransac_score_round(F_round, H, d_m, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err, s);
+        launch_ransac_score_round(F_round, H, d_m, d_mo, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)d_cnt, d_err,
-                           min_count, (const uint32_t *)d_tied, d_best);
+                           min_count, (const uint32_t *)d_tied, d_best, reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(scored[b], s);
         if (!may_exit_early && !g_listener.wants_counts() && round + 1 < rounds) {
