@@ -499,6 +499,19 @@ void device_free(cvhip_device *dev)
         if (rb.ready) (void)hipEventDestroy(rb.ready);
         if (rb.stream) (void)hipStreamDestroy(rb.stream);
     }
+    {
+        auto &rq = dev->d.rq;
+        for (hipStream_t g : rq.gen)
+            if (g) {
+                (void)hipStreamSynchronize(g);
+                (void)hipStreamDestroy(g);
+            }
+        for (hipEvent_t ev : rq.ready)
+            if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : rq.scored)
+            if (ev) (void)hipEventDestroy(ev);
+        if (rq.uploaded) (void)hipEventDestroy(rq.uploaded);
+    }
     if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
     if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
     if (dev->d.orb_pattern) (void)hipFree(dev->d.orb_pattern);

@@ -205,6 +205,12 @@ struct Device {
         bool pending[2] = {false, false};
         int next = 0;
     } rb;
+    // the RANSAC loops' generator streams and round events (created on first use: creating two streams and seven events
+    // per find_ransac call cost 1.5 ms of every ~9 ms call)
+    struct RansacQueues {
+        hipStream_t gen[2] = {nullptr, nullptr};
+        hipEvent_t ready[3] = {nullptr, nullptr, nullptr}, scored[3] = {nullptr, nullptr, nullptr}, uploaded = nullptr;
+    } rq;
     // RCCL communicators created on this handle (cvhip_rccl_create) enqueue on its stream: while any is alive,
     // cvhip_device_destroy only marks the handle and the last cvhip_rccl_destroy frees it
     int comm_refs = 0;

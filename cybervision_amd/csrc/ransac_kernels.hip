@@ -421,7 +421,7 @@ struct RansacBest {
     uint32_t matches_count;
     uint32_t valid;
     uint32_t err_known; // best_error has been computed (it is only ever needed to break a tie in matches_count)
-    uint32_t pad;
+    uint32_t pad;       // (ransac_pick_best_approx_kernel's note of the count its match order was made for)
 };
 
 // The fold of validate_f (:210-216) for a batch of hypotheses, one lane per hypothesis.
@@ -592,11 +592,13 @@ __device__ __forceinline__ bool match_fits(const double (&f)[9], uint4 m, double
 // Largest coordinate of the match list (one word, once per call): the scale of the f32 screen's error bounds.
 // Also writes the match list once as f32 (exact below 2^24; a larger coordinate switches the screen off through W), so
 // that the counting kernel's screen does not convert the same 29 000 matches for every one of 25 000 hypotheses.
-// The f32 copy is laid out for the counting kernel's packed arithmetic: matches go in groups of 128, lane l of a wave
-// handles matches 128 g + l and 128 g + 64 + l as the two halves of a packed pair, so plane c (x1, y1, x2, y2) holds
-// float2 {c of match 128 g + l, c of match 128 g + 64 + l} at index 64 g + l: four 8-byte loads per lane and step land
-// directly in the registers of the packed operands.  Padded with zeros to a whole group.
-__host__ __device__ inline uint32_t ransac_padded(uint32_t N) { return (N + 127u) / 128u * 128u; }
+// The f32 copy is laid out for the counting kernel: matches go in groups of 256, lane l of a wave handles matches
+// 256 g + l + 64 h (h = 0..3), so plane c (x1, y1, x2, y2) holds the float4 {c of those four matches} at index 64 g + l:
+// four 16-byte loads per lane and step.  Padded with zeros to a whole group.
+constexpr uint32_t COUNT_GROUP = 256;
+__host__ __device__ inline uint32_t ransac_padded(uint32_t N) { return (N + COUNT_GROUP - 1u) / COUNT_GROUP * COUNT_GROUP; }
+// (index of match i's value inside a plane of ransac_padded(N) floats)
+__host__ __device__ inline uint32_t ransac_plane_slot(uint32_t i) { return 4u * (64u * (i >> 8) + (i & 63u)) + ((i >> 6) & 3u); }
 __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__restrict__ matches, uint32_t N,
                                                                  uint32_t *__restrict__ out, float4 *__restrict__ matches_f32)
 {
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__r
             v = matches[i];
             m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
         }
-        const uint32_t g = i >> 7, r = i & 127u, slot = 2u * (64u * g + (r & 63u)) + (r >> 6);
+        const uint32_t slot = ransac_plane_slot(i);
         planes[slot] = (float)v.x;
         planes[np + slot] = (float)v.y;
         planes[2u * np + slot] = (float)v.z;
@@ -645,8 +647,6 @@ __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__r
 //   |q| > m, q < 0: certainly an inlier (then t den > t E_den: the exact denominator is positive and err is finite);
 //   |q| > m, q > 0: certainly none; otherwise (and for NaN, which compares false) the f64 expression decides.
 // A hypothesis with non-finite, tiny or huge coefficients is not screened at all (its pairs all take the f64 path).
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float wave_uniform(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
@@ -704,12 +704,10 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
         // (E_den >= 32u Tmax^2 >= 2e-18, times t >= 1e-6; squares below 1e31); false for NaN / inf coefficients too
         screen[k] = Tmax >= 1e-6 && Tmax * W <= 1e12 && Tr2 <= 1e12 && t >= 1e-6 && t <= 1e12 && W < 16777216.0;
     }
-    const auto bc = [](float v) { return v2f{v, v}; };
     const uint32_t np = ransac_padded(N);
-    const v2f *const px1 = reinterpret_cast<const v2f *>(matches_f32), *const py1 = px1 + np / 2, *const px2 = px1 + np,
-                    *const py2 = px1 + 3 * (np / 2);
-    v2f p1x = px1[lane], p1y = py1[lane], p2x = px2[lane], p2y = py2[lane]; // the first step's matches
-    for (uint32_t base = 0; base < N; base += 128) {
+    const float4 *const px1 = matches_f32, *const py1 = px1 + np / 4, *const px2 = px1 + np / 2, *const py2 = px1 + 3 * (np / 4);
+    float4 p1x = px1[lane], p1y = py1[lane], p2x = px2[lane], p2y = py2[lane]; // the first step's matches
+    for (uint32_t base = 0; base < N; base += COUNT_GROUP) {
         bool any_alive = false;
 #pragma unroll
         for (int k = 0; k < COUNT_K; k++) {
@@ -720,46 +718,54 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
         if (!any_alive) break;
         // the next step's matches are on their way while this step's are tested
         // (the last step loads itself again: no branch, nothing read past the end)
-        const uint32_t qn = ((base + 128 < N ? base + 128 : base) >> 1) + lane;
-        const v2f n1x = px1[qn], n1y = py1[qn], n2x = px2[qn], n2y = py2[qn];
-        const uint32_t ia = base + lane, ib = base + 64 + lane;
+        const uint32_t qn = ((base + COUNT_GROUP < N ? base + COUNT_GROUP : base) >> 2) + lane;
+        const float4 n1x = px1[qn], n1y = py1[qn], n2x = px2[qn], n2y = py2[qn];
         // the ragged last group: lanes past the end count for nothing
-        unsigned long long va = ~0ull, vb = ~0ull;
-        if (base + 128 > N) {
-            va = N - base >= 64u ? ~0ull : (1ull << (N - base)) - 1ull;
-            vb = N - base <= 64u ? 0ull : (N - base >= 128u ? ~0ull : (1ull << (N - base - 64u)) - 1ull);
+        unsigned long long valid[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        if (base + COUNT_GROUP > N) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const uint32_t first = base + 64u * h;
+                valid[h] = first >= N ? 0ull : (N - first >= 64u ? ~0ull : (1ull << (N - first)) - 1ull);
+            }
         }
 #pragma unroll
         for (int k = 0; k < COUNT_K; k++) {
             if (!alive[k]) continue; // (scalar)
-            // lane masks (scalar registers) of the two halves: certainly in, still open
-            unsigned long long in_a = 0ull, in_b = 0ull, open_a = va, open_b = vb;
+            // lane masks (scalar registers) per quarter of the group: certainly in, still open
+            unsigned long long in[4] = {0ull, 0ull, 0ull, 0ull}, open[4] = {valid[0], valid[1], valid[2], valid[3]};
             if (screen[k]) {
                 const float *c = ff[k];
-                const v2f r0 = pk_fma(p2x, bc(c[0]), pk_fma(p2y, bc(c[3]), bc(c[6])));
-                const v2f r1 = pk_fma(p2x, bc(c[1]), pk_fma(p2y, bc(c[4]), bc(c[7])));
-                const v2f r2 = pk_fma(p2x, bc(c[2]), pk_fma(p2y, bc(c[5]), bc(c[8])));
-                const v2f nn = pk_fma(r0, p1x, pk_fma(r1, p1y, r2));
-                const v2f a0 = pk_fma(p1x, bc(c[0]), pk_fma(p1y, bc(c[1]), bc(c[2])));
-                const v2f a1 = pk_fma(p1x, bc(c[3]), pk_fma(p1y, bc(c[4]), bc(c[5])));
-                const v2f den = pk_fma(a0, a0, pk_fma(a1, a1, pk_fma(r0, r0, r1 * r1)));
-                const v2f d = bc(T_f) * den;
-                const v2f q = pk_fma(nn, nn, -d);
-                const v2f m = pk_fma(d, bc(0x1p-18f), pk_fma(__builtin_elementwise_max(nn, -nn), bc(En2[k]), bc(C0[k])));
-                in_a = __builtin_amdgcn_ballot_w64(q.x < -m.x) & va;
-                in_b = __builtin_amdgcn_ballot_w64(q.y < -m.y) & vb;
-                open_a = ~(in_a | __builtin_amdgcn_ballot_w64(q.x > m.x)) & va;
-                open_b = ~(in_b | __builtin_amdgcn_ballot_w64(q.y > m.y)) & vb;
+#pragma unroll
+                for (int h = 0; h < 4; h++) { // the lane's four matches, one after the other (see the note on packed f32 above)
+                    const float x1 = p1x[h], y1 = p1y[h], x2 = p2x[h], y2 = p2y[h];
+                    const float r0 = __builtin_fmaf(x2, c[0], __builtin_fmaf(y2, c[3], c[6]));
+                    const float r1 = __builtin_fmaf(x2, c[1], __builtin_fmaf(y2, c[4], c[7]));
+                    const float r2 = __builtin_fmaf(x2, c[2], __builtin_fmaf(y2, c[5], c[8]));
+                    const float nn = __builtin_fmaf(r0, x1, __builtin_fmaf(r1, y1, r2));
+                    const float a0 = __builtin_fmaf(x1, c[0], __builtin_fmaf(y1, c[1], c[2]));
+                    const float a1 = __builtin_fmaf(x1, c[3], __builtin_fmaf(y1, c[4], c[5]));
+                    const float den = __builtin_fmaf(a0, a0, __builtin_fmaf(a1, a1, __builtin_fmaf(r0, r0, r1 * r1)));
+                    const float d = T_f * den;
+                    const float q = __builtin_fmaf(nn, nn, -d);
+                    const float m = __builtin_fmaf(d, 0x1p-18f, __builtin_fmaf(__builtin_fabsf(nn), En2[k], C0[k]));
+                    in[h] = __builtin_amdgcn_ballot_w64(q < -m) & valid[h];
+                    open[h] = ~(in[h] | __builtin_amdgcn_ballot_w64(q > m)) & valid[h];
+                }
             }
-            count[k] += (uint32_t)__popcll(in_a) + (uint32_t)__popcll(in_b);
-            if ((open_a | open_b) != 0ull) { // rare (never, when the screen is off: always): the reference's f64 expression
+            count[k] += (uint32_t)__popcll(in[0]) + (uint32_t)__popcll(in[1]) + (uint32_t)__popcll(in[2]) + (uint32_t)__popcll(in[3]);
+            if ((open[0] | open[1] | open[2] | open[3]) != 0ull) { // rare (never, when the screen is off: always): the reference's f64 expression
                 double f[9], err;
 #pragma unroll
                 for (int i = 0; i < 9; i++) f[i] = F[(size_t)slot[k] * 9 + i];
-                bool fa = false, fb = false;
-                if ((open_a >> lane) & 1ull) fa = match_fits(f, matches[ia], t, t_hi, err);
-                if ((open_b >> lane) & 1ull) fb = match_fits(f, matches[ib], t, t_hi, err);
-                count[k] += (uint32_t)__popcll(__ballot(fa)) + (uint32_t)__popcll(__ballot(fb));
+                const uint32_t mine = (uint32_t)((open[0] >> lane) & 1ull) | (uint32_t)((open[1] >> lane) & 1ull) << 1 |
+                                      (uint32_t)((open[2] >> lane) & 1ull) << 2 | (uint32_t)((open[3] >> lane) & 1ull) << 3;
+#pragma unroll 1
+                for (uint32_t h = 0; h < 4; h++) {
+                    bool fits = false;
+                    if ((mine >> h) & 1u) fits = match_fits(f, matches[base + 64u * h + lane], t, t_hi, err);
+                    count[k] += (uint32_t)__popcll(__ballot(fits));
+                }
             }
         }
         p1x = n1x, p1y = n1y, p2x = n2x, p2y = n2y;
@@ -949,45 +955,58 @@ __global__ __launch_bounds__(1024) void ransac_tied_approx_kernel(const double *
 }
 
 // The counting kernel's copy of the match list, reordered whenever the best hypothesis changes: the matches the best
-// hypothesis REJECTS first, then the ones it accepts.  Counting is order-free, and a hypothesis is abandoned as soon as
-// its misses exceed N - (best count) - with the list in the matcher's order a hypothesis that is nearly as good as
-// the best one (most are: an epipolar constraint that is roughly right accepts most true correspondences) collects those
-// misses over ~3/4 of the list; with the best hypothesis' outliers in front, which nearly every hypothesis misses, it has
-// used up its allowance right behind them.  The winner and every hypothesis that ties it are never abandoned, so the
-// round's result is unchanged; the tie-break sums run over the list in its original order.
-// One workgroup of 1024 threads; scratch: 17 words of LDS.
+// hypothesis REJECTS first, then the ones it accepts - those it fits worst in front.  Counting is order-free, and a
+// hypothesis is abandoned as soon as its misses exceed N - (best count).  With the list in the matcher's order a
+// hypothesis that is nearly as good as the best one (most are: an epipolar constraint that is roughly right accepts most
+// true correspondences) collects those misses over ~0.7 of the list; with the best hypothesis' outliers in front, which
+// nearly every hypothesis misses, and its marginal inliers next, it has used up its allowance at 0.37 - the floor
+// is (N - best count) / N = 0.355 on config 5's pairs (scripts/ransac_order_study.py).  The winner and every hypothesis
+// that ties it are never abandoned, so the round's result is unchanged; the tie-break sums run over the list in its
+// original order.  Nothing here has to be exact - any order counts the same - so the classes come from an f32
+// evaluation, a counting sort over REORDER_CLASSES error classes with the order inside a class as the LDS atomics fall,
+// and the list is only reordered again when the best count has grown by 1/64 since the last time.
+// One workgroup of 1024 threads; scratch: 2 * REORDER_CLASSES words of LDS.
+constexpr uint32_t REORDER_CLASSES = 9; // rejected; accepted with err / t in (7/8, 1], (6/8, 7/8], ..., [0, 1/8]
 __device__ void ransac_reorder_matches(const double *best_f, const uint4 *__restrict__ matches, uint32_t N, double t,
                                        uint4 *__restrict__ order_u32, float *__restrict__ order_planes, uint32_t *scratch)
 {
-    const double t_hi = t * (1.0 + 0x1p-40);
-    double f[9], err;
+    float c[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) f[i] = best_f[i];
-    const uint32_t chunk = (N + 1023u) / 1024u, i0 = min(threadIdx.x * chunk, N), i1 = min(i0 + chunk, N);
-    uint32_t rejected = 0;
-    for (uint32_t i = i0; i < i1; i++) rejected += match_fits(f, matches[i], t, t_hi, err) ? 0u : 1u;
-    // exclusive scan of `rejected` over the block: inside the wave, then over the 16 wave totals
-    uint32_t incl = rejected;
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)incl, sft, 64);
-        if ((threadIdx.x & 63) >= (uint32_t)sft) incl += v;
+    for (int i = 0; i < 9; i++) c[i] = (float)best_f[i];
+    const float tf = (float)t;
+    uint32_t *const total = scratch, *const cursor = scratch + REORDER_CLASSES;
+    if (threadIdx.x < 2 * REORDER_CLASSES) scratch[threadIdx.x] = 0u;
+    __syncthreads();
+    const auto error_class = [&](uint4 v) -> uint32_t {
+        const float x1 = (float)v.x, y1 = (float)v.y, x2 = (float)v.z, y2 = (float)v.w;
+        const float r0 = __builtin_fmaf(x2, c[0], __builtin_fmaf(y2, c[3], c[6]));
+        const float r1 = __builtin_fmaf(x2, c[1], __builtin_fmaf(y2, c[4], c[7]));
+        const float r2 = __builtin_fmaf(x2, c[2], __builtin_fmaf(y2, c[5], c[8]));
+        const float nn = __builtin_fmaf(r0, x1, __builtin_fmaf(r1, y1, r2));
+        const float a0 = __builtin_fmaf(x1, c[0], __builtin_fmaf(y1, c[1], c[2]));
+        const float a1 = __builtin_fmaf(x1, c[3], __builtin_fmaf(y1, c[4], c[5]));
+        const float den = __builtin_fmaf(a0, a0, __builtin_fmaf(a1, a1, __builtin_fmaf(r0, r0, r1 * r1)));
+        const float x = nn * nn, y = tf * den;
+        if (!(x <= y)) return 0u; // rejected (or not a number)
+        const float r = __fdividef(x, y); // in [0, 1], NaN for 0 / 0
+        return 1u + min(7u, (uint32_t)fmaxf((1.0f - r) * 8.0f, 0.0f));
+    };
+    for (uint32_t i = threadIdx.x; i < N; i += 1024u) atomicAdd(&total[error_class(matches[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { // class c starts where the classes before it end
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < REORDER_CLASSES; k++) {
+            cursor[k] = run;
+            run += total[k];
+        }
     }
     __syncthreads();
-    if ((threadIdx.x & 63) == 63) scratch[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t before = incl - rejected, total = 0;
-    for (uint32_t w = 0; w < 16; w++) {
-        if (w < (threadIdx.x >> 6)) before += scratch[w];
-        total += scratch[w];
-    }
     const uint32_t np = ransac_padded(N);
-    uint32_t out_pos = before, in_pos = total + (i0 - before);
-    for (uint32_t i = i0; i < i1; i++) {
+    for (uint32_t i = threadIdx.x; i < N; i += 1024u) {
         const uint4 v = matches[i];
-        const uint32_t pos = match_fits(f, v, t, t_hi, err) ? in_pos++ : out_pos++;
+        const uint32_t pos = atomicAdd(&cursor[error_class(v)], 1u);
         order_u32[pos] = v;
-        const uint32_t g = pos >> 7, r = pos & 127u, slot = 2u * (64u * g + (r & 63u)) + (r >> 6);
+        const uint32_t slot = ransac_plane_slot(pos);
         order_planes[slot] = (float)v.x;
         order_planes[np + slot] = (float)v.y;
         order_planes[2u * np + slot] = (float)v.z;
@@ -1091,7 +1110,11 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const dou
         }
     }
     __syncthreads();
-    if (s_replaced && order_u32) ransac_reorder_matches(best->f, matches, N, t, order_u32, order_planes, reinterpret_cast<uint32_t *>(errs));
+    // (best->pad: the best count the counting kernel's list was last ordered by; 0 = not yet)
+    if (s_replaced && order_u32 && (best->pad == 0u || top >= best->pad + max(best->pad >> 6, 1u))) {
+        ransac_reorder_matches(best->f, matches, N, t, order_u32, order_planes, reinterpret_cast<uint32_t *>(errs));
+        if (threadIdx.x == 0) best->pad = top;
+    }
 }
 
 // The live slots of a round's hypothesis buffer, in slot order (count, scan, scatter).  Depends on the hypotheses only,
@@ -2097,14 +2120,18 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // (one generator stream per round in flight: the LM tails of consecutive rounds - a couple of hundred waves each,
     // bound by their longest loop - then run side by side instead of queueing behind each other)
     constexpr uint32_t GEN_STREAMS = GEN_DEPTH - 1;
-    hipStream_t g[GEN_STREAMS] = {};
-    hipEvent_t ready[GEN_DEPTH] = {}, scored[GEN_DEPTH] = {}, uploaded = nullptr;
-    for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = hipStreamCreateWithFlags(&g[k], hipStreamNonBlocking);
+    static_assert(GEN_STREAMS == 2 && GEN_DEPTH == 3, "Device::RansacQueues holds two streams and three events of each kind");
+    Device::RansacQueues &rq = dev->d.rq; // (kept on the handle: created once)
+    for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++)
+        if (!rq.gen[k]) e = hipStreamCreateWithFlags(&rq.gen[k], hipStreamNonBlocking);
     for (uint32_t b = 0; b < GEN_DEPTH && e == hipSuccess; b++) {
-        e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&scored[b], hipEventDisableTiming);
+        if (!rq.ready[b]) e = hipEventCreateWithFlags(&rq.ready[b], hipEventDisableTiming);
+        if (e == hipSuccess && !rq.scored[b]) e = hipEventCreateWithFlags(&rq.scored[b], hipEventDisableTiming);
     }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&uploaded, hipEventDisableTiming);
+    if (e == hipSuccess && !rq.uploaded) e = hipEventCreateWithFlags(&rq.uploaded, hipEventDisableTiming);
+    hipStream_t *const g = rq.gen;
+    hipEvent_t *const ready = rq.ready, *const scored = rq.scored;
+    const hipEvent_t uploaded = rq.uploaded;
     if (e == hipSuccess) e = hipEventRecord(uploaded, s);
     for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = hipStreamWaitEvent(g[k], uploaded, 0);
     const auto generate_round = [&](uint32_t r) { // into buffer r % GEN_DEPTH, once its last reader (round r - GEN_DEPTH) is done
@@ -2157,13 +2184,6 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
             if (out_inlier_mask) std::memcpy(out_inlier_mask, h_mask.data(), N);
         }
     }
-    for (uint32_t b = 0; b < GEN_DEPTH; b++) {
-        if (ready[b]) (void)hipEventDestroy(ready[b]);
-        if (scored[b]) (void)hipEventDestroy(scored[b]);
-    }
-    if (uploaded) (void)hipEventDestroy(uploaded);
-    for (uint32_t k = 0; k < GEN_STREAMS; k++)
-        if (g[k]) (void)hipStreamDestroy(g[k]);
     if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
     return rc;
 }
