@@ -1136,7 +1136,9 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
                                       RansacBest *best, uint32_t *out_count, double *out_err_sum, hipStream_t s)
 {
     const uint4 *m4 = reinterpret_cast<const uint4 *>(matches);
-    (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
+    // (the device loops read the counts through the live list only, and the counting kernel writes every live slot when
+    // there is a match at all: only the entry point that hands ALL counts back needs the others zeroed)
+    if (!live_ready || N == 0) (void)hipMemsetAsync(out_count, 0, (size_t)H * sizeof(uint32_t), s);
     // (scratch of the compaction: out_err_sum's first words, until the count kernel overwrites them)
     if (!live_ready) launch_ransac_live(F, H, live, n_live, reinterpret_cast<uint32_t *>(out_err_sum), s);
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
@@ -2315,7 +2317,7 @@ extern "C" int cvhip_optimize_perspective_f(const double *F, const uint32_t *mat
 // vector.  tests/test_orb_ransac_gpu.py compares the result with the host function bit for bit.
 // ---------------------------------------------------------------------------------------------------------
 namespace refit {
-constexpr int THREADS = 1024;
+constexpr int THREADS = 512; // (28 dots x 8 chains = 224 of them carry the long phases; 512 leave 256 registers a thread)
 constexpr int MAX_DOTS = 49;
 struct DotJob {
     const double *a, *b;
@@ -2325,34 +2327,79 @@ struct Shared {
     double q[7], g[7], A0[49], step[7], trial[7];
     double parts[MAX_DOTS * 8], dotv[MAX_DOTS];
     DotJob jobs[MAX_DOTS];
-    int pair_a[28], pair_b[28];
     double mu, nu, rho;
     int action;
 };
 enum { CONTINUE = 0, DONE_TRUE = 1, DONE_FALSE = 2, ACCEPT = 3, ACCEPT_CONVERGED = 4, REJECT = 5 };
 
-// sh.dotv[d] = lm::long_dot(jobs[d].a, sa, jobs[d].b, sb, n) for d < nd
-__device__ void dots(Shared &sh, int nd, uint32_t n)
+// sh.dotv[d] = lm::long_dot(jobs[d].a, sa, jobs[d].b, sb, n) for d < nd <= 7 (g = J'r, and the two r.r of every iteration).
+// long_dot keeps eight partial sums (indices k, k + 8, ... in order): eight chains of dependent additions per dot, so only
+// 16 .. 56 lanes carry this phase; one lane per chain fetching its own strided operands block after block waited 57 us
+// per call for two dots of 19 000.  Here all threads load a tile of the factors with coalesced accesses - the NEXT tile's loads are
+// in flight while this one is added - and leave the products in LDS; the chain lanes add them from there in long_dot's
+// order.  prod: STAGE_DOUBLES doubles of LDS.
+constexpr uint32_t STAGE_DOUBLES = 4096 + 64;
+__device__ void dots_staged(Shared &sh, double *prod, int nd, uint32_t n)
 {
     __syncthreads(); // jobs written, operands complete
-    const uint32_t n8 = n & ~7u;
-    for (int c = (int)threadIdx.x; c < nd * 8; c += THREADS) {
-        const DotJob jb = sh.jobs[c >> 3];
-        double part = 0.0;
-        uint32_t i = (uint32_t)(c & 7);
-        // (the chain of additions is serial; its operands are not - sixteen products' loads in flight at a time)
-        for (; i + 8u * 15u < n8; i += 8u * 16u) {
-            double prod[16];
+    const uint32_t n8 = n & ~7u, tid = threadIdx.x;
+    const uint32_t rows = (4096u / (uint32_t)nd) & ~63u, pitch = rows + 8u; // rows of a tile; +8: the dots' rows start in different banks
+    const uint32_t per_tile = rows * (uint32_t)nd;
+    constexpr uint32_t PER_THREAD = 4096 / THREADS;
+    double fa[PER_THREAD], fb[PER_THREAD];
+    uint32_t at[PER_THREAD]; // where the element's product goes (~0u: the thread has no element there)
+    const auto load = [&](uint32_t base) {
 #pragma unroll
-            for (uint32_t u = 0; u < 16; u++) prod[u] = jb.a[(size_t)(i + 8u * u) * jb.sa] * jb.b[(size_t)(i + 8u * u) * jb.sb];
-#pragma unroll
-            for (uint32_t u = 0; u < 16; u++) part += prod[u];
+        for (uint32_t u = 0; u < PER_THREAD; u++) {
+            const uint32_t e = tid + THREADS * u, d = e / rows, k = e - d * rows, idx = base + k;
+            at[u] = ~0u;
+            if (e < per_tile && idx < n8) {
+                const DotJob jb = sh.jobs[d];
+                fa[u] = jb.a[(size_t)idx * jb.sa];
+                fb[u] = jb.b[(size_t)idx * jb.sb];
+                at[u] = d * pitch + k;
+            }
         }
-        for (; i < n8; i += 8) part += jb.a[(size_t)i * jb.sa] * jb.b[(size_t)i * jb.sb];
-        sh.parts[c] = part;
+    };
+    double part = 0.0;
+    if (n8) load(0);
+    for (uint32_t base = 0; base < n8; base += rows) {
+#pragma unroll
+        for (uint32_t u = 0; u < PER_THREAD; u++)
+            if (at[u] != ~0u) prod[at[u]] = fa[u] * fb[u];
+        __syncthreads();
+        if (base + rows < n8) load(base + rows);
+        if (tid < (uint32_t)nd * 8u) {
+            const double *mine = prod + (tid >> 3) * pitch + (tid & 7u);
+            const uint32_t steps = min(rows, n8 - base) >> 3;
+            // (sixteen products at a time, the next sixteen on their way from LDS while these are added: one dependent
+            // addition after the other is all the lane waits for)
+            constexpr uint32_t BATCH = 16;
+            double ba[BATCH], bb[BATCH]; // two batches, used in turn (no copies between them)
+            const auto fetch = [&](double (&into)[BATCH], uint32_t from) {
+#pragma unroll
+                for (uint32_t k = 0; k < BATCH; k++) into[k] = mine[8u * (from + k)];
+            };
+            uint32_t u = 0;
+            if (steps >= BATCH) fetch(ba, 0);
+            while (u + BATCH <= steps) {
+                if (u + 2u * BATCH <= steps) fetch(bb, u + BATCH);
+#pragma unroll
+                for (uint32_t k = 0; k < BATCH; k++) part += ba[k];
+                u += BATCH;
+                if (u + BATCH > steps) break;
+                if (u + 2u * BATCH <= steps) fetch(ba, u + BATCH);
+#pragma unroll
+                for (uint32_t k = 0; k < BATCH; k++) part += bb[k];
+                u += BATCH;
+            }
+            for (; u < steps; u++) part += mine[8u * u];
+        }
+        __syncthreads();
     }
+    if (tid < (uint32_t)nd * 8u) sh.parts[tid] = part;
     __syncthreads();
-    for (int d = (int)threadIdx.x; d < nd; d += THREADS) {
+    for (int d = (int)tid; d < nd; d += THREADS) {
         const DotJob jb = sh.jobs[d];
         double total = 0.0;
         for (uint32_t k = 0; k < 4; k++) total += sh.parts[d * 8 + k] + sh.parts[d * 8 + k + 4];
@@ -2372,7 +2419,7 @@ __device__ void evaluate(const double *at_lds, const uint4 *__restrict__ inl, ui
     }
 }
 // Jacobian at sh.q and g = J'res -> sh.g
-__device__ void linearise(Shared &sh, const uint4 *__restrict__ inl, uint32_t n, const double *res, double *J)
+__device__ void linearise(Shared &sh, double *stage, const uint4 *__restrict__ inl, uint32_t n, const double *res, double *J)
 {
     double at[7], M[9];
     for (int i = 0; i < 7; i++) at[i] = sh.q[i];
@@ -2384,29 +2431,65 @@ __device__ void linearise(Shared &sh, const uint4 *__restrict__ inl, uint32_t n,
         for (int j = 0; j < 7; j++) J[(size_t)j * n + i] = row[j];
     }
     if (threadIdx.x < 7) sh.jobs[threadIdx.x] = DotJob{J + (size_t)threadIdx.x * n, res, 1u, 1u};
-    dots(sh, 7, n);
+    dots_staged(sh, stage, 7, n);
     if (threadIdx.x < 7) sh.g[threadIdx.x] = sh.dotv[threadIdx.x];
     __syncthreads();
 }
-__device__ void normal_matrix(Shared &sh, uint32_t n, const double *J)
+// J'J.  a[i] * b[i] == b[i] * a[i]: entry (j, i) is entry (i, j) bit for bit, so 28 of the 49 dots are evaluated - by 224
+// chain lanes that would pull each of J's seven columns through one CU's L1 eight times over (75 us per call).
+// Instead a tile of the seven columns is loaded ONCE into LDS by all threads (the next tile's loads in flight meanwhile)
+// and the chain lanes form their products from there: long_dot's products, long_dot's additions, in its order.
+__device__ void normal_matrix(Shared &sh, double *stage, uint32_t n, const double *J)
 {
-    // a[i] * b[i] == b[i] * a[i]: entry (j, i) of J'J is entry (i, j) bit for bit, so 28 of the 49 dots are evaluated
-    if (threadIdx.x < 28) {
-        int a = 0, rem = (int)threadIdx.x; // pair number -> (a, b), a <= b
+    constexpr uint32_t ROWS = THREADS, PITCH = ROWS + 8u; // one row of the tile per thread; 7 * PITCH <= STAGE_DOUBLES
+    static_assert(7u * PITCH <= STAGE_DOUBLES, "the stage holds a tile of seven columns");
+    const uint32_t n8 = n & ~7u, tid = threadIdx.x;
+    int a = 0, b = 0;
+    if (tid < 28u * 8u) { // pair number -> (a, b), a <= b
+        int rem = (int)(tid >> 3);
         while (rem >= 7 - a) {
             rem -= 7 - a;
             a++;
         }
-        const int b = a + rem;
-        sh.jobs[threadIdx.x] = DotJob{J + (size_t)a * n, J + (size_t)b * n, 1u, 1u};
-        sh.pair_a[threadIdx.x] = a;
-        sh.pair_b[threadIdx.x] = b;
+        b = a + rem;
     }
-    dots(sh, 28, n);
-    if (threadIdx.x < 28) {
-        const int a = sh.pair_a[threadIdx.x], b = sh.pair_b[threadIdx.x];
-        sh.A0[a * 7 + b] = sh.dotv[threadIdx.x];
-        sh.A0[b * 7 + a] = sh.dotv[threadIdx.x];
+    __syncthreads(); // J complete; the stage is free
+    double col[7], part = 0.0;
+    const auto load = [&](uint32_t base) {
+        if (base + tid < n8) {
+#pragma unroll
+            for (int c = 0; c < 7; c++) col[c] = J[(size_t)c * n + base + tid];
+        }
+    };
+    if (n8) load(0);
+    for (uint32_t base = 0; base < n8; base += ROWS) {
+        if (base + tid < n8) {
+#pragma unroll
+            for (int c = 0; c < 7; c++) stage[c * PITCH + tid] = col[c];
+        }
+        __syncthreads();
+        if (base + ROWS < n8) load(base + ROWS);
+        if (tid < 28u * 8u) {
+            const double *ca = stage + a * PITCH + (tid & 7u), *cb = stage + b * PITCH + (tid & 7u);
+            const uint32_t steps = min(ROWS, n8 - base) >> 3;
+            for (uint32_t u = 0; u < steps; u++) part += ca[8u * u] * cb[8u * u];
+        }
+        __syncthreads();
+    }
+    if (tid < 28u * 8u) sh.parts[tid] = part;
+    __syncthreads();
+    if (tid < 28u) {
+        int pa = 0, rem = (int)tid;
+        while (rem >= 7 - pa) {
+            rem -= 7 - pa;
+            pa++;
+        }
+        const int pb = pa + rem;
+        double total = 0.0;
+        for (uint32_t k = 0; k < 4; k++) total += sh.parts[tid * 8 + k] + sh.parts[tid * 8 + k + 4];
+        for (uint32_t i = n8; i < n; i++) total += J[(size_t)pa * n + i] * J[(size_t)pb * n + i];
+        sh.A0[pa * 7 + pb] = total;
+        sh.A0[pb * 7 + pa] = total;
     }
     __syncthreads();
 }
@@ -2427,16 +2510,17 @@ __global__ __launch_bounds__(refit::THREADS) void ransac_refit_kernel(const uint
 {
     using namespace refit;
     __shared__ Shared sh;
+    __shared__ double stage[STAGE_DOUBLES];
     const bool lead = threadIdx.x == 0;
     if (threadIdx.x < 7) sh.q[threadIdx.x] = F_in[threadIdx.x]; // params_from_perspective_f, :429-440
     __syncthreads();
     evaluate(sh.q, inl, n, r);
     __syncthreads();
-    linearise(sh, inl, n, r, J);
+    linearise(sh, stage, inl, n, r, J);
     bool found = false, failed = false;
     if (fabs(largest7(sh.g)) <= 1e-12) found = true; // (every thread reads the same values)
     if (!found) {
-        normal_matrix(sh, n, J);
+        normal_matrix(sh, stage, n, J);
         if (lead) {
             double mu = 0.0;
             for (int j = 0; j < 7; j++) {
@@ -2483,7 +2567,7 @@ __global__ __launch_bounds__(refit::THREADS) void ransac_refit_kernel(const uint
                 sh.jobs[0] = DotJob{r, r, 1u, 1u};
                 sh.jobs[1] = DotJob{r_new, r_new, 1u, 1u};
             }
-            dots(sh, 2, n);
+            dots_staged(sh, stage, 2, n);
             if (lead) {
                 const double before = sh.dotv[0], after = sh.dotv[1];
                 double step[7], damped[7];
@@ -2509,12 +2593,12 @@ __global__ __launch_bounds__(refit::THREADS) void ransac_refit_kernel(const uint
             if (action != REJECT) {
                 for (uint32_t i = threadIdx.x; i < n; i += THREADS) r[i] = r_new[i];
                 __syncthreads();
-                linearise(sh, inl, n, r, J);
+                linearise(sh, stage, inl, n, r, J);
                 if (action == ACCEPT_CONVERGED || fabs(largest7(sh.g)) <= 1e-12) {
                     found = true;
                     break;
                 }
-                normal_matrix(sh, n, J); // J changed: J'J for the next iteration
+                normal_matrix(sh, stage, n, J); // J changed: J'J for the next iteration
                 if (lead) {
                     const double w = 2.0 * sh.rho - 1.0, shrink = 1.0 - w * w * w;
                     sh.mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
