@@ -1874,6 +1874,48 @@ __global__ void ransac_inlier_mask_kernel(const RansacBest *__restrict__ best, c
     mask[i] = (fabs(err) < __builtin_inf() && !(fabs(err) > t)) ? 1 : 0; // optimize_result, :231-239
 }
 
+// ---- optimize_result's tail (:233-254) without leaving the device: the winner's inliers in list order, the refit on
+// them (ransac_refit_kernel), the inliers of the refitted matrix.  One workgroup of 1024 threads compacts (the order is
+// the refit's summation order, so it is the list's).
+__global__ __launch_bounds__(1024) void ransac_compact_inliers_kernel(const uint8_t *__restrict__ mask, const uint4 *__restrict__ matches,
+                                                                       uint32_t N, uint4 *__restrict__ inliers, uint32_t *__restrict__ n_out)
+{
+    __shared__ uint32_t wave_total[16];
+    const uint32_t chunk = (N + 1023u) / 1024u, i0 = min(threadIdx.x * chunk, N), i1 = min(i0 + chunk, N);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; i++) mine += mask[i] ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, sft, 64);
+        if ((threadIdx.x & 63) >= (uint32_t)sft) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wave_total[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t at = incl - mine, total = 0;
+    for (uint32_t w = 0; w < 16; w++) {
+        if (w < (threadIdx.x >> 6)) at += wave_total[w];
+        total += wave_total[w];
+    }
+    for (uint32_t i = i0; i < i1; i++)
+        if (mask[i]) inliers[at++] = matches[i];
+    if (threadIdx.x == 0) *n_out = total;
+}
+// fits_model of the refitted matrix as optimize_result's second filter evaluates it (:248-254; the arithmetic of the
+// host loop it replaces: lm::residual_of)
+__global__ void ransac_refit_mask_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches, uint32_t N, double t,
+                                         uint8_t *__restrict__ mask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double M[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) M[k] = F[k];
+    const uint4 m = matches[i];
+    const double err = lm::residual_of(M, lm::make_obs(m.x, m.y, m.z, m.w));
+    mask[i] = (fabs(err) < __builtin_inf() && !(fabs(err) > t)) ? 1 : 0;
+}
+
 } // namespace cvhip
 
 using namespace cvhip;
@@ -2072,11 +2114,15 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
 
 // Shared driver of the two RANSAC models: rounds of `per_round` samples x `slots` hypotheses each.
 namespace {
+// optimize_result's tail on the device (defined behind ransac_refit_kernel): d_mask holds the winner's inlier mask on entry
+// and the refitted matrix' on return, d_F_out [9] the refitted matrix (the winner itself where the refit declines)
+hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double t, uint8_t *d_mask, const double *d_F_in,
+                             double *d_F_out, hipStream_t s);
 constexpr uint32_t GEN_DEPTH = 3; // hypothesis buffers: the round being scored + the two being generated
 template <typename Generate>
 int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
                   double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
-                  uint8_t *out_inlier_mask, const char *what, Generate generate)
+                  uint8_t *out_inlier_mask, const char *what, bool refit_tail, Generate generate)
 {
     hipStream_t s = dev->d.stream;
     const uint32_t H = per_round * slots;
@@ -2176,6 +2222,12 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         std::memcpy(out_F, h_best.f, sizeof(h_best.f));
         hipLaunchKernelGGL(ransac_inlier_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_best, m4, N, t, d_mask);
         e = hipGetLastError();
+        double *d_Fo = nullptr;
+        if (refit_tail) { // optimize_result (:246-254) right behind it, without a round trip through the host
+            if (e == hipSuccess) e = mem.alloc(&d_Fo, 9);
+            if (e == hipSuccess) e = launch_refit_tail(mem, m4, N, t, d_mask, reinterpret_cast<const double *>(d_best), d_Fo, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_F, d_Fo, 9 * sizeof(double), hipMemcpyDeviceToHost, s);
+        }
         std::vector<uint8_t> h_mask(N);
         if (e == hipSuccess) e = hipMemcpyAsync(h_mask.data(), d_mask, N, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -2191,9 +2243,10 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
 }
 } // namespace
 
-extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension,
-                                        uint64_t seed, uint32_t rounds, double *out_F, uint32_t *out_inlier_count,
-                                        uint8_t *out_inlier_mask)
+namespace {
+// refit_tail: optimize_result's refit and second inlier filter (:246-254) follow on the device (cvhip_find_ransac)
+int ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension, uint64_t seed, uint32_t rounds,
+                       double *out_F, uint32_t *out_inlier_count, uint8_t *out_inlier_mask, bool refit_tail)
 {
     // constants of the perspective model, fundamentalmatrix.rs:16-30
     constexpr uint32_t RANSAC_K = 1000000, CHECK_INTERVAL = 50000, RANSAC_N = 7, RANSAC_D = 200, EARLY_EXIT = 50000,
@@ -2211,13 +2264,21 @@ extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *match
     char *d_gen = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_gen, GEN_DEPTH * gen_bytes));
     const int rc = ransac_rounds(dev, mem, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
-                                 out_inlier_count, out_inlier_mask, "ransac_perspective",
+                                 out_inlier_count, out_inlier_mask, "ransac_perspective", refit_tail,
                                  [&](const uint4 *m4, uint32_t round, int buffer, double *d_F, hipStream_t s) {
                                      PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
                                      launch_generate_perspective(m4, limit, t, (unsigned long long)seed, round, CHECK_INTERVAL,
                                                                  nullptr, pencils, (uint32_t *)(pencils + CHECK_INTERVAL), d_F, s);
                                  });
     return rc;
+}
+} // namespace
+
+extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension,
+                                        uint64_t seed, uint32_t rounds, double *out_F, uint32_t *out_inlier_count,
+                                        uint8_t *out_inlier_mask)
+{
+    return ransac_perspective(dev, matches, N, max_dimension, seed, rounds, out_F, out_inlier_count, out_inlier_mask, false);
 }
 
 // Test hooks of the two generators: the models of B caller-chosen samples (`per` match indices each).
@@ -2504,11 +2565,14 @@ __device__ double largest7(const double *v)
 
 // inl: the n inliers; r, r_new [n], J [7 x n, column by column]: workspace; F_in: the winner (F[8] = 1); F_out / refined as
 // cvhip_optimize_perspective_f
-__global__ __launch_bounds__(refit::THREADS) void ransac_refit_kernel(const uint4 *__restrict__ inl, uint32_t n, double *r,
-                                                                       double *r_new, double *J, const double *F_in,
+// n_dev (optional): the number of inliers where only the device knows it (the device loops' tail); J is then laid out
+// for that n as well
+__global__ __launch_bounds__(refit::THREADS) void ransac_refit_kernel(const uint4 *__restrict__ inl, uint32_t n, const uint32_t *__restrict__ n_dev,
+                                                                       double *r, double *r_new, double *J, const double *F_in,
                                                                        double *F_out, int *refined)
 {
     using namespace refit;
+    if (n_dev) n = *n_dev;
     __shared__ Shared sh;
     __shared__ double stage[STAGE_DOUBLES];
     const bool lead = threadIdx.x == 0;
@@ -2644,8 +2708,8 @@ extern "C" int cvhip_optimize_perspective_f_device(cvhip_device *dev, const doub
     CVHIP_TRY_HIP(mem.alloc(&d_ref, 1));
     if (n) CVHIP_TRY_HIP(hipMemcpyAsync(d_inl, matches, (size_t)n * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     CVHIP_TRY_HIP(hipMemcpyAsync(d_F, F, 9 * sizeof(double), dev_ptr(F) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(ransac_refit_kernel, dim3(1), dim3(refit::THREADS), 0, s, reinterpret_cast<const uint4 *>(d_inl), n, d_r, d_rn,
-                       d_J, (const double *)d_F, d_F + 9, d_ref);
+    hipLaunchKernelGGL(ransac_refit_kernel, dim3(1), dim3(refit::THREADS), 0, s, reinterpret_cast<const uint4 *>(d_inl), n,
+                       (const uint32_t *)nullptr, d_r, d_rn, d_J, (const double *)d_F, d_F + 9, d_ref);
     CVHIP_TRY_HIP(hipGetLastError());
     double h_F[9];
     int h_ref = 0;
@@ -2656,6 +2720,28 @@ extern "C" int cvhip_optimize_perspective_f_device(cvhip_device *dev, const doub
     *out_refined = h_ref;
     return CVHIP_OK;
 }
+
+namespace {
+hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double t, uint8_t *d_mask, const double *d_F_in,
+                             double *d_F_out, hipStream_t s)
+{
+    uint32_t *d_inl = nullptr, *d_n = nullptr;
+    double *d_r = nullptr, *d_rn = nullptr, *d_J = nullptr;
+    int *d_ref = nullptr;
+    hipError_t e = mem.alloc(&d_inl, (size_t)N * 4);
+    if (e == hipSuccess) e = mem.alloc(&d_n, 1);
+    if (e == hipSuccess) e = mem.alloc(&d_r, N);
+    if (e == hipSuccess) e = mem.alloc(&d_rn, N);
+    if (e == hipSuccess) e = mem.alloc(&d_J, (size_t)N * 7);
+    if (e == hipSuccess) e = mem.alloc(&d_ref, 1);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ransac_compact_inliers_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)d_mask, m4, N, reinterpret_cast<uint4 *>(d_inl), d_n);
+    hipLaunchKernelGGL(ransac_refit_kernel, dim3(1), dim3(refit::THREADS), 0, s, reinterpret_cast<const uint4 *>(d_inl), 0u,
+                       (const uint32_t *)d_n, d_r, d_rn, d_J, d_F_in, d_F_out, d_ref);
+    hipLaunchKernelGGL(ransac_refit_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const double *)d_F_out, m4, N, t, d_mask);
+    return hipGetLastError();
+}
+} // namespace
 
 // fits_model (:452-458) of one F for every match: the inlier filter of optimize_result (:233-236, 248-254).
 extern "C" int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32_t *matches, uint32_t N, double t,
@@ -2711,38 +2797,9 @@ extern "C" int cvhip_find_ransac(cvhip_device *dev, int projection, const uint32
     if (projection == 0) return cvhip_ransac_affine(dev, matches, N, seed, out_F, out_inlier_count, out_inlier_mask);
     if (!dev || !matches || !out_F) return fail(CVHIP_ERR_INVALID, "null argument");
     try {
-        std::vector<uint32_t> host_m;
-        const uint32_t *hm = matches;
-        if (dev_ptr(matches)) { // the refit is host arithmetic: it needs the inliers on the host
-            host_m.resize((size_t)N * 4);
-            CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
-            CVHIP_TRY_HIP(hipMemcpy(host_m.data(), matches, (size_t)N * 16, hipMemcpyDeviceToHost));
-            hm = host_m.data();
-        }
-        std::vector<uint8_t> mask(N ? N : 1);
-        uint32_t cnt = 0;
-        double F0[9];
-        CVHIP_TRY(cvhip_ransac_perspective(dev, matches, N, max_dimension, seed, 0, F0, &cnt, mask.data()));
-        std::vector<uint32_t> inl;
-        inl.reserve((size_t)cnt * 4);
-        for (uint32_t i = 0; i < N; i++)
-            if (mask[i]) inl.insert(inl.end(), hm + 4 * (size_t)i, hm + 4 * (size_t)i + 4);
-        int refined = 0;
-        CVHIP_TRY(cvhip_optimize_perspective_f_device(dev, F0, inl.data(), (uint32_t)(inl.size() / 4), out_F, &refined)); // :246
-        // :248-254 - the inliers of the refitted matrix (of F0 itself where the refit returned None)
-        const double t = 10.0 / 1000.0 * max_dimension;
-        uint32_t n_in = 0;
-        for (uint32_t i = 0; i < N; i++) { // fits_model on the host: N <= a few 10^4, once
-            const lm::Obs o = lm::make_obs(hm[4 * (size_t)i], hm[4 * (size_t)i + 1], hm[4 * (size_t)i + 2], hm[4 * (size_t)i + 3]);
-            double M[9];
-            for (int k = 0; k < 9; k++) M[k] = out_F[k];
-            const double err = lm::residual_of(M, o);
-            const bool in = std::fabs(err) < __builtin_inf() && !(std::fabs(err) > t);
-            if (out_inlier_mask) out_inlier_mask[i] = in ? 1 : 0;
-            n_in += in ? 1u : 0u;
-        }
-        if (out_inlier_count) *out_inlier_count = n_in;
-        return CVHIP_OK;
+        // the RANSAC rounds, the winner's inliers, optimize_result's refit on them (:246) and the inliers of the refitted
+        // matrix (:248-254; of the winner itself where the refit returns None): one enqueue, one read-back
+        return ransac_perspective(dev, matches, N, max_dimension, seed, 0, out_F, out_inlier_count, out_inlier_mask, true);
     } catch (const std::bad_alloc &) {
         return cvhip::fail(CVHIP_ERR_NOMEM, "cvhip_find_ransac: out of host memory");
     }

@@ -18,5 +18,5 @@ for r in rows[i0:]:
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cvhip::", "")
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
     print(f"{s:9.1f} {e:9.1f} {e - s:8.1f}  q{r.get('Queue_Id', '?'):>3s}  {name[:60]}")
-    if "ransac_inlier_mask_kernel" in name or "refit" in name and e > 20000:
+    if "ransac_coord_max_kernel" in name and s > 0:
         break
