@@ -25,6 +25,9 @@ SOURCES = ["cvhip_api.hip", "corr_kernels.hip", "orb_kernels.hip", "ransac_kerne
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    # no SLP vectorisation: it packs adjacent f32 operations into v_pk_*_f32, which this chip issues at half the rate of
+    # the two plain instructions they replace (measured on ransac_count_kernel: 8.8 pipe-cycles per packed instruction)
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function",
 ]
 LINK = ["-ldl", "-pthread"]  # cvhip_rccl.hip opens librccl.so.1 lazily (dlopen): no link-time dependency on RCCL

@@ -659,6 +659,7 @@ __device__ __forceinline__ float wave_uniform(float v)
 // Everything per hypothesis is wave-uniform and - the wave index being made a SCALAR with readfirstlane - lives in
 // scalar registers: coefficients, bounds, the running count, the alive flag; the loop's branches are scalar branches
 // and the lane masks of the tests stay SGPR pairs.
+constexpr uint32_t TIED_CAP = 4096; // hypotheses at the round's maximum count that get an ordered error sum (usually 1)
 constexpr int COUNT_K = 2;
 __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
                                                             uint32_t N, double t, const uint32_t *__restrict__ live,
@@ -667,12 +668,16 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
                                                             const uint32_t *__restrict__ coord_max,
                                                             const float4 *__restrict__ matches_f32,
                                                             uint32_t *__restrict__ out_count,
-                                                            double *__restrict__ out_err_sum)
+                                                            double *__restrict__ out_err_sum, uint32_t *__restrict__ cand)
 {
+    // cand (the device loops; optional): [0] the largest count completed so far in this launch, [1] the number of
+    // candidates, then (slot, count) pairs - every hypothesis whose count was at least the largest seen when it finished,
+    // which includes everyone at the final maximum.  The running maximum also raises the abandonment bound: a hypothesis
+    // that cannot reach a count somebody already HAS cannot be the round's winner, nor tie with it.
     const uint32_t n_hyp = *n_live, lane = threadIdx.x & 63;
     const uint32_t j0 = (blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * COUNT_K;
     if (j0 >= n_hyp || N == 0) return; // (an empty list: the counts stay at the zeros they were cleared to)
-    const uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
+    uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
     const double t_hi = t * (1.0 + 0x1p-40);
     const double W = (double)*coord_max, u = 0x1p-24;
     const float T_f = wave_uniform((float)t);
@@ -720,6 +725,10 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
         // (the last step loads itself again: no branch, nothing read past the end)
         const uint32_t qn = ((base + COUNT_GROUP < N ? base + COUNT_GROUP : base) >> 2) + lane;
         const float4 n1x = px1[qn], n1y = py1[qn], n2x = px2[qn], n2y = py2[qn];
+        // (the running maximum as of now, for the next step's test - looked at every eighth step only: it is ONE word that
+        // every wave of the launch reads past its L1, and at every step the L2 channel that holds it was the bottleneck)
+        uint32_t running = 0;
+        if (cand && ((base / COUNT_GROUP) & 7u) == 7u) running = __hip_atomic_load(&cand[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the ragged last group: lanes past the end count for nothing
         unsigned long long valid[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         if (base + COUNT_GROUP > N) {
@@ -769,18 +778,32 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
             }
         }
         p1x = n1x, p1y = n1y, p2x = n2x, p2y = n2y;
+        bound = max(bound, (uint32_t)__builtin_amdgcn_readfirstlane((int)running));
     }
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < COUNT_K; k++)
             if (j0 + k < n_hyp) {
-                out_count[slot[k]] = alive[k] ? count[k] : 0u;
+                const uint32_t final_count = alive[k] ? count[k] : 0u;
+                out_count[slot[k]] = final_count;
                 out_err_sum[slot[k]] = 0.0;
+                // (a look before the atomic: same-address atomics queue up in L2 - 25 000 of them cost round 0 a quarter of a
+                // millisecond - and all but a few dozen hypotheses are below the maximum that is already there)
+                if (cand && final_count >= max(min_count, 1u) &&
+                    final_count >= __hip_atomic_load(&cand[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    const uint32_t seen = atomicMax(&cand[0], final_count);
+                    if (final_count >= seen) {
+                        const uint32_t at = atomicAdd(&cand[1], 1u);
+                        if (at < TIED_CAP) {
+                            cand[2 + 2 * at] = slot[k];
+                            cand[3 + 2 * at] = final_count;
+                        }
+                    }
+                }
             }
     }
 }
 
-constexpr uint32_t TIED_CAP = 4096; // hypotheses at the round's maximum count that get an ordered error sum (usually 1)
 
 // the round's largest count, and the list of the live hypotheses that have it: tied[0] = their number, then the slots
 __global__ __launch_bounds__(1024) void ransac_round_max_kernel(const uint32_t *__restrict__ counts,
@@ -927,15 +950,15 @@ __device__ double block_ordered_sum(const double (&f)[9], const uint4 *__restric
     return *result;
 }
 
-__global__ __launch_bounds__(1024) void ransac_tied_approx_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
-                                                                   uint32_t N, double t, const uint32_t *__restrict__ tied,
-                                                                   RansacBest *best, double *__restrict__ out_err_sum)
+__device__ void ransac_tied_approx(const double *__restrict__ F, const uint4 *__restrict__ matches, uint32_t N, double t,
+                                   const uint32_t *tied, RansacBest *best, double *__restrict__ out_err_sum, uint32_t block,
+                                   uint32_t blocks)
 {
     __shared__ double scratch[16];
     if (tied[0] == 0u || tied[0] > TIED_CAP || !ransac_round_needs_errors(tied, best)) return;
     const uint32_t n_items = tied[0], top = tied[1 + TIED_CAP];
     const uint32_t n_all = n_items + ((best->valid && top == best->matches_count && !best->err_known) ? 1u : 0u);
-    for (uint32_t b = blockIdx.x; b < n_all; b += gridDim.x) {
+    for (uint32_t b = block; b < n_all; b += blocks) {
         const bool carried = b == n_items;
         const uint32_t h = carried ? 0u : tied[1 + b];
         double f[9];
@@ -952,6 +975,12 @@ __global__ __launch_bounds__(1024) void ransac_tied_approx_kernel(const double *
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(1024) void ransac_tied_approx_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                                   uint32_t N, double t, const uint32_t *__restrict__ tied,
+                                                                   RansacBest *best, double *__restrict__ out_err_sum)
+{
+    ransac_tied_approx(F, matches, N, t, tied, best, out_err_sum, blockIdx.x, gridDim.x);
 }
 
 // The counting kernel's copy of the match list, reordered whenever the best hypothesis changes: the matches the best
@@ -1014,11 +1043,9 @@ __device__ void ransac_reorder_matches(const double *best_f, const uint4 *__rest
     }
 }
 
-__global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
-                                                                        uint32_t N, double t, const uint32_t *__restrict__ counts,
-                                                                        double *__restrict__ err_sums, uint32_t min_count,
-                                                                        const uint32_t *__restrict__ tied, RansacBest *best,
-                                                                        uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+__device__ void ransac_pick_best_approx(const double *__restrict__ F, const uint4 *__restrict__ matches, uint32_t N, double t,
+                                        double *__restrict__ err_sums, uint32_t min_count, const uint32_t *tied,
+                                        RansacBest *best, uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
 {
     __shared__ double errs[1024];
     __shared__ uint32_t s_replaced;
@@ -1116,6 +1143,50 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const dou
         if (threadIdx.x == 0) best->pad = top;
     }
 }
+__global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                                        uint32_t N, double t, const uint32_t *__restrict__ counts,
+                                                                        double *__restrict__ err_sums, uint32_t min_count,
+                                                                        const uint32_t *__restrict__ tied, RansacBest *best,
+                                                                        uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+{
+    (void)counts;
+    ransac_pick_best_approx(F, matches, N, t, err_sums, min_count, tied, best, order_u32, order_planes);
+}
+
+// The device loops' round end in ONE launch behind the counting kernel: the round's maximum list from the counting
+// kernel's candidates (its own atomic maximum, and whoever reached it), the tie-break sums where they decide, the pick, the
+// reordering of the counting list.  Three launches and their gaps less on a chain of twenty rounds (~30 us each).
+// cand: as ransac_count_kernel leaves it, cleared here for the next round; tied: [2 + TIED_CAP] words of workspace.
+__global__ __launch_bounds__(1024) void ransac_round_finish_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                                    uint32_t N, double t, double *__restrict__ err_sums,
+                                                                    uint32_t min_count, uint32_t *__restrict__ cand,
+                                                                    uint32_t *tied, RansacBest *best,
+                                                                    uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+{
+    if (threadIdx.x == 0) {
+        const uint32_t top = cand[0], listed = cand[1];
+        uint32_t n = 0;
+        if (listed > TIED_CAP) {
+            n = TIED_CAP + 1u; // (never seen: more record holders than the list takes; the round is skipped, as above)
+        } else {
+            for (uint32_t i = 0; i < listed; i++)
+                if (cand[3 + 2 * i] == top) { // insertion by slot: the list's order does not depend on who finished first
+                    const uint32_t h = cand[2 + 2 * i];
+                    uint32_t at = n++;
+                    for (; at > 0 && tied[at] > h; at--) tied[1 + at] = tied[at];
+                    tied[1 + at] = h;
+                }
+        }
+        tied[0] = n;
+        tied[1 + TIED_CAP] = top;
+        cand[0] = 0u;
+        cand[1] = 0u;
+    }
+    __syncthreads();
+    ransac_tied_approx(F, matches, N, t, tied, best, err_sums, 0u, 1u);
+    __syncthreads();
+    ransac_pick_best_approx(F, matches, N, t, err_sums, min_count, tied, best, order_u32, order_planes);
+}
 
 // The live slots of a round's hypothesis buffer, in slot order (count, scan, scatter).  Depends on the hypotheses only,
 // so the device loops run it on the GENERATOR's stream right behind the generation - off the scoring chain.
@@ -1133,7 +1204,7 @@ static void launch_ransac_live(const double *F, uint32_t H, uint32_t *live, uint
 static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_t *matches, const uint32_t *count_matches, const float4 *matches_f32,
                                       uint32_t N, double t, uint32_t *live, uint32_t *n_live, uint32_t *tied,
                                       const uint32_t *coord_max, bool live_ready, bool approx_sums, uint32_t min_count,
-                                      RansacBest *best, uint32_t *out_count, double *out_err_sum, hipStream_t s)
+                                      RansacBest *best, uint32_t *out_count, double *out_err_sum, hipStream_t s, uint32_t *cand = nullptr)
 {
     const uint4 *m4 = reinterpret_cast<const uint4 *>(matches);
     // (the device loops read the counts through the live list only, and the counting kernel writes every live slot when
@@ -1144,7 +1215,8 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
     // (count_matches / matches_f32: the counting kernel's own copy of the list - same matches, any order)
     hipLaunchKernelGGL(ransac_count_kernel, dim3((H + 4 * COUNT_K - 1) / (4 * COUNT_K)), dim3(256), 0, s, F, reinterpret_cast<const uint4 *>(count_matches), N, t, (const uint32_t *)live,
-                       (const uint32_t *)n_live, min_count, (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum);
+                       (const uint32_t *)n_live, min_count, (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum, cand);
+    if (cand) return; // the device loops: ransac_round_finish_kernel takes it from the candidates
     hipLaunchKernelGGL(ransac_round_max_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)out_count, (const uint32_t *)live,
                        (const uint32_t *)n_live, min_count, tied);
     if (approx_sums) // the device loops: parallel sums now, the ordered fold inside ransac_pick_best_approx_kernel where it decides
@@ -2146,6 +2218,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     uint32_t *d_mo = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_mf, ransac_padded(N));
     if (e == hipSuccess) e = mem.alloc(&d_mo, (size_t)N * 4);
+    uint32_t *d_cand = nullptr; // the counting kernel's running maximum and candidate list (ransac_round_finish_kernel clears it per round)
+    if (e == hipSuccess) e = mem.alloc(&d_cand, 2 + 2 * (size_t)TIED_CAP);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cand, 0, 2 * sizeof(uint32_t), s);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
@@ -2200,9 +2275,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
         uint32_t *lv = d_live + (size_t)b * live_words;
-        launch_ransac_score_round(F_round, H, d_m, d_mo, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err, s);
-        hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)d_cnt, d_err,
-                           min_count, (const uint32_t *)d_tied, d_best, reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+        launch_ransac_score_round(F_round, H, d_m, d_mo, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err, s, d_cand);
+        hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
+                           reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(scored[b], s);
         if (!may_exit_early && !g_listener.wants_counts() && round + 1 < rounds) {
