@@ -7,12 +7,13 @@
 //  * ransac_score_kernel: the all-matches fold of validate_f (:210-216) with fits_model / reprojection_error
 //    (:452-471) for a batch of hypotheses, one lane per hypothesis, count and ordered error sum bit-identical to
 //    --mode=cpu (cvhip_ransac_score);
-//  * a ROUND's scoring as the device loops run it: live-slot compaction, ransac_count_kernel (one wave per hypothesis;
-//    packed-f32 screen with rigorous bounds, f64 in the guard band: exact counts), the round's maximum, ordered sums
-//    only where a tie in the count needs them, Ord (:623-649) as a reduction;
+//  * a ROUND's scoring as the device loops run it: live-slot compaction, ransac_count_kernel (one wave per two
+//    hypotheses; f32 screen with rigorous bounds, f64 in the guard band: exact counts; its own copy of the match list in
+//    the order that abandons hopeless hypotheses soonest), ransac_round_finish_kernel (the round's maximum, tie-break
+//    sums only where a tie in the count needs them, Ord (:623-649) as a reduction, the re-sort);
 //  * the generators: affine (4-point, one-sided Jacobi SVD) and perspective (7-point pencil / root / queued LM);
-//  * ransac_rounds: generation two rounds ahead of scoring on separate streams; ransac_refit_kernel: optimize_result's
-//    refit (:246) on one workgroup, bit-equal to the host loop;
+//  * ransac_rounds: generation two rounds ahead of scoring on separate streams; optimize_result's tail on the device:
+//    inlier compaction, ransac_refit_kernel (the refit, :246, on one workgroup, bit-equal to the host loop), second filter;
 //  * the C entry points (include/cvhip.h).
 // f64 throughout except the screen, contraction off; expression order follows nalgebra 0.35's
 // published gemv / dot algorithms (column-by-column axpy; 3-vector dot = (a0*b0 + a1*b1) + a2*b2).
@@ -628,8 +629,10 @@ __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__r
     }
 }
 
-// The counting kernel decides most (hypothesis, match) pairs in PACKED f32 - two matches per lane and instruction,
-// fused multiply-adds allowed because nothing here is a result: the f32 values of n and of the denominator come with
+// The counting kernel decides most (hypothesis, match) pairs in f32 - plain v_fma_f32, four matches per lane and step
+// (packed f32 was tried first: a v_pk_fma_f32 holds the SIMD for ~8.8 cycles against 4 for each of the two plain
+// instructions it replaces) - with fused multiply-adds allowed because nothing here is a
+// result: the f32 values of n and of the denominator come with
 // rigorous error bounds (below), "certainly an inlier" / "certainly not" are decided against those, and only a pair
 // that falls inside the guard band (~1e-4 of them) is evaluated with the reference's f64 expression (match_fits).
 // The count is therefore exactly the f64 count.
@@ -652,13 +655,13 @@ __device__ __forceinline__ float wave_uniform(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-// COUNT_K live hypotheses per wave.  Measured on one box (config 5's RANSAC stage, ms): one hypothesis per wave 45.7,
-// two 42.6, four 46.6 (registers: 90 VGPRs and 5 waves per SIMD at two).  The counters say the vector ALU is what
-// the kernel waits for most (busy 0.66 of the time), the rest is the latency of the match list's loads (a wave streams
-// its 464 KB from L2 for every pair of hypotheses): the list is therefore loaded one step AHEAD of the arithmetic.
-// Everything per hypothesis is wave-uniform and - the wave index being made a SCALAR with readfirstlane - lives in
-// scalar registers: coefficients, bounds, the running count, the alive flag; the loop's branches are scalar branches
-// and the lane masks of the tests stay SGPR pairs.
+// COUNT_K live hypotheses per wave (config 5's RANSAC stage, packed-f32 form, ms: one per wave 45.7, two 42.6, four 46.6 -
+// the match list is streamed from L2 once per wave, two hypotheses share it, four cost too many registers).  The kernel
+// is bound by vector issue (SQ_ACTIVE_INST_VALU 0.92 - 0.98 of its cycles in this form), so what counts is the number
+// of vector instructions per pair: 23.  Everything per hypothesis is wave-uniform and - the wave index being made a
+// SCALAR with readfirstlane - lives in scalar registers where the compiler allows: bounds, the running count, the alive
+// flag; the loop's branches are scalar branches and the lane masks of the tests stay SGPR pairs.  The list is loaded
+// one step AHEAD of the arithmetic.
 constexpr uint32_t TIED_CAP = 4096; // hypotheses at the round's maximum count that get an ordered error sum (usually 1)
 constexpr int COUNT_K = 2;
 __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
