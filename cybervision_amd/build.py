@@ -25,11 +25,13 @@ SOURCES = ["cvhip_api.hip", "corr_kernels.hip", "orb_kernels.hip", "ransac_kerne
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
-    # no SLP vectorisation: it packs adjacent f32 operations into v_pk_*_f32, which this chip issues at half the rate of
-    # the two plain instructions they replace (measured on ransac_count_kernel: 8.8 pipe-cycles per packed instruction)
-    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function",
 ]
+# per source.  ransac_kernels.hip: no SLP vectorisation - it packs the counting kernel's adjacent f32 fmas into
+# v_pk_fma_f32, which holds a SIMD for ~8.8 cycles against 4 + 4 for the two plain instructions.
+# (The dense kernels' hand-written v_pk_add_f32 / v_pk_mul_f32 pairs are the other way round: written out as plain
+# instructions window_stats_kernel ran 0.54 -> 0.66 ms.)
+EXTRA_FLAGS = {"ransac_kernels.hip": ["-fno-slp-vectorize"]}
 LINK = ["-ldl", "-pthread"]  # cvhip_rccl.hip opens librccl.so.1 lazily (dlopen): no link-time dependency on RCCL
 
 
@@ -64,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     def compile_one(src: str) -> Path:
         obj = OBJ / (src + ".o")
         if force or _stale(obj, [CSRC / src] + hdrs):
-            cmd = [cc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
