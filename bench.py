@@ -124,7 +124,7 @@ def valu_profile(world):
             "cycles_per_valu_instr": big.get("cycles_per_valu_instr")}
 
 
-def measure_sfm3(size, steps, warmup):
+def measure_sfm3(size, steps, warmup, dev=None):
     """BASELINE config 5 ("3-image perspective SFM: ORB + RANSAC F-matrix on GPU + pairwise dense correlation"):
     three synthetic size^2 perspective views, resident in HBM as u8 pyramids; one step = per-level ORB on the three
     images, 3 x matcher (threshold 48), 3 x perspective find_ransac (device RANSAC + LM refit), 3 x dense correlation
@@ -138,7 +138,9 @@ def measure_sfm3(size, steps, warmup):
     views, K, poses = synth.make_sfm_views(size)
     lsteps = synth.optimal_scale_steps(size, size)
     torch.cuda.set_device(0)
-    dev = correlation.create_gpu_context(ordinal=0, stream=torch.cuda.current_stream().cuda_stream)
+    own_dev = dev is None  # (the headline run hands its handle over: one set of side streams per process, see Device::aux)
+    if own_dev:
+        dev = correlation.create_gpu_context(ordinal=0, stream=torch.cuda.current_stream().cuda_stream)
     pyr = [[torch.from_numpy(l).cuda() for l in synth.box_pyramid(v, lsteps)] for v in views]
     acc, n_pairs, matches, inliers, dense_cells = {}, 0, [], [], []
     t0 = time.perf_counter()
@@ -157,7 +159,8 @@ def measure_sfm3(size, steps, warmup):
         matches.append(int(len(e["matches"])))
         inliers.append(int(len(e["inliers"])) if e["inliers"] is not None else 0)
         dense_cells.append(reconstruction.match_count(e["xy"]) if "xy" in e else 0)
-    dev.close()
+    if own_dev:
+        dev.close()
     stage_ms = {k: round(v / steps, 3) for k, v in acc.items()}
     return {"size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
             "dense_mpixels_per_s": round(n_pairs * size * size / 1e6 / (stage_ms["dense"] / 1e3), 2),
@@ -264,6 +267,9 @@ def main():
     dev = correlation.create_gpu_context(ordinal=local_rank, stream=stream.cuda_stream)
     pc = correlation.PointCorrelations(dev, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
     pc.set_borrow_inputs(True)
+    # the pyramid is complete in HBM before the timed region starts: the library may compute a level's window statistics
+    # on its side stream, under the coarse levels' search (cvhip_ctx_set_stats_ahead; same bits)
+    pc.set_stats_ahead(True)
     band_mode = False
     final_gather = None
     sim = None
@@ -496,7 +502,7 @@ def main():
         d1 = d2 = None
         torch.cuda.empty_cache()
         # ---- BASELINE config 5, per-stage times
-        sfm3 = measure_sfm3(2048 if W == 4096 else max(W // 2, 256), 5, 1)
+        sfm3 = measure_sfm3(2048 if W == 4096 else max(W // 2, 256), 5, 1, dev=dev)
 
     sharded_ok = None
     if world > 1:

@@ -215,6 +215,11 @@ class PointCorrelations:
         the last pixel of each and keeps them unchanged until the call's work has completed (include/cvhip.h)."""
         _lib.check(_lib.lib().cvhip_ctx_set_borrow_inputs(self._h, int(borrow)), "cvhip_ctx_set_borrow_inputs")
 
+    def set_stats_ahead(self, ahead: bool):
+        """cvhip_ctx_set_stats_ahead: the window statistics of borrowed level images run on a side stream, under the
+        coarse levels' search (the images must be complete in memory when they are passed)."""
+        _lib.check(_lib.lib().cvhip_ctx_set_stats_ahead(self._h, int(ahead)), "cvhip_ctx_set_stats_ahead")
+
     def set_search_version(self, version: int):
         _lib.check(_lib.lib().cvhip_ctx_set_search_version(self._h, version), "cvhip_ctx_set_search_version")
 

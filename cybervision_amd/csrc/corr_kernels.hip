@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
 
 void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, uint2 *istats_a,
                               const uint8_t *img_b, uint32_t wb, uint32_t hb, uint2 *istats_b,
-                              uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s)
+                              uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s, uint32_t lds_ballast)
 {
     const StatsJob ja{img_a, wa, ha, row0, row1 < ha ? row1 : ha, istats_a};
     const StatsJob jb{img_b, wb, hb, row0, row1 < hb ? row1 : hb, istats_b};
@@ -327,7 +327,9 @@ void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, ui
         return;
     }
     dim3 grid(((wa > wb ? wa : wb) + 63) / 64, (rows + WS_ROWS - 1) / WS_ROWS, 2);
-    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), 0, s, ja, jb, min_stdev, zero_words);
+    // lds_ballast: dynamic LDS the kernel never touches - it only limits how many of its workgroups a CU holds, so that a
+    // launch that runs as filler beside another stream's small kernels leaves them LDS and wave slots
+    hipLaunchKernelGGL(window_stats_kernel, grid, dim3(256), lds_ballast, s, ja, jb, min_stdev, zero_words);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1749,8 +1751,11 @@ struct CrossJob { // one direction's cross-check: `own` is filtered against `oth
 // One or both directions of a level in one launch (blockIdx.z).  The two filters may run side by side: a
 // match's supporters are exactly the matches it supports, so neither ever removes a cell the other one needs and
 // each decision depends on the UNFILTERED other grid only.
-__global__ __launch_bounds__(256) void cross_check_kernel(CrossJob ja, CrossJob jb)
+// zero_words (optional): eight u32 cleared by the first threads - the work-list counts of the NEXT level's search passes
+// (cvhip_ctx_set_stats_ahead: the statistics kernel that otherwise clears them runs on another stream)
+__global__ __launch_bounds__(256) void cross_check_kernel(CrossJob ja, CrossJob jb, uint32_t *__restrict__ zero_words)
 {
+    if (zero_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) zero_words[threadIdx.x] = 0u;
     const CrossJob &job = blockIdx.z == 0 ? ja : jb;
     uint32_t *__restrict__ own = job.own;
     const uint32_t *__restrict__ other = job.other;
@@ -1814,23 +1819,26 @@ void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint3
     if (row1 <= row0) return;
     dim3 grid((ow + 63) / 64, (row1 - row0 + 4 * CC_ROWS - 1) / (4 * CC_ROWS), 1);
     const CrossJob j{own, other, ow, row1, rw, rh, row0};
-    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, j, j);
+    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, j, j, (uint32_t *)nullptr);
 }
 
 // forward and reverse cross-check of a level in one launch
 void launch_cross_check_pair(uint32_t *fwd, uint32_t *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
-                             uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s)
+                             uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s, uint32_t *zero_words)
 {
     f_row1 = f_row1 < fh ? f_row1 : fh;
     r_row1 = r_row1 < rh ? r_row1 : rh;
     const uint32_t rows_f = f_row1 > f_row0 ? f_row1 - f_row0 : 0u, rows_r = r_row1 > r_row0 ? r_row1 - r_row0 : 0u;
     const uint32_t rows_max = rows_f > rows_r ? rows_f : rows_r;
-    if (rows_max == 0) return;
+    if (rows_max == 0) {
+        if (zero_words) (void)hipMemsetAsync(zero_words, 0, 8 * sizeof(uint32_t), s);
+        return;
+    }
     // an empty range is expressed as oh = row0 (every thread of that slice exits)
     const CrossJob jf{fwd, rev, fw, rows_f ? f_row1 : f_row0, rw, rh, f_row0};
     const CrossJob jr{rev, fwd, rw, rows_r ? r_row1 : r_row0, fw, fh, r_row0};
     dim3 grid(((fw > rw ? fw : rw) + 63) / 64, (rows_max + 4 * CC_ROWS - 1) / (4 * CC_ROWS), 2);
-    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, jf, jr);
+    hipLaunchKernelGGL(cross_check_kernel, grid, dim3(256), 0, s, jf, jr, zero_words);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -179,6 +179,17 @@ static void shard_rows(const cvhip_ctx *c, uint32_t lh, uint32_t *row0, uint32_t
 
 // Level images of a call: copied into the context's padded buffers - or, when the caller has vouched for the
 // padding of its device buffers (cvhip_ctx_set_borrow_inputs), used where they are.
+// The statistics words of level k live at their own offset of the per-image pool (level j has at most max_px / 4^j
+// pixels): the statistics of a finer level can then be computed while a coarser level is still being searched
+// (cvhip_ctx_set_stats_ahead).
+static size_t stats_level_offset(size_t max_px, int k)
+{
+    size_t off = 0;
+    for (int j = 0; j < k; j++) off += ((max_px >> (2 * j)) + 63) & ~(size_t)63;
+    return off;
+}
+static size_t stats_pool_elems(size_t max_px) { return stats_level_offset(max_px, 16) + 64; }
+
 static int stage_images(cvhip_ctx *c, const uint8_t *img1, size_t n1, const uint8_t *img2, size_t n2, hipStream_t s)
 {
     const uint8_t *src[2] = {img1, img2};
@@ -275,8 +286,8 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
     SearchJob &j = plan.job;
     j.img1 = c->cur_img[a];
     j.img2 = c->cur_img[b];
-    j.stats1 = c->istats[a];
-    j.stats2 = c->istats[b];
+    j.stats1 = c->istats[a] + stats_level_offset(c->max_px, k);
+    j.stats2 = c->istats[b] + stats_level_offset(c->max_px, k);
     j.prev = ds.cells[ds.cur];
     j.range = dir == 0 ? c->range : c->range_rev;
     j.contenders = dir == 0 ? c->contenders : c->contenders_rev;
@@ -501,16 +512,23 @@ void device_free(cvhip_device *dev)
     }
     {
         auto &rq = dev->d.rq;
-        for (hipStream_t g : rq.gen)
-            if (g) {
-                (void)hipStreamSynchronize(g);
-                (void)hipStreamDestroy(g);
-            }
         for (hipEvent_t ev : rq.ready)
             if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : rq.scored)
             if (ev) (void)hipEventDestroy(ev);
         if (rq.uploaded) (void)hipEventDestroy(rq.uploaded);
+    }
+    for (hipStream_t &g : dev->d.aux)
+        if (g) {
+            (void)hipStreamSynchronize(g);
+            (void)hipStreamDestroy(g);
+            g = nullptr;
+        }
+    {
+        auto &sa = dev->d.sa;
+        for (hipEvent_t ev : sa.done)
+            if (ev) (void)hipEventDestroy(ev);
+        if (sa.fence) (void)hipEventDestroy(sa.fence);
     }
     if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
     if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
@@ -669,7 +687,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&c->dir[d].scores, ge * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
-        if (e == hipSuccess) e = hipMalloc(&c->istats[d], c->max_px * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc(&c->istats[d], stats_pool_elems(c->max_px) * sizeof(uint2));
     }
     if (!reused) {
         if (e == hipSuccess) e = hipMalloc(&c->range, c->max_px * sizeof(uint32_t));
@@ -725,8 +743,8 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
             sr1 = ctx->band[k].st[1];
         }
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->istats[0], ctx->cur_img[1], w2, h2,
-                                     ctx->istats[1], sr0, sr1, ctx->min_stdev, nullptr, s);
+            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->istats[0] + stats_level_offset(ctx->max_px, k), ctx->cur_img[1], w2, h2,
+                                     ctx->istats[1] + stats_level_offset(ctx->max_px, k), sr0, sr1, ctx->min_stdev, nullptr, s);
         }));
     }
     report(progress, user, dir, 0.20f);
@@ -765,17 +783,49 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s));
+    bool stats_ahead = false;
     {
         uint32_t sr0 = 0, sr1 = std::max(h1, h2);
         if (ctx->band_mode) {
             sr0 = ctx->band[k].st[0];
             sr1 = ctx->band[k].st[1];
         }
-        // both images in one launch, which also clears the work-list counts of the level's two search passes
-        CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->istats[0], ctx->cur_img[1], w2, h2,
-                                     ctx->istats[1], sr0, sr1, ctx->min_stdev, ctx->work, s);
-        }));
+        uint2 *const st0 = ctx->istats[0] + stats_level_offset(ctx->max_px, k), *const st1 = ctx->istats[1] + stats_level_offset(ctx->max_px, k);
+        stats_ahead = ctx->stats_ahead && ctx->time_kernels != 1 && !ctx->band_mode && !sharded && ctx->borrow_inputs &&
+                      is_device_ptr(img1) && is_device_ptr(img2) && k < 16;
+        if (stats_ahead) {
+            // The statistics depend on the level's images only.  On a stream of their own they run while the main stream
+            // works through the coarse levels - a chain of ~40 small dependent launches that leaves the chip idle for
+            // ~0.4 ms of a 4096^2 pair - instead of 0.5 ms of full-chip work in line with it.
+            Device &d = ctx->dev->d;
+            hipStream_t side = nullptr;
+            CVHIP_TRY_HIP(aux_stream(d, 0, &side));
+            if (!d.sa.fence) CVHIP_TRY_HIP(hipEventCreateWithFlags(&d.sa.fence, hipEventDisableTiming));
+            if (!d.sa.done[k]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&d.sa.done[k], hipEventDisableTiming));
+            if (first_pass || !ctx->stats_ahead_fenced) {
+                // a new pyramid run: its side-stream work starts behind everything enqueued so far (the previous run's
+                // readers of these buffers among it), and its first level finds the work-list counts cleared
+                CVHIP_TRY_HIP(hipEventRecord(d.sa.fence, s));
+                CVHIP_TRY_HIP(hipStreamWaitEvent(side, d.sa.fence, 0));
+                CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 8 * sizeof(uint32_t), s));
+                ctx->stats_ahead_fenced = true;
+            }
+            // (48 KB of LDS ballast per workgroup: three of them per CU instead of eight.  A full-chip grid beside the
+            // coarse levels starved their small kernels - a 30 us box launch took the 370 us of the statistics kernel,
+            // stream priorities notwithstanding; at four per CU the chain still lost 0.17 ms; at two the statistics of the
+            // full-resolution level are not done when that level's turn comes: step 5.60 / 5.45 / 5.37 / 5.47 ms for
+            // 0 / 32 / 48 / 64 KB)
+            launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev, nullptr, side,
+                                     48u * 1024u);
+            CVHIP_TRY_HIP(hipEventRecord(d.sa.done[k], side));
+            CVHIP_TRY_HIP(hipStreamWaitEvent(s, d.sa.done[k], 0));
+        } else {
+            ctx->stats_ahead_fenced = false;
+            // both images in one launch, which also clears the work-list counts of the level's two search passes
+            CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
+                launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev, ctx->work, s);
+            }));
+        }
     }
     report(progress, user, 0, 0.20f);
     if (!sharded) {
@@ -836,7 +886,9 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
             ctx->rev_cross_check_pending = true;
         }
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_CROSS, [&] {
-            launch_cross_check_pair(df.cells[df.cur], dr.cells[dr.cur], df.lw, df.lh, dr.lw, dr.lh, f0, f1, r0, r1, s);
+            // (stats ahead: the next level's statistics kernel runs on another stream and cannot clear the work-list counts)
+            launch_cross_check_pair(df.cells[df.cur], dr.cells[dr.cur], df.lw, df.lh, dr.lw, dr.lh, f0, f1, r0, r1, s,
+                                    stats_ahead ? ctx->work : nullptr);
         }));
         CVHIP_TRY_HIP(hipGetLastError());
     }
@@ -1171,6 +1223,13 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset)
     CVHIP_TRY_HIP(hipMemcpy(v, ctx->d_cand, sizeof(v), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; i++) out[i] = (uint64_t)v[i];
     if (reset) CVHIP_TRY_HIP(hipMemset(ctx->d_cand, 0, sizeof(v)));
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_stats_ahead(cvhip_ctx *ctx, int ahead)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    ctx->stats_ahead = ahead != 0;
     return CVHIP_OK;
 }
 

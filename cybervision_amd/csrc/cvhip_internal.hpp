@@ -87,7 +87,8 @@ struct WorkList {
 };
 void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, uint2 *istats_a,
                               const uint8_t *img_b, uint32_t wb, uint32_t hb, uint2 *istats_b,
-                              uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s);
+                              uint32_t row0, uint32_t row1, float min_stdev, uint32_t *zero_words, hipStream_t s,
+                              uint32_t lds_ballast = 0);
 // One direction's search pass of a level: everything its kernels need.  The kernels of the two directions of a level
 // are launched together (jobs[0], jobs[1] -> blockIdx.z); per-pass callers launch one job.
 struct SearchJob {
@@ -113,7 +114,7 @@ size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
 void launch_cross_check_pair(uint32_t *fwd, uint32_t *rev, uint32_t fw, uint32_t fh, uint32_t rw, uint32_t rh, uint32_t f_row0,
-                             uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s);
+                             uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s, uint32_t *zero_words = nullptr);
 // scores == nullptr: the level's scores were not computed (CorrParams::need_scores): NaN everywhere
 void launch_expand_grid(const uint32_t *cells, const float *scores, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
                         int32_t *out_xy, float *out_corr, hipStream_t s);
@@ -205,17 +206,35 @@ struct Device {
         bool pending[2] = {false, false};
         int next = 0;
     } rb;
+    // Side streams of the handle, shared by whoever needs one (the RANSAC generators: both; the statistics-ahead mode:
+    // the first) and created on first use.  Shared on purpose: a process gets four hardware queues, and a fifth stream
+    // is mapped onto a queue that is already in use - its "concurrent" kernels then wait for that stream's (with a
+    // stream of its own for the statistics, config 5's RANSAC stage ran 22 -> 27 ms in a process that had used both)
+    hipStream_t aux[2] = {nullptr, nullptr};
     // the RANSAC loops' generator streams and round events (created on first use: creating two streams and seven events
     // per find_ransac call cost 1.5 ms of every ~9 ms call)
     struct RansacQueues {
-        hipStream_t gen[2] = {nullptr, nullptr};
         hipEvent_t ready[3] = {nullptr, nullptr, nullptr}, scored[3] = {nullptr, nullptr, nullptr}, uploaded = nullptr;
     } rq;
+    // cvhip_ctx_set_stats_ahead: the side stream the window statistics of the finer levels run on while the coarse levels'
+    // (launch-latency bound) search chain occupies the main stream, one "done" event per level, one fence (created on
+    // first use)
+    struct StatsAhead {
+        hipEvent_t done[16] = {};
+        hipEvent_t fence = nullptr;
+    } sa;
     // RCCL communicators created on this handle (cvhip_rccl_create) enqueue on its stream: while any is alive,
     // cvhip_device_destroy only marks the handle and the last cvhip_rccl_destroy frees it
     int comm_refs = 0;
     bool destroy_pending = false;
 };
+inline hipError_t aux_stream(Device &d, int i, hipStream_t *out)
+{
+    hipError_t e = hipSuccess;
+    if (!d.aux[i]) e = hipStreamCreateWithFlags(&d.aux[i], hipStreamNonBlocking);
+    *out = d.aux[i];
+    return e;
+}
 // -> at least `bytes` of page-locked host memory owned by the handle (nullptr: out of memory)
 inline void *pinned_scratch(Device &d, size_t bytes)
 {
@@ -321,6 +340,8 @@ struct cvhip_ctx {
     uint8_t *img[2] = {nullptr, nullptr}; // level image staging (padded), [0]=searched [1]=target of the call
     const uint8_t *cur_img[2] = {nullptr, nullptr}; // the images the current call works on: img[] or the caller's own
     bool borrow_inputs = false;                     // cvhip_ctx_set_borrow_inputs
+    bool stats_ahead = false;                       // cvhip_ctx_set_stats_ahead
+    bool stats_ahead_fenced = false;                // this pyramid run's side-stream work is ordered behind everything earlier
     // per level pixel {window sum | VALID << 31, f32 bits of stdev}: avg = sum / 121 is derived where it is needed
     uint2 *istats[2] = {nullptr, nullptr};
     // 1 = per-candidate exact kernel, 2 = integer filter per candidate + exact re-evaluation,

@@ -2246,16 +2246,15 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // (one generator stream per round in flight: the LM tails of consecutive rounds - a couple of hundred waves each,
     // bound by their longest loop - then run side by side instead of queueing behind each other)
     constexpr uint32_t GEN_STREAMS = GEN_DEPTH - 1;
-    static_assert(GEN_STREAMS == 2 && GEN_DEPTH == 3, "Device::RansacQueues holds two streams and three events of each kind");
+    static_assert(GEN_STREAMS == 2 && GEN_DEPTH == 3, "Device holds two side streams, Device::RansacQueues three events of each kind");
     Device::RansacQueues &rq = dev->d.rq; // (kept on the handle: created once)
-    for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++)
-        if (!rq.gen[k]) e = hipStreamCreateWithFlags(&rq.gen[k], hipStreamNonBlocking);
+    hipStream_t g[GEN_STREAMS] = {};
+    for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = aux_stream(dev->d, (int)k, &g[k]);
     for (uint32_t b = 0; b < GEN_DEPTH && e == hipSuccess; b++) {
         if (!rq.ready[b]) e = hipEventCreateWithFlags(&rq.ready[b], hipEventDisableTiming);
         if (e == hipSuccess && !rq.scored[b]) e = hipEventCreateWithFlags(&rq.scored[b], hipEventDisableTiming);
     }
     if (e == hipSuccess && !rq.uploaded) e = hipEventCreateWithFlags(&rq.uploaded, hipEventDisableTiming);
-    hipStream_t *const g = rq.gen;
     hipEvent_t *const ready = rq.ready, *const scored = rq.scored;
     const hipEvent_t uploaded = rq.uploaded;
     if (e == hipSuccess) e = hipEventRecord(uploaded, s);

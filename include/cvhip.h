@@ -222,6 +222,15 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, void **scores, u
  * image stays unchanged until the work of the call has completed on the device's stream.  Host images are
  * still copied.  Off by default. */
 int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow);
+/* Window statistics of a level (compute_image_point_data, mod.rs:632-694) on a stream of the library's own, ahead of
+ * the level's turn: they depend on the level's images only, and the coarse levels' search is a chain of small
+ * dependent launches that leaves the chip idle for ~0.4 ms of a 4096^2 pair - room for the 0.5 ms of full-chip work
+ * the statistics of the two finest levels are.  Applies to cvhip_correlate_level calls with BORROWED device images
+ * (cvhip_ctx_set_borrow_inputs) outside band / shard mode and outside per-kernel timing; the caller additionally
+ * promises that a level image is complete in memory when it is passed (not merely ordered on the handle's stream:
+ * the statistics kernel reads it on another stream, ordered behind the work enqueued before the pyramid run's FIRST
+ * level only).  Same results bit for bit.  Off by default. */
+int cvhip_ctx_set_stats_ahead(cvhip_ctx *ctx, int ahead);
 
 /* Measurement hooks (bench.py).  time_kernels: 1 = every kernel launch is bracketed by HIP events on the
  * stream it is launched on, 2 = only the launches of the search class ([2] below), 0 = off.  Timing is

@@ -340,6 +340,38 @@ def test_borrowed_device_inputs(gpu_device, oracle):
     assert_same_grid(got, run_oracle(oracle, c), "borrowed inputs")
 
 
+def test_stats_ahead_same_bits(gpu_device, oracle):
+    """cvhip_ctx_set_stats_ahead: the window statistics of borrowed level images run on a side stream under the coarse
+    levels' search - the grid is the oracle's, also when one context runs two pyramids back to back."""
+    import torch
+
+    c = cases.make_case("ragged_dims")
+    p1, p2 = cases.pyramids(c)
+
+    def resident(p):
+        buf = torch.zeros(p.size + 64, dtype=torch.uint8, device="cuda")
+        buf[:p.size].copy_(torch.from_numpy(p).reshape(-1))
+        return buf[:p.size].view(p.shape[0], p.shape[1])
+
+    d1, d2 = [resident(p) for p in p1], [resident(p) for p in p2]
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    want = run_oracle(oracle, c)
+    pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"])
+    try:
+        pc.set_borrow_inputs(True)
+        pc.set_stats_ahead(True)
+        torch.cuda.synchronize()
+        for run in range(2):
+            pc.first_pass = True  # (a new pyramid run on the same context)
+            for i in range(c["steps"] + 1):
+                k = c["steps"] - i
+                pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+            assert_same_grid(pc.complete(), want, f"stats ahead, run {run}")
+    finally:
+        pc.close()
+
+
 def test_error_reporting(gpu_device):
     from cybervision_amd._lib import CvhipError
 
