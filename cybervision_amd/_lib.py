@@ -80,6 +80,8 @@ SIGNATURES = {
     "cvhip_ransac_affine_models": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp]),
     "cvhip_fits_model": (C.c_int, [_vp, _vp, _vp, _u32, C.c_double, _vp]),
     "cvhip_ransac_round_score": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp, _vp]),
+    "cvhip_ransac_rounds_pick": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u32, C.c_double, _u32, _vp, C.POINTER(_u32),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cvhip_find_ransac": (C.c_int, [_vp, C.c_int, _vp, _u32, C.c_double, C.c_uint64, _vp, C.POINTER(_u32), _vp, PROGRESS_FN,
                                     MATCHES_FN, _vp]),
     "cvhip_optimize_perspective_f": (C.c_int, [_vp, _vp, _u32, _vp, _vp]),

@@ -2089,6 +2089,73 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     return CVHIP_OK;
 }
 
+// Test hook: the device loops' ROUNDS on caller-given hypotheses - `rounds` consecutive slices of F, each scored as
+// ransac_rounds scores a generated round: live-slot compaction, the counting kernel on its own, re-sorted copy of the
+// match list with the abandonment bound of the best so far and the launch's running maximum, the candidate list,
+// ransac_round_finish_kernel (maximum list, tie-break sums, pick, re-sort).  -> the best hypothesis after the last
+// round as the loops would carry it: its matrix, inlier count and mean error (NaN where it was never needed), and
+// its index in F (-1: no hypothesis reached min_count).  Must equal Ord's (:623-649) maximum over the hypotheses'
+// (count, mean error) of cvhip_ransac_score, first of equals by index.
+extern "C" int cvhip_ransac_rounds_pick(cvhip_device *dev, const double *F, uint32_t H, uint32_t rounds, const uint32_t *matches,
+                                        uint32_t N, double t, uint32_t min_count, double *out_F, uint32_t *out_count,
+                                        double *out_mean_error, int64_t *out_index)
+{
+    if (!dev || !F || !matches || !out_F || !out_count || !out_mean_error || !out_index) return fail(CVHIP_ERR_INVALID, "null argument");
+    if (H == 0 || N == 0 || rounds == 0 || rounds > H) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_rounds_pick: empty input");
+    CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
+    hipStream_t s = dev->d.stream;
+    DevAllocs mem(dev->d);
+    const uint32_t per = (H + rounds - 1) / rounds; // hypotheses per round (the last round may be shorter)
+    double *d_F = nullptr, *d_err = nullptr;
+    uint32_t *d_m = nullptr, *d_mo = nullptr, *d_cnt = nullptr, *d_live = nullptr, *d_cand = nullptr;
+    RansacBest *d_best = nullptr;
+    float4 *d_mf = nullptr;
+    CVHIP_TRY_HIP(mem.alloc(&d_F, (size_t)H * 9));
+    CVHIP_TRY_HIP(mem.alloc(&d_err, std::max<size_t>(per, 64)));
+    CVHIP_TRY_HIP(mem.alloc(&d_m, (size_t)N * 4));
+    CVHIP_TRY_HIP(mem.alloc(&d_mo, (size_t)N * 4));
+    CVHIP_TRY_HIP(mem.alloc(&d_cnt, per));
+    const size_t live_words = (size_t)per + 1 + (per + 1023) / 1024;
+    CVHIP_TRY_HIP(mem.alloc(&d_live, live_words + 3 + TIED_CAP));
+    CVHIP_TRY_HIP(mem.alloc(&d_cand, 2 + 2 * (size_t)TIED_CAP));
+    CVHIP_TRY_HIP(mem.alloc(&d_best, 1));
+    CVHIP_TRY_HIP(mem.alloc(&d_mf, ransac_padded(N)));
+    uint32_t *const d_tied = d_live + live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_F, F, (size_t)H * 9 * sizeof(double), dev_ptr(F) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    CVHIP_TRY_HIP(hipMemcpyAsync(d_mo, d_m, (size_t)N * 16, hipMemcpyDeviceToDevice, s));
+    CVHIP_TRY_HIP(hipMemsetAsync(d_best, 0, sizeof(RansacBest), s));
+    CVHIP_TRY_HIP(hipMemsetAsync(d_cand, 0, 2 * sizeof(uint32_t), s));
+    const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
+    hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, m4, N, d_coord_max, d_mf);
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t first = r * per, n = std::min(per, H - std::min(H, first));
+        if (n == 0) break;
+        const double *F_round = d_F + (size_t)first * 9;
+        launch_ransac_live(F_round, n, d_live, d_live + per, d_live + per + 1, s);
+        launch_ransac_score_round(F_round, n, d_m, d_mo, d_mf, N, t, d_live, d_live + per, d_tied, d_coord_max, true, true, min_count, d_best,
+                                  d_cnt, d_err, s, d_cand);
+        hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
+                           reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+    }
+    CVHIP_TRY_HIP(hipGetLastError());
+    RansacBest h_best;
+    CVHIP_TRY_HIP(hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s));
+    CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    *out_index = -1;
+    *out_count = 0;
+    *out_mean_error = std::nan("");
+    for (int i = 0; i < 9; i++) out_F[i] = 0.0;
+    if (!h_best.valid) return CVHIP_OK;
+    std::memcpy(out_F, h_best.f, sizeof(h_best.f));
+    *out_count = h_best.matches_count;
+    if (h_best.err_known) *out_mean_error = h_best.best_error;
+    if (!dev_ptr(F)) // (the index: the first hypothesis with exactly these nine doubles)
+        for (uint32_t h = 0; h < H && *out_index < 0; h++)
+            if (std::memcmp(F + (size_t)h * 9, h_best.f, sizeof(h_best.f)) == 0) *out_index = (int64_t)h;
+    return CVHIP_OK;
+}
+
 // The listener of the cvhip_find_ransac call in progress on this thread (fundamentalmatrix.rs:41-47, 103): the model
 // entry points below are reached through it and report once per round.
 namespace {

@@ -54,6 +54,20 @@ def ransac_round_score(device, F, matches, t: float):
     return cnt, err
 
 
+def ransac_rounds_pick(device, F, rounds: int, matches, t: float, min_count: int):
+    """cvhip_ransac_rounds_pick: the device loops' rounds (pruned counting on the re-sorted list, candidates, finish
+    kernel) over `rounds` consecutive slices of caller-given hypotheses.
+    -> (index in F or -1, F_best [3, 3], count, mean error or NaN)."""
+    F = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(-1, 9))
+    m = _matches(matches)
+    out_F = np.zeros(9, dtype=np.float64)
+    cnt, err, idx = C.c_uint32(0), C.c_double(0.0), C.c_int64(-1)
+    _lib.check(_lib.lib().cvhip_ransac_rounds_pick(device.handle, _p(F), F.shape[0], int(rounds), _p(m), m.shape[0], float(t),
+                                                   int(min_count), _p(out_F), C.byref(cnt), C.byref(err), C.byref(idx)),
+               "cvhip_ransac_rounds_pick")
+    return int(idx.value), out_F.reshape(3, 3), int(cnt.value), float(err.value)
+
+
 def find_ransac_affine(device, matches, seed: int = 0):
     """FundamentalMatrix::new(Affine, _).find_ransac(matches) entirely on the device
     (cvhip_ransac_affine).  -> (F[3, 3] float64, inlier_mask[N] bool).  Raises CvhipError (code -5) with

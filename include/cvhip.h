@@ -395,6 +395,16 @@ int cvhip_fits_model(cvhip_device *dev, const double *F, const uint32_t *matches
  * out_count must equal cvhip_ransac_score's counts; out_err_sum its sums where non-zero. */
 int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint32_t H, const uint32_t *matches, uint32_t N, double t,
                              uint32_t *out_count, double *out_err_sum);
+/* Test hook: the device loops' rounds on caller-given hypotheses: F is cut into `rounds` consecutive slices and every
+ * slice is scored as cvhip_ransac_perspective / cvhip_find_ransac score a generated round - the counting kernel on its
+ * own re-sorted copy of the match list, abandoning hypotheses against the best of the earlier slices and the running
+ * maximum of the launch; the round's candidates; tie-break sums only where counts tie; the pick.  Out: the best
+ * hypothesis after the last slice (its nine doubles, inlier count, mean error - NaN where no tie ever asked for it -
+ * and its index in F, -1 if none reached min_count; the index needs F on the host).  Must be Ord's maximum
+ * (fundamentalmatrix.rs:623-649) over cvhip_ransac_score's (count, err_sum / count), first of equals by index. */
+int cvhip_ransac_rounds_pick(cvhip_device *dev, const double *F, uint32_t H, uint32_t rounds, const uint32_t *matches, uint32_t N,
+                             double t, uint32_t min_count, double *out_F, uint32_t *out_count, double *out_mean_error,
+                             int64_t *out_index);
 /* FundamentalMatrix::new(projection, max_dimension).find_ransac(matches) in one call (fundamentalmatrix.rs:72-147
  * and optimize_result :231-257): cvhip_ransac_affine for projection 0 (max_dimension unused); for projection 1
  * cvhip_ransac_perspective, then the LM refit of the winner on its inliers (cvhip_optimize_perspective_f_device: the

@@ -375,6 +375,51 @@ def test_device_perspective_ransac_recovers_planted_geometry(gpu_device, oracle,
     assert ei.value.code == -5 and "Not enough matches" in str(ei.value)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rounds", [1, 3, 8])
+def test_device_rounds_pick_ord_maximum(gpu_device, rounds):
+    """The device loops' round machinery (cvhip_ransac_rounds_pick: counting kernel on its re-sorted list with the
+    abandonment bounds, the candidate list, ransac_round_finish_kernel) on caller-given hypotheses against Ord's maximum
+    (fundamentalmatrix.rs:623-649) over the full fold of every hypothesis (cvhip_ransac_score): the same hypothesis wins
+    - generated models with their dead slots, near-duplicates of the good ones, and exact duplicates that tie."""
+    import cases
+
+    m, truth, _, _ = cases.perspective_matches(n=6000, outlier_frac=0.35)
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+    rng = np.random.default_rng(11 + rounds)
+    good = np.flatnonzero(truth)
+    idx = np.stack([rng.choice(len(m), 7, replace=False) for _ in range(1500)] +
+                   [rng.choice(good, 7, replace=False) for _ in range(500)]).astype(np.uint32)
+    F = fundamentalmatrix.perspective_models_device(gpu_device, m, idx, t).reshape(-1, 9)  # NaN rows = dead slots
+    cnt, err = fundamentalmatrix.ransac_score(gpu_device, np.nan_to_num(F, nan=0.0), m, t)
+    cnt = np.where(np.isfinite(F).all(axis=1), cnt, 0)
+    order = np.argsort(-cnt.astype(np.int64), kind="stable")
+    top = F[order[:40]]
+    pert = top * (1.0 + 1e-7 * rng.standard_normal(top.shape))
+    pert[:, 8] = 1.0
+    F = np.concatenate([F, pert, top[:5], top[:5]])  # exact duplicates of the five best: ties in count AND error
+    F = F[rng.permutation(len(F))]
+    live = np.isfinite(F).all(axis=1)
+    cnt, err = fundamentalmatrix.ransac_score(gpu_device, np.nan_to_num(F, nan=0.0), m, t)
+    cnt = np.where(live, cnt, 0).astype(np.int64)
+    min_count = 207
+    # Ord: more matches win; among equal counts the smaller mean error; the first of equals stays
+    best = -1
+    for h in np.flatnonzero(cnt >= min_count):
+        if best < 0 or cnt[h] > cnt[best] or (cnt[h] == cnt[best] and err[h] / cnt[h] < err[best] / cnt[best]):
+            best = int(h)
+    assert best >= 0 and (cnt == cnt[best]).sum() >= 2  # the planted duplicates do tie
+    got_idx, got_F, got_cnt, got_err = fundamentalmatrix.ransac_rounds_pick(gpu_device, F, rounds, m, t, min_count)
+    assert got_cnt == cnt[best]
+    assert (got_F.reshape(9) == F[best]).all(), (got_idx, best)
+    first_equal = int(np.flatnonzero((F == F[best]).all(axis=1))[0])
+    assert got_idx == first_equal
+    if np.isfinite(got_err):
+        assert abs(got_err - err[best] / cnt[best]) <= 1e-9 * abs(err[best] / cnt[best])
+    # nothing reaches an impossible minimum: no winner
+    assert fundamentalmatrix.ransac_rounds_pick(gpu_device, F, rounds, m, t, len(m) + 1)[0] == -1
+
+
 def test_device_refit_equals_host_refit_bit_for_bit(gpu_device, oracle):
     """cvhip_optimize_perspective_f_device (one workgroup, eight threads per long dot product) against
     cvhip_optimize_perspective_f (one host thread) and the oracle: same loop, same accumulation order -> same bits.
