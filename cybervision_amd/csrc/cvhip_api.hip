@@ -791,7 +791,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
             sr1 = ctx->band[k].st[1];
         }
         uint2 *const st0 = ctx->istats[0] + stats_level_offset(ctx->max_px, k), *const st1 = ctx->istats[1] + stats_level_offset(ctx->max_px, k);
-        stats_ahead = ctx->stats_ahead && ctx->time_kernels != 1 && !ctx->band_mode && !sharded && ctx->borrow_inputs &&
+        stats_ahead = ctx->stats_ahead && ctx->time_kernels != 1 && !sharded && ctx->borrow_inputs &&
                       is_device_ptr(img1) && is_device_ptr(img2) && k < 16;
         if (stats_ahead) {
             // The statistics depend on the level's images only.  On a stream of their own they run while the main stream

@@ -226,7 +226,7 @@ int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow);
  * the level's turn: they depend on the level's images only, and the coarse levels' search is a chain of small
  * dependent launches that leaves the chip idle for ~0.4 ms of a 4096^2 pair - room for the 0.5 ms of full-chip work
  * the statistics of the two finest levels are.  Applies to cvhip_correlate_level calls with BORROWED device images
- * (cvhip_ctx_set_borrow_inputs) outside band / shard mode and outside per-kernel timing; the caller additionally
+ * (cvhip_ctx_set_borrow_inputs) outside row-shard mode and outside per-kernel timing; the caller additionally
  * promises that a level image is complete in memory when it is passed (not merely ordered on the handle's stream:
  * the statistics kernel reads it on another stream, ordered behind the work enqueued before the pyramid run's FIRST
  * level only).  Same results bit for bit.  Off by default. */

@@ -878,8 +878,8 @@ def _digest_of(xy, corr):
             hashlib.sha256(np.ascontiguousarray(score_bits).tobytes()).hexdigest())
 
 
-@pytest.mark.parametrize("den", [2, 4, 8])
-def test_config4_band_plan_4096_matches_oracle_digest(gpu_device, den):
+@pytest.mark.parametrize("den,ahead", [(2, False), (4, False), (8, False), (8, True)])
+def test_config4_band_plan_4096_matches_oracle_digest(gpu_device, den, ahead):
     """BASELINE config 4 as far as one GPU allows: the N-rank independent-band plan (cvhip_ctx_set_row_band(r, N)) on the
     4096^2 headline pair.  The N band contexts run one after the other on this GPU - each the whole 7-level pyramid on
     its band + halo, no exchange between levels - their forward bands are stitched into context 0 (what the single
@@ -895,12 +895,22 @@ def test_config4_band_plan_4096_matches_oracle_digest(gpu_device, den):
     steps = synth.optimal_scale_steps(size, size)
     c = dict(img1=a, img2=b, F=synth.F_HORIZONTAL, projection=0, steps=steps)
     p1, p2 = cases.pyramids(c)
+    if ahead:  # as bench.py runs it: level images resident and borrowed, their statistics on the side stream
+        def resident(p):
+            buf = torch.zeros(p.size + 64, dtype=torch.uint8, device="cuda")
+            buf[:p.size].copy_(torch.from_numpy(p).reshape(-1))
+            return buf[:p.size].view(p.shape[0], p.shape[1])
+
+        p1, p2 = [resident(p) for p in p1], [resident(p) for p in p2]
+        torch.cuda.synchronize()
     Fd = correlation.CorrelationDirection.Forward
     main = correlation.PointCorrelations(gpu_device, (size, size), (size, size), c["F"])
     try:
         for r in range(den):
             pc = main if r == 0 else correlation.PointCorrelations(gpu_device, (size, size), (size, size), c["F"])
             try:
+                pc.set_borrow_inputs(ahead)
+                pc.set_stats_ahead(ahead)
                 assert pc.set_row_band(r, den), "the headline geometry is row-local"
                 for i in range(steps + 1):
                     k = steps - i
