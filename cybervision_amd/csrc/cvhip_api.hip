@@ -518,6 +518,11 @@ void device_free(cvhip_device *dev)
             if (ev) (void)hipEventDestroy(ev);
         if (rq.uploaded) (void)hipEventDestroy(rq.uploaded);
     }
+    for (hipEvent_t &ev : dev->d.orb_ev)
+        if (ev) {
+            (void)hipEventDestroy(ev);
+            ev = nullptr;
+        }
     for (hipStream_t &g : dev->d.aux)
         if (g) {
             (void)hipStreamSynchronize(g);

@@ -211,6 +211,7 @@ struct Device {
     // is mapped onto a queue that is already in use - its "concurrent" kernels then wait for that stream's (with a
     // stream of its own for the statistics, config 5's RANSAC stage ran 22 -> 27 ms in a process that had used both)
     hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t orb_ev[3] = {nullptr, nullptr, nullptr}; // cvhip_orb_extract_batch's fork / join events
     // the RANSAC loops' generator streams and round events (created on first use: creating two streams and seven events
     // per find_ransac call cost 1.5 ms of every ~9 ms call)
     struct RansacQueues {

@@ -735,14 +735,38 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     hipStream_t s = dev->d.stream;
     DevAllocs mem(dev->d);
+    // The images of a batch are independent and every one of them is a chain of ~25 small launches (2 - 25 us each: a
+    // 2048^2 view's four pyramid levels took 1.1 ms, almost all of it launch latency): the chains go round-robin onto the
+    // handle's stream and its two side streams, forked and joined with events around each stage.
+    constexpr uint32_t LANES = 3;
+    hipStream_t lane_stream[LANES] = {s, nullptr, nullptr};
+    const uint32_t lanes = n_images > 1 ? LANES : 1;
+    for (uint32_t l = 1; l < lanes; l++) CVHIP_TRY_HIP(aux_stream(dev->d, (int)l - 1, &lane_stream[l]));
+    for (uint32_t l = 0; l < lanes; l++)
+        if (!dev->d.orb_ev[l]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&dev->d.orb_ev[l], hipEventDisableTiming));
+    const auto fork = [&]() -> int { // the side streams continue from where the handle's stream is
+        if (lanes == 1) return CVHIP_OK;
+        CVHIP_TRY_HIP(hipEventRecord(dev->d.orb_ev[0], s));
+        for (uint32_t l = 1; l < lanes; l++) CVHIP_TRY_HIP(hipStreamWaitEvent(lane_stream[l], dev->d.orb_ev[0], 0));
+        return CVHIP_OK;
+    };
+    const auto join = [&]() -> int { // ... and the handle's stream from where they all are
+        for (uint32_t l = 1; l < lanes; l++) {
+            CVHIP_TRY_HIP(hipEventRecord(dev->d.orb_ev[l], lane_stream[l]));
+            CVHIP_TRY_HIP(hipStreamWaitEvent(s, dev->d.orb_ev[l], 0));
+        }
+        return CVHIP_OK;
+    };
     try {
         std::vector<OrbJob> jobs(n_images);
 
         // ---- stage A: contrast stretch, FAST score, NMS count -> corner totals
         uint32_t *h_counts = static_cast<uint32_t *>(pinned_scratch(dev->d, 4096));
         if (!h_counts) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
+        CVHIP_TRY(fork());
         for (uint32_t i = 0; i < n_images; i++) {
             OrbJob &j = jobs[i];
+            hipStream_t s = lane_stream[i % lanes]; // (this image's chain)
             j.img = imgs[i];
             j.w = ws[i];
             j.h = hs[i];
@@ -770,6 +794,7 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, j.d_counts, j.nblocks, j.d_total);
             CVHIP_TRY_HIP(hipMemcpyAsync(h_counts + i, j.d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         }
+        CVHIP_TRY(join());
         report(0.20f);
         CVHIP_TRY_HIP(hipStreamSynchronize(s));
         CVHIP_TRY_HIP(hipGetLastError());
@@ -808,7 +833,7 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
         }
         const double guard = dev->d.orb_guard;
         // descriptors of image j from the orientations in j.d_sc, results into the image's staging block
-        const auto describe = [&](OrbJob &j, double g) -> int {
+        const auto describe = [&](OrbJob &j, double g, hipStream_t s) -> int {
             uint32_t *d_out_n = j.d_pack, *d_out_xy = j.xy_dev ? j.out_xy : j.d_pack + 64,
                      *d_out_desc = j.desc_dev ? j.out_desc : j.d_pack + 64 + (size_t)j.out_cap * 2;
             CVHIP_TRY_HIP(hipMemsetAsync(j.d_pack, 0, 8, s)); // {n_out, open count}
@@ -820,9 +845,11 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             CVHIP_TRY_HIP(hipMemcpyAsync(stage + j.pack_off, j.d_pack, back, hipMemcpyDeviceToHost, s));
             return CVHIP_OK;
         };
+        CVHIP_TRY(fork()); // (behind the pattern upload)
         for (uint32_t i = 0; i < n_images; i++) {
             OrbJob &j = jobs[i];
             if (j.n_fast == 0) continue;
+            hipStream_t s = lane_stream[i % lanes];
             CVHIP_TRY_HIP(mem.alloc(&j.d_kp, (size_t)j.n_fast * 2));
             hipLaunchKernelGGL(nms_write_kernel, dim3(j.nblocks), dim3(256), 0, s, j.d_score, j.w, j.h, j.d_counts, j.n_fast, j.d_kp);
             unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
@@ -857,11 +884,12 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
                                j.d_sc);
             if (i == 0) report(0.35f);
             if (guard > 0.0) {
-                CVHIP_TRY(describe(j, guard));
+                CVHIP_TRY(describe(j, guard, s));
             } else { // device orientations switched off (cvhip_orb_set_orientation_guard(dev, 0)): the host path for all
                 CVHIP_TRY_HIP(hipMemcpyAsync(stage + j.mom_off, j.d_mom, j.mom_bytes, hipMemcpyDeviceToHost, s));
             }
         }
+        CVHIP_TRY(join());
         report(0.70f);
         CVHIP_TRY_HIP(hipStreamSynchronize(s));
         CVHIP_TRY_HIP(hipGetLastError());
@@ -919,7 +947,7 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             for (auto &th : pool) th.join();
             for (OrbJob *j : redo) {
                 CVHIP_TRY_HIP(hipMemcpyAsync(j->d_sc, stage + j->sc_off, j->sc_bytes, hipMemcpyHostToDevice, s));
-                CVHIP_TRY(describe(*j, 0.0));
+                CVHIP_TRY(describe(*j, 0.0, s));
             }
             CVHIP_TRY_HIP(hipStreamSynchronize(s));
             CVHIP_TRY_HIP(hipGetLastError());
