@@ -589,6 +589,111 @@ __global__ __launch_bounds__(256) void match_kernel(const uint32_t *__restrict__
     }
     if (q < n1 && bj != 0xFFFFFFFFu) atomicMin(&best[q], ((unsigned long long)bd << 32) | bj);
 }
+// ---- the same minimum on the matrix pipe ------------------------------------------------------------------------
+// Hamming distance of 256-bit descriptors is an inner product: d(a, b) = |a| + |b| - 2 a.b with the bits as 0 / 1.
+// All pairs of 30 000 x 30 000 descriptors are then a [n1 x 256] x [256 x n2] integer matrix product, which
+// v_mfma_i32_32x32x32_i8 does exactly (8 instructions per 32 x 32 pairs against ~19 vector instructions PER PAIR of the
+// kernel above, which is bound by vector issue: 0.63 ms for config 5's 30 000 x 29 000).  The descriptors are expanded
+// once per call to one byte per bit (queries 0 / 1, candidates 0 / -1, so the product comes out as -a.b), with their
+// popcounts next to them; a wave keeps the 32 x 256 bytes of its 32 queries in registers, the candidate tiles stream
+// through LDS (shared by the workgroup's four waves), and the epilogue per product is one shift-add and one minimum
+// on the key  (|b| + 256 + 2 (-a.b)) << 16 | j  - |a| is added once at the end, the minimum over j commutes with it.
+// Both operands use the same lane -> byte map (lane l = row / column l & 31, bytes 16 (l >> 5) .. +15 of the 32-byte
+// K slab), so the instruction's internal k order is irrelevant: a sum over all 256 positions either way.
+// First minimum wins as above: the key's low half is j, and the splits of the candidate list meet in the same
+// 64-bit atomicMin.
+typedef int match_i32x4 __attribute__((ext_vector_type(4)));
+typedef int match_i32x16 __attribute__((ext_vector_type(16)));
+constexpr uint32_t MM_ROWS = 32;       // queries per wave, candidates per tile
+constexpr uint32_t MM_PAD_COUNT = 0x4000; // popcount given to the padding rows: no threshold admits them
+
+// bits -> bytes (ones = 1 for queries, 0xFF for candidates), popcounts; rows n .. n_pad - 1 are padding
+__global__ __launch_bounds__(256) void match_expand_kernel(const uint32_t *__restrict__ desc, uint32_t n, uint32_t n_pad,
+                                                            uint32_t one, uint32_t *__restrict__ bytes, uint32_t *__restrict__ pop)
+{
+    // one thread per (row, 32-bit word): 32 bytes out
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x, row = t >> 3, wd = t & 7u;
+    if (row >= n_pad) return;
+    const uint32_t v = row < n ? desc[(size_t)row * 8 + wd] : 0u;
+    uint4 *out = reinterpret_cast<uint4 *>(bytes + (size_t)row * 64 + wd * 8);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t nib = (v >> (16 * q + 4 * k)) & 0xFu;
+            o[k] = ((nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21)) * one;
+        }
+        out[q] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    if (wd == 0) {
+        uint32_t c = MM_PAD_COUNT;
+        if (row < n) {
+            c = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) c += __popc(desc[(size_t)row * 8 + k]);
+        }
+        pop[row] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void match_mfma_kernel(const uint32_t *__restrict__ qbytes, const uint32_t *__restrict__ qpop,
+                                                          uint32_t n1, const uint32_t *__restrict__ cbytes,
+                                                          const uint32_t *__restrict__ cpop, uint32_t n2_pad, uint32_t chunk,
+                                                          uint32_t threshold, unsigned long long *__restrict__ best)
+{
+    constexpr uint32_t PITCH = 17;          // uint4 per candidate row: 16 + 1, so that the 32 rows a ds_read_b128 touches spread over the banks
+    __shared__ uint4 tile[MM_ROWS * PITCH]; // 32 candidates x 256 bytes
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, r = lane & 31u, h = lane >> 5;
+    const uint32_t q0 = (blockIdx.x * 4 + wave) * MM_ROWS; // this wave's queries (rows past n1 are padding: they exist)
+    // A: query q0 + r, K slab s = bytes 32 s + 16 h .. + 15
+    match_i32x4 a[8];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(qbytes + (size_t)(q0 + r) * 64);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            const uint4 v = src[2 * s8 + h];
+            a[s8] = match_i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        }
+    }
+    uint32_t lowest[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) lowest[i] = 0xFFFFFFFFu;
+    const uint32_t first = blockIdx.y * chunk, last = min(n2_pad, first + chunk); // multiples of MM_ROWS
+    for (uint32_t base = first; base < last; base += MM_ROWS) {
+        __syncthreads();
+        // the tile: 32 x 256 bytes = 512 uint4, two per thread
+        tile[(threadIdx.x >> 4) * PITCH + (threadIdx.x & 15u)] = reinterpret_cast<const uint4 *>(cbytes + (size_t)base * 64)[threadIdx.x];
+        tile[((threadIdx.x >> 4) + 16u) * PITCH + (threadIdx.x & 15u)] = reinterpret_cast<const uint4 *>(cbytes + (size_t)base * 64)[threadIdx.x + 256];
+        // this lane's candidate (column r of the tile): its popcount and index in the key's format.  |b| - 2 a.b alone can
+        // be negative (down to -|b|): a bias of 256 keeps the key's high half an unsigned number until |a| is added
+        const uint32_t kb = ((cpop[base + r] + 256u) << 16) | (base - first + r);
+        __syncthreads();
+        match_i32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            const uint4 v = tile[r * PITCH + 2 * s8 + h];
+            const match_i32x4 b = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s8], b, acc, 0, 0, 0);
+        }
+        // acc[i] = -(common ones) of query row (i & 3) + 8 (i >> 2) + 4 h and candidate column r
+#pragma unroll
+        for (int i = 0; i < 16; i++) lowest[i] = min(lowest[i], ((uint32_t)acc[i] << 17) + kb);
+    }
+    // per query: + its own popcount, the threshold, the minimum over the 32 candidate columns (lanes of one half)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t q = q0 + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+        uint32_t key = lowest[i];
+#pragma unroll
+        for (int sft = 16; sft > 0; sft >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, sft, 64)); // (stays inside a half of 32)
+        if (r == 0 && q < n1 && key != 0xFFFFFFFFu) {
+            const uint32_t d = (key >> 16) + qpop[q] - 256u; // |a| + |b| - 2 a.b
+            if (d <= threshold) atomicMin(&best[q], ((unsigned long long)d << 32) | (unsigned long long)(first + (key & 0xFFFFu)));
+        }
+    }
+}
+
 // best[] -> the sort's keys (distance; 0xFFFFFFFF = no match, sorts last), the matched index and the query index
 __global__ __launch_bounds__(256) void match_unpack_kernel(const unsigned long long *__restrict__ best, uint32_t n1,
                                                             uint32_t *__restrict__ best_j, uint32_t *__restrict__ best_d,
@@ -1020,11 +1125,31 @@ extern "C" int cvhip_match_points(cvhip_device *dev, const uint32_t *xy1, const 
     unsigned long long *d_key = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_key, n1));
     CVHIP_TRY_HIP(hipMemsetAsync(d_key, 0xFF, (size_t)n1 * sizeof(unsigned long long), s)); // no match
-    const uint32_t qblocks = (n1 + 255) / 256, tiles = (n2 + MATCH_TILE - 1) / MATCH_TILE;
-    const uint32_t splits = std::max(1u, std::min(tiles, (2048u + qblocks - 1) / qblocks)); // >= ~2 workgroups per SIMD
-    const uint32_t chunk = (tiles + splits - 1) / splits * MATCH_TILE;
-    hipLaunchKernelGGL(match_kernel, dim3(qblocks, (n2 + chunk - 1) / chunk), dim3(256), 0, s, d_desc1, n1, d_desc2, n2, chunk,
-                       threshold, d_key);
+    const uint32_t qblocks = (n1 + 255) / 256;
+    if ((size_t)n1 * n2 >= (size_t)1 << 22 && threshold < MM_PAD_COUNT) {
+        // the matrix-pipe form (see match_mfma_kernel): descriptors as bytes, 128 queries per workgroup, the candidate list
+        // split so that the launch has ~4 workgroups per CU (a split covers at most 65 536 candidates: 16 bits of the key)
+        const uint32_t n1_pad = (n1 + 127u) / 128u * 128u, n2_pad = (n2 + MM_ROWS - 1) / MM_ROWS * MM_ROWS;
+        uint32_t *d_b1 = nullptr, *d_b2 = nullptr, *d_p1 = nullptr, *d_p2 = nullptr;
+        CVHIP_TRY_HIP(mem.alloc(&d_b1, (size_t)n1_pad * 64));
+        CVHIP_TRY_HIP(mem.alloc(&d_b2, (size_t)n2_pad * 64));
+        CVHIP_TRY_HIP(mem.alloc(&d_p1, n1_pad));
+        CVHIP_TRY_HIP(mem.alloc(&d_p2, n2_pad));
+        hipLaunchKernelGGL(match_expand_kernel, dim3((n1_pad * 8 + 255) / 256), dim3(256), 0, s, d_desc1, n1, n1_pad, 1u, d_b1, d_p1);
+        hipLaunchKernelGGL(match_expand_kernel, dim3((n2_pad * 8 + 255) / 256), dim3(256), 0, s, d_desc2, n2, n2_pad, 0xFFu, d_b2, d_p2);
+        const uint32_t wgs = n1_pad / 128u, tiles = n2_pad / MM_ROWS;
+        uint32_t splits = std::max(1u, std::min(tiles, (1024u + wgs - 1) / wgs));
+        uint32_t chunk = (tiles + splits - 1) / splits * MM_ROWS;
+        chunk = std::min(chunk, 65536u);
+        hipLaunchKernelGGL(match_mfma_kernel, dim3(wgs, (n2_pad + chunk - 1) / chunk), dim3(256), 0, s, (const uint32_t *)d_b1,
+                           (const uint32_t *)d_p1, n1, (const uint32_t *)d_b2, (const uint32_t *)d_p2, n2_pad, chunk, threshold, d_key);
+    } else {
+        const uint32_t tiles = (n2 + MATCH_TILE - 1) / MATCH_TILE;
+        const uint32_t splits = std::max(1u, std::min(tiles, (2048u + qblocks - 1) / qblocks)); // >= ~2 workgroups per SIMD
+        const uint32_t chunk = (tiles + splits - 1) / splits * MATCH_TILE;
+        hipLaunchKernelGGL(match_kernel, dim3(qblocks, (n2 + chunk - 1) / chunk), dim3(256), 0, s, d_desc1, n1, d_desc2, n2, chunk,
+                           threshold, d_key);
+    }
     hipLaunchKernelGGL(match_unpack_kernel, dim3(qblocks), dim3(256), 0, s, (const unsigned long long *)d_key, n1, d_bj, d_bd,
                        d_q);
     // stable ascending sort by distance (sort_by_key, pointmatching.rs:74); unmatched = ~0 go last

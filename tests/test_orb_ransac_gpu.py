@@ -100,6 +100,54 @@ def test_matcher_ties_across_candidate_chunks(gpu_device, oracle):
     assert (want_m[:, 2] < 40).all()  # (x2 = the candidate's index: always a first occurrence)
 
 
+def test_matcher_matrix_pipe_path(gpu_device, oracle):
+    """Large descriptor sets go through match_mfma_kernel (Hamming distance as an int8 matrix product): random
+    descriptors with planted near-duplicates at every small distance, duplicates of one candidate spread over MORE than
+    65 536 candidates (several splits of the candidate list, first index must win), ragged sizes, thresholds 0 .. 256."""
+    rng = np.random.default_rng(23)
+
+    def rand_desc(n):
+        return rng.integers(0, 2 ** 32, size=(n, 8), dtype=np.uint64).astype(np.uint32)
+
+    # (a) random sets with near-duplicates: query i is candidate perm[i] with (i % 40) bits flipped
+    n1, n2 = 2500, 2300
+    desc2 = rand_desc(n2)
+    desc1 = desc2[rng.integers(0, n2, size=n1)].copy()
+    for i in range(n1):
+        for b in rng.choice(256, size=i % 40, replace=False):
+            desc1[i, b // 32] ^= np.uint32(1) << np.uint32(b % 32)
+    desc1[-50:] = rand_desc(50)  # and some with no close candidate at all
+    xy1 = np.stack([np.arange(n1), np.arange(n1) + 3], axis=1).astype(np.uint32)
+    xy2 = np.stack([np.arange(n2), 2 * np.arange(n2)], axis=1).astype(np.uint32)
+    for thr in (0, 5, 48, 64, 200, 256):
+        want_m, want_d = oracle.match_points(xy1, desc1, xy2, desc2, thr)
+        got_m, got_d = pointmatching.match_points(gpu_device, xy1, desc1, xy2, desc2, thr)
+        assert got_m.shape == want_m.shape and (got_m == want_m).all() and (got_d == want_d).all(), thr
+    # (b) ties across the splits of a long candidate list: 40 base descriptors, each 1 801 times among 72 040 candidates
+    base = rand_desc(40)
+    desc2 = np.tile(base, (1801, 1))
+    desc1 = np.concatenate([base, base ^ np.uint32(1), base ^ np.uint32(3), np.roll(base, 1, axis=0)])
+    xy1 = np.stack([np.arange(len(desc1)), np.arange(len(desc1)) + 3], axis=1).astype(np.uint32)
+    xy2 = np.stack([np.arange(len(desc2)), 2 * np.arange(len(desc2))], axis=1).astype(np.uint32)
+    for thr in (0, 1, 64):
+        want_m, want_d = oracle.match_points(xy1, desc1, xy2, desc2, thr)
+        got_m, got_d = pointmatching.match_points(gpu_device, xy1, desc1, xy2, desc2, thr)
+        assert got_m.shape == want_m.shape and (got_m == want_m).all() and (got_d == want_d).all(), thr
+    assert (want_m[:, 2] < 40).all()  # (x2 = the candidate's index: always a first occurrence)
+    # (c) all-zero and all-one descriptors (popcounts 0 and 256: the key's bias)
+    desc1 = np.zeros((2100, 8), dtype=np.uint32)
+    desc1[1::2] = 0xFFFFFFFF
+    desc2 = np.zeros((2050, 8), dtype=np.uint32)
+    desc2[::3] = 0xFFFFFFFF
+    desc2[5] = 0x0000FFFF
+    xy1 = np.stack([np.arange(len(desc1)), np.arange(len(desc1))], axis=1).astype(np.uint32)
+    xy2 = np.stack([np.arange(len(desc2)), np.arange(len(desc2))], axis=1).astype(np.uint32)
+    for thr in (0, 128, 256):
+        want_m, want_d = oracle.match_points(xy1, desc1, xy2, desc2, thr)
+        got_m, got_d = pointmatching.match_points(gpu_device, xy1, desc1, xy2, desc2, thr)
+        assert got_m.shape == want_m.shape and (got_m == want_m).all() and (got_d == want_d).all(), thr
+
+
 def ransac_inputs(n=3000, hyp=700, seed=2):
     rng = np.random.default_rng(seed)
     x1 = rng.integers(0, 2000, size=n)
