@@ -534,6 +534,8 @@ void device_free(cvhip_device *dev)
         for (hipEvent_t ev : sa.done)
             if (ev) (void)hipEventDestroy(ev);
         if (sa.fence) (void)hipEventDestroy(sa.fence);
+        if (sa.probe_side) (void)hipEventDestroy(sa.probe_side);
+        if (sa.probe_main) (void)hipEventDestroy(sa.probe_main);
     }
     if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
     if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
@@ -798,6 +800,19 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
         uint2 *const st0 = ctx->istats[0] + stats_level_offset(ctx->max_px, k), *const st1 = ctx->istats[1] + stats_level_offset(ctx->max_px, k);
         stats_ahead = ctx->stats_ahead && ctx->time_kernels != 1 && !sharded && ctx->borrow_inputs &&
                       is_device_ptr(img1) && is_device_ptr(img2) && k < 16;
+        if (stats_ahead && ctx->dev->d.sa.verdict == 0 && ctx->dev->d.sa.probe_recorded && first_pass) {
+            // the previous run's probe, if it has completed (never waits)
+            Device::StatsAhead &sa = ctx->dev->d.sa;
+            float lead_ms = 0.0f;
+            const hipError_t pe = hipEventElapsedTime(&lead_ms, sa.probe_side, sa.probe_main);
+            if (pe == hipSuccess) {
+                sa.verdict = lead_ms > 0.05f ? 1 : -1; // (overlapping: ~1 ms at 4096^2; in line: zero or negative)
+                sa.probe_recorded = false;
+            } else {
+                (void)hipGetLastError(); // hipErrorNotReady: ask again at the next run
+            }
+        }
+        if (stats_ahead && ctx->dev->d.sa.verdict < 0) stats_ahead = false;
         if (stats_ahead) {
             // The statistics depend on the level's images only.  On a stream of their own they run while the main stream
             // works through the coarse levels - a chain of ~40 small dependent launches that leaves the chip idle for
@@ -814,6 +829,15 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
                 CVHIP_TRY_HIP(hipStreamWaitEvent(side, d.sa.fence, 0));
                 CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 8 * sizeof(uint32_t), s));
                 ctx->stats_ahead_fenced = true;
+            }
+            // (only where the answer is unambiguous: a full-resolution level of a megapixel or more, several levels deep)
+            const bool probe = d.sa.verdict == 0 && !d.sa.probe_recorded && k == 0 && !first_pass && (size_t)w1 * h1 >= ((size_t)1 << 20);
+            if (probe) {
+                if (!d.sa.probe_side) CVHIP_TRY_HIP(hipEventCreate(&d.sa.probe_side));
+                if (!d.sa.probe_main) CVHIP_TRY_HIP(hipEventCreate(&d.sa.probe_main));
+                CVHIP_TRY_HIP(hipEventRecord(d.sa.probe_side, side)); // the full-resolution statistics start here ...
+                CVHIP_TRY_HIP(hipEventRecord(d.sa.probe_main, s));    // ... and the main stream gets here when level 1 is done
+                d.sa.probe_recorded = true;
             }
             // (48 KB of LDS ballast per workgroup: three of them per CU instead of eight.  A full-chip grid beside the
             // coarse levels starved their small kernels - a 30 us box launch took the 370 us of the statistics kernel,

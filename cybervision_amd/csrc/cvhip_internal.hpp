@@ -223,6 +223,14 @@ struct Device {
     struct StatsAhead {
         hipEvent_t done[16] = {};
         hipEvent_t fence = nullptr;
+        // Self-check.  Two streams only overlap if the driver gave them different hardware queues; on one queue the
+        // throttled statistics kernel would stand IN LINE with everything else, at 3/8 of its normal occupancy - worse than
+        // not using the mode at all.  Until a verdict exists, a pyramid run records when the full-resolution statistics
+        // START on the side stream and when the main stream ARRIVES at that level; the next run reads the two (if they have
+        // completed): statistics that did not start well before the arrival did not overlap - the mode switches itself off.
+        hipEvent_t probe_side = nullptr, probe_main = nullptr;
+        bool probe_recorded = false;
+        int verdict = 0; // 0 = not known yet, 1 = overlapping, -1 = switched off
     } sa;
     // RCCL communicators created on this handle (cvhip_rccl_create) enqueue on its stream: while any is alive,
     // cvhip_device_destroy only marks the handle and the last cvhip_rccl_destroy frees it
