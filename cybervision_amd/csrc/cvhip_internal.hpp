@@ -212,6 +212,13 @@ struct Device {
     // stream of its own for the statistics, config 5's RANSAC stage ran 22 -> 27 ms in a process that had used both)
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t orb_ev[3] = {nullptr, nullptr, nullptr}; // cvhip_orb_extract_batch's fork / join events
+    struct OrbLanes { // ... and what it learned about running three image chains at once on this handle (orb_kernels.hip)
+        size_t shape = 0;
+        double best_ms = 0.0;
+        uint32_t samples = 0; // batches timed so far (three lanes, two, one)
+        bool decided = false;
+        uint32_t use_lanes = 3;
+    } orb_lanes;
     // the RANSAC loops' generator streams and round events (created on first use: creating two streams and seven events
     // per find_ransac call cost 1.5 ms of every ~9 ms call)
     struct RansacQueues {

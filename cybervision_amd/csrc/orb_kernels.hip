@@ -22,6 +22,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <chrono>
 #include <cmath>
 #include <system_error>
 #include <thread>
@@ -845,7 +846,26 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
     // handle's stream and its two side streams, forked and joined with events around each stage.
     constexpr uint32_t LANES = 3;
     hipStream_t lane_stream[LANES] = {s, nullptr, nullptr};
-    const uint32_t lanes = n_images > 1 ? LANES : 1;
+    // Three chains only run side by side if the driver gave the three streams different hardware queues - it does not
+    // always (config 5's twelve extractions: 2.3 ms, or 3.7 ms in about every other process; 3.4 ms on one stream).  So the
+    // handle times three, two and one chain(s) at a time on the batches after the first of a shape and keeps the fastest.
+    Device::OrbLanes &ol = dev->d.orb_lanes;
+    size_t shape = n_images;
+    for (uint32_t i = 0; i < n_images; i++) shape = shape * 1000003u + (size_t)ws[i] * 65537u + hs[i];
+    uint32_t lanes = n_images > 1 ? LANES : 1;
+    int measuring = 0; // 1 + the number of lanes this call is the sample for
+    if (n_images > 1) {
+        if (ol.shape != shape) { // (the first batch of a shape also pays for streams, events and staging memory: not a sample)
+            ol = Device::OrbLanes{};
+            ol.shape = shape;
+        } else if (ol.decided) {
+            lanes = ol.use_lanes;
+        } else {
+            lanes = LANES - ol.samples; // three, then two, then one
+            measuring = 1 + (int)lanes;
+        }
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
     for (uint32_t l = 1; l < lanes; l++) CVHIP_TRY_HIP(aux_stream(dev->d, (int)l - 1, &lane_stream[l]));
     for (uint32_t l = 0; l < lanes; l++)
         if (!dev->d.orb_ev[l]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&dev->d.orb_ev[l], hipEventDisableTiming));
@@ -1071,6 +1091,14 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             *j.out_n = n_out;
         }
         report(1.0f);
+        if (measuring) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            if (ol.samples == 0 || ms < 0.95 * ol.best_ms) { // (fewer lanes only where they are clearly faster)
+                ol.best_ms = ms;
+                ol.use_lanes = lanes;
+            }
+            ol.decided = ++ol.samples == LANES;
+        }
         return CVHIP_OK;
     } catch (const std::bad_alloc &) {
         return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of host memory");
