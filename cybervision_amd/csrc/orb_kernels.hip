@@ -54,7 +54,7 @@ struct Taps11 {
 // ---------------------------------------------------------------------------------------------
 // img is the library's own 4-byte-aligned copy: dword loads, four pixels per lane and load; one pair of atomics per
 // workgroup (a pair per wave from 2048 workgroups - 16 k atomics on two addresses - cost 120 us per image).
-__global__ __launch_bounds__(256) void minmax_kernel(const uint8_t *__restrict__ img, size_t n, uint32_t *__restrict__ mm)
+__device__ __forceinline__ void minmax_body(const uint8_t *__restrict__ img, size_t n, uint32_t *__restrict__ mm)
 {
     __shared__ uint32_t wlo[4], whi[4];
     uint32_t lo = 255, hi = 0;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t *__restrict__
     }
 }
 
-__global__ void contrast_kernel(const uint8_t *__restrict__ img, size_t n, const uint32_t *__restrict__ mm,
+__device__ __forceinline__ void contrast_body(const uint8_t *__restrict__ img, size_t n, const uint32_t *__restrict__ mm,
                                 uint8_t *__restrict__ out)
 {
     const uint32_t lo = mm[0], hi = mm[1];
@@ -130,7 +130,7 @@ __device__ __forceinline__ int ring_best_min9(const int (&d)[16])
     return best;
 }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+__device__ __forceinline__ void fast_score_body(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
                                                           uint8_t *__restrict__ score)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -174,7 +174,7 @@ __device__ __forceinline__ bool nms_survives(const uint8_t *__restrict__ score, 
 // ---------------------------------------------------------------------------------------------
 // ordered (scan-order) stream compaction helpers: block counts -> exclusive scan -> write
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nms_count_kernel(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
+__device__ __forceinline__ void nms_count_body(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
                                                          uint32_t *__restrict__ block_counts)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void nms_count_kernel(const uint8_t *__restric
 }
 
 // single-block exclusive scan over n values (in place); total written to *total
-__global__ __launch_bounds__(1024) void exclusive_scan_kernel(uint32_t *__restrict__ data, uint32_t n,
+__device__ __forceinline__ void exclusive_scan_body(uint32_t *__restrict__ data, uint32_t n,
                                                                uint32_t *__restrict__ total)
 {
     __shared__ uint32_t wtot[16];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(uint32_t *__restri
     if (threadIdx.x == 0) *total = carry_s;
 }
 
-__global__ __launch_bounds__(256) void nms_write_kernel(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
+__device__ __forceinline__ void nms_write_body(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
                                                          const uint32_t *__restrict__ block_offsets, uint32_t cap,
                                                          uint32_t *__restrict__ out_xy)
 {
@@ -260,18 +260,20 @@ __device__ __forceinline__ unsigned long long f64_order_key(double v)
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
-__global__ __launch_bounds__(64) void harris_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+__device__ __forceinline__ void harris_body(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
                                                      const uint32_t *__restrict__ kp_xy,
                                                      const uint32_t *__restrict__ n_ptr, uint32_t cap, Taps7 kg,
                                                      unsigned long long *__restrict__ keys,
-                                                     uint32_t *__restrict__ idx)
+                                                     uint32_t *__restrict__ idx, uint32_t tag = 0u, uint32_t none = 0xFFFFFFFFu)
 {
+    // tag / none: the batched form sorts the corners of several images together - the value carries the image in its top
+    // bits (tag), and "None" is the all-ones INDEX under that tag
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     const uint32_t n = min(*n_ptr, cap);
     if (i >= cap) return;
     if (i >= n) {
         keys[i] = 0ull;
-        idx[i] = 0xFFFFFFFFu;
+        idx[i] = none;
         return;
     }
     const double sobel_x[9] = {-1.0, 0.0, 1.0, -2.0, 0.0, 2.0, -1.0, 0.0, 1.0};
@@ -305,13 +307,13 @@ __global__ __launch_bounds__(64) void harris_kernel(const uint8_t *__restrict__ 
         key = f64_order_key(det - HARRIS_K * (trace * trace));
     }
     keys[i] = key;
-    idx[i] = ok ? i : 0xFFFFFFFFu;
+    idx[i] = ok ? (i | tag) : none;
 }
 
 // ---------------------------------------------------------------------------------------------
 // gaussian_blur<11> (orb.rs:271-314): horizontal then vertical, f64, taps added in index order.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+__device__ __forceinline__ void blur_h_body(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
                                                       Taps11 kg, double *__restrict__ out)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t *__restrict__
     }
     out[(size_t)y * w + x] = sum;
 }
-__global__ __launch_bounds__(256) void blur_v_kernel(const double *__restrict__ in, uint32_t w, uint32_t h, Taps11 kg,
+__device__ __forceinline__ void blur_v_body(const double *__restrict__ in, uint32_t w, uint32_t h, Taps11 kg,
                                                       double *__restrict__ out)
 {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -351,7 +353,7 @@ __device__ __forceinline__ bool blur_valid(uint32_t w, uint32_t h, uint32_t x, u
 // patch moments (orb.rs:316-339): one wave per ranked keypoint.  Integer sums are exact, so the
 // wave-parallel reduction equals the reference's serial loop.  out = (m00, m10, m01, valid).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void moments_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
+__device__ __forceinline__ void moments_body(const double *__restrict__ blur, uint32_t w, uint32_t h,
                                                       const uint32_t *__restrict__ kp_xy,
                                                       const uint32_t *__restrict__ sorted_idx, uint32_t count,
                                                       unsigned long long *__restrict__ out, double *__restrict__ sincos)
@@ -441,7 +443,7 @@ __device__ __forceinline__ unsigned long long sat_add_signed(unsigned long long 
     return a > nb ? a - nb : 0ull;
 }
 
-__global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
+__device__ __forceinline__ void brief_body(const double *__restrict__ blur, uint32_t w, uint32_t h,
                                                     const uint32_t *__restrict__ kp_xy,
                                                     const uint32_t *__restrict__ sorted_idx, uint32_t count,
                                                     const double *__restrict__ sincos,
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ bl
 }
 
 // ordered compaction of <= 10240 ranked keypoints by flag (single block)
-__global__ __launch_bounds__(1024) void final_compact_kernel(const uint32_t *__restrict__ flags,
+__device__ __forceinline__ void final_compact_body(const uint32_t *__restrict__ flags,
                                                               const uint32_t *__restrict__ kp_xy,
                                                               const uint32_t *__restrict__ sorted_idx,
                                                               const uint32_t *__restrict__ desc, uint32_t count,
@@ -547,6 +549,197 @@ __global__ __launch_bounds__(1024) void final_compact_kernel(const uint32_t *__r
         __syncthreads();
     }
     if (threadIdx.x == 0) *out_n = min(carry_s, cap);
+}
+
+
+// ---- launchable forms: one image per launch (the redo path, single images), and one launch for ALL images of a batch
+// (blockIdx.z = the image: the bodies only ever look at blockIdx.x / .y) ----
+__global__ __launch_bounds__(256) void minmax_kernel(const uint8_t *__restrict__ img, size_t n, uint32_t *__restrict__ mm)
+{
+    minmax_body(img, n, mm);
+}
+__global__ void contrast_kernel(const uint8_t *__restrict__ img, size_t n, const uint32_t *__restrict__ mm,
+                                uint8_t *__restrict__ out)
+{
+    contrast_body(img, n, mm, out);
+}
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+                                                          uint8_t *__restrict__ score)
+{
+    fast_score_body(img, w, h, score);
+}
+__global__ __launch_bounds__(256) void nms_count_kernel(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
+                                                         uint32_t *__restrict__ block_counts)
+{
+    nms_count_body(score, w, h, block_counts);
+}
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(uint32_t *__restrict__ data, uint32_t n,
+                                                               uint32_t *__restrict__ total)
+{
+    exclusive_scan_body(data, n, total);
+}
+__global__ __launch_bounds__(256) void nms_write_kernel(const uint8_t *__restrict__ score, uint32_t w, uint32_t h,
+                                                         const uint32_t *__restrict__ block_offsets, uint32_t cap,
+                                                         uint32_t *__restrict__ out_xy)
+{
+    nms_write_body(score, w, h, block_offsets, cap, out_xy);
+}
+__global__ __launch_bounds__(64) void harris_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+                                                     const uint32_t *__restrict__ kp_xy,
+                                                     const uint32_t *__restrict__ n_ptr, uint32_t cap, Taps7 kg,
+                                                     unsigned long long *__restrict__ keys,
+                                                     uint32_t *__restrict__ idx)
+{
+    harris_body(img, w, h, kp_xy, n_ptr, cap, kg, keys, idx);
+}
+__global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t *__restrict__ img, uint32_t w, uint32_t h,
+                                                      Taps11 kg, double *__restrict__ out)
+{
+    blur_h_body(img, w, h, kg, out);
+}
+__global__ __launch_bounds__(256) void blur_v_kernel(const double *__restrict__ in, uint32_t w, uint32_t h, Taps11 kg,
+                                                      double *__restrict__ out)
+{
+    blur_v_body(in, w, h, kg, out);
+}
+__global__ __launch_bounds__(64) void moments_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
+                                                      const uint32_t *__restrict__ kp_xy,
+                                                      const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                      unsigned long long *__restrict__ out, double *__restrict__ sincos)
+{
+    moments_body(blur, w, h, kp_xy, sorted_idx, count, out, sincos);
+}
+__global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
+                                                    const uint32_t *__restrict__ kp_xy,
+                                                    const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                    const double *__restrict__ sincos,
+                                                    const signed char *__restrict__ pattern,
+                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ flags, double guard,
+                                                    uint32_t *__restrict__ open_count)
+{
+    brief_body(blur, w, h, kp_xy, sorted_idx, count, sincos, pattern, desc, flags, guard, open_count);
+}
+__global__ __launch_bounds__(1024) void final_compact_kernel(const uint32_t *__restrict__ flags,
+                                                              const uint32_t *__restrict__ kp_xy,
+                                                              const uint32_t *__restrict__ sorted_idx,
+                                                              const uint32_t *__restrict__ desc, uint32_t count,
+                                                              uint32_t cap, uint32_t *__restrict__ out_xy,
+                                                              uint32_t *__restrict__ out_desc,
+                                                              uint32_t *__restrict__ out_n)
+{
+    final_compact_body(flags, kp_xy, sorted_idx, desc, count, cap, out_xy, out_desc, out_n);
+}
+
+// One image of a batch as the batched launches see it (a table of these in device memory, blockIdx.z picks the row).
+struct OrbJobDev {
+    const uint8_t *img;       // the library's padded copy
+    uint8_t *adj, *score;
+    uint32_t *mm, *counts, *total;
+    uint32_t w, h, nblocks, rblocks, g2x, g2y;
+    unsigned long long n;
+    // stage B
+    uint32_t n_fast, count, out_cap, key_off;
+    uint32_t *kp, *idx_sorted, *desc, *flags, *pack, *out_xy, *out_desc;
+    unsigned long long *keys, *mom;
+    uint32_t *idx;
+    double *blur_h, *blur, *sc;
+};
+constexpr uint32_t ORB_TAG_SHIFT = 28, ORB_TAG_MASK = 0x0FFFFFFFu; // (image << 28 | corner index) as the sorts' value
+
+__global__ __launch_bounds__(256) void orb_stage_a_init_jobs(const OrbJobDev *jobs, uint32_t n_jobs)
+{
+    for (uint32_t i = threadIdx.x; i < n_jobs; i += 256) {
+        jobs[i].mm[0] = 255u; // {min, max} = {255, 0}
+        jobs[i].mm[1] = 0u;
+    }
+}
+__global__ __launch_bounds__(256) void minmax_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    minmax_body(j.img, (size_t)j.n, j.mm); // (a grid-stride loop: every workgroup of the launch takes part)
+}
+__global__ __launch_bounds__(256) void contrast_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    contrast_body(j.img, (size_t)j.n, j.mm, j.adj);
+}
+__global__ __launch_bounds__(256) void fast_score_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= j.g2x || blockIdx.y >= j.g2y) return;
+    fast_score_body(j.adj, j.w, j.h, j.score);
+}
+__global__ __launch_bounds__(256) void nms_count_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= j.nblocks) return;
+    nms_count_body(j.score, j.w, j.h, j.counts);
+}
+__global__ __launch_bounds__(1024) void exclusive_scan_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    exclusive_scan_body(j.counts, j.nblocks, j.total);
+}
+__global__ __launch_bounds__(256) void nms_write_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= j.nblocks || j.n_fast == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x < 2) j.pack[threadIdx.x] = 0u; // {n_out, open count} of the describe step
+    nms_write_body(j.score, j.w, j.h, j.counts, j.n_fast, j.kp);
+}
+__global__ __launch_bounds__(64) void harris_jobs(const OrbJobDev *jobs, Taps7 kg)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= (j.n_fast + 63u) / 64u) return;
+    const uint32_t tag = blockIdx.z << ORB_TAG_SHIFT;
+    harris_body(j.img, j.w, j.h, j.kp, j.total, j.n_fast, kg, j.keys, j.idx, tag, tag | ORB_TAG_MASK);
+}
+// Grouping the globally sorted corners by image, keeping their order: rank r of the first sort gets the 32-bit key
+// (image << 28 | r), a full-width sort of those keys brings every image's ranks together in ascending r, and the
+// gather below turns them back into plain per-image index lists (None = ~0, as the single-image sort leaves it).
+__global__ __launch_bounds__(256) void orb_rank_key_kernel(const uint32_t *__restrict__ tagged, uint32_t n, uint32_t *__restrict__ key)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    key[i] = (tagged[i] & ~ORB_TAG_MASK) | i;
+}
+__global__ __launch_bounds__(256) void orb_untag_kernel(const uint32_t *__restrict__ tagged, const uint32_t *__restrict__ key_sorted,
+                                                        uint32_t n, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = tagged[key_sorted[i] & ORB_TAG_MASK] & ORB_TAG_MASK;
+    out[i] = v == ORB_TAG_MASK ? 0xFFFFFFFFu : v;
+}
+__global__ __launch_bounds__(256) void blur_h_jobs(const OrbJobDev *jobs, Taps11 kg)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= j.g2x || blockIdx.y >= j.g2y || j.n_fast == 0) return;
+    blur_h_body(j.img, j.w, j.h, kg, j.blur_h);
+}
+__global__ __launch_bounds__(256) void blur_v_jobs(const OrbJobDev *jobs, Taps11 kg)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= j.g2x || blockIdx.y >= j.g2y || j.n_fast == 0) return;
+    blur_v_body(j.blur_h, j.w, j.h, kg, j.blur);
+}
+__global__ __launch_bounds__(64) void moments_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= j.count) return;
+    moments_body(j.blur, j.w, j.h, j.kp, j.idx_sorted, j.count, j.mom, j.sc);
+}
+__global__ __launch_bounds__(64) void brief_jobs(const OrbJobDev *jobs, const signed char *__restrict__ pattern, double guard)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (blockIdx.x >= j.count) return;
+    brief_body(j.blur, j.w, j.h, j.kp, j.idx_sorted, j.count, j.sc, pattern, j.desc, j.flags, guard, j.pack + 1);
+}
+__global__ __launch_bounds__(1024) void final_compact_jobs(const OrbJobDev *jobs)
+{
+    const OrbJobDev &j = jobs[blockIdx.z];
+    if (j.n_fast == 0) return;
+    final_compact_body(j.flags, j.kp, j.idx_sorted, j.desc, j.count, j.out_cap, j.out_xy, j.out_desc, j.pack);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -852,9 +1045,16 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
     Device::OrbLanes &ol = dev->d.orb_lanes;
     size_t shape = n_images;
     for (uint32_t i = 0; i < n_images; i++) shape = shape * 1000003u + (size_t)ws[i] * 65537u + hs[i];
-    uint32_t lanes = n_images > 1 ? LANES : 1;
+    // Up to 16 images go out as ONE launch per kernel (a table of the images in device memory, blockIdx.z the image):
+    // config 5's twelve image levels were ~300 launches of 2 - 25 us, i.e. launch latency; as a batch they are ~30.
+    // (16 images of fewer than 2^28 pixels together: image index and rank share one 32-bit word in stage B's sorts.)  Larger
+    // batches go image by image, their chains round-robin over the handle's streams:
+    size_t batch_px = 0;
+    for (uint32_t i = 0; i < n_images; i++) batch_px += (size_t)ws[i] * hs[i];
+    const bool batched = n_images <= 16 && batch_px < ((size_t)1 << ORB_TAG_SHIFT);
+    uint32_t lanes = n_images > 1 && !batched ? LANES : 1;
     int measuring = 0; // 1 + the number of lanes this call is the sample for
-    if (n_images > 1) {
+    if (n_images > 1 && !batched) {
         if (ol.shape != shape) { // (the first batch of a shape also pays for streams, events and staging memory: not a sample)
             ol = Device::OrbLanes{};
             ol.shape = shape;
@@ -886,40 +1086,96 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
         std::vector<OrbJob> jobs(n_images);
 
         // ---- stage A: contrast stretch, FAST score, NMS count -> corner totals
-        uint32_t *h_counts = static_cast<uint32_t *>(pinned_scratch(dev->d, 4096));
-        if (!h_counts) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
-        CVHIP_TRY(fork());
-        for (uint32_t i = 0; i < n_images; i++) {
-            OrbJob &j = jobs[i];
-            hipStream_t s = lane_stream[i % lanes]; // (this image's chain)
-            j.img = imgs[i];
-            j.w = ws[i];
-            j.h = hs[i];
-            j.cap = cap;
-            j.out_xy = out_xy[i];
-            j.out_desc = out_desc[i];
-            j.out_n = &out_n[i];
-            j.n = (size_t)j.w * j.h;
-            j.nblocks = (uint32_t)((j.n + 255) / 256);
-            CVHIP_TRY_HIP(mem.alloc(&j.d_img, j.n + IMG_PAD));
-            CVHIP_TRY_HIP(mem.alloc(&j.d_adj, j.n + IMG_PAD));
-            CVHIP_TRY_HIP(mem.alloc(&j.d_score, j.n));
-            CVHIP_TRY_HIP(mem.alloc(&j.d_mm, 2));
-            CVHIP_TRY_HIP(mem.alloc(&j.d_counts, j.nblocks));
-            CVHIP_TRY_HIP(mem.alloc(&j.d_total, 1));
-            CVHIP_TRY_HIP(hipMemcpyAsync(j.d_img, j.img, j.n, dev_ptr(j.img) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-            CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(j.d_mm), 255, 1, s)); // {min, max} = {255, 0}
-            CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(j.d_mm + 1), 0, 1, s));
-            const unsigned rblocks = (unsigned)std::min<size_t>(2048, (j.n + 255) / 256);
-            hipLaunchKernelGGL(minmax_kernel, dim3(std::min(rblocks, 512u)), dim3(256), 0, s, j.d_img, j.n, j.d_mm);
-            hipLaunchKernelGGL(contrast_kernel, dim3(rblocks), dim3(256), 0, s, j.d_img, j.n, j.d_mm, j.d_adj);
-            dim3 grid2d((j.w + 63) / 64, (j.h + 3) / 4);
-            hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, j.d_adj, j.w, j.h, j.d_score);
-            hipLaunchKernelGGL(nms_count_kernel, dim3(j.nblocks), dim3(256), 0, s, j.d_score, j.w, j.h, j.d_counts);
-            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, j.d_counts, j.nblocks, j.d_total);
-            CVHIP_TRY_HIP(hipMemcpyAsync(h_counts + i, j.d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        char *pinned = static_cast<char *>(pinned_scratch(dev->d, 4096 + (size_t)n_images * sizeof(OrbJobDev)));
+        if (!pinned) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
+        uint32_t *h_counts = reinterpret_cast<uint32_t *>(pinned);
+        OrbJobDev *h_tbl = reinterpret_cast<OrbJobDev *>(pinned + 4096), *d_tbl = nullptr;
+        uint32_t *d_totals = nullptr;
+        if (batched) {
+            CVHIP_TRY_HIP(mem.alloc(&d_tbl, n_images));
+            CVHIP_TRY_HIP(mem.alloc(&d_totals, n_images));
+            uint32_t gx_contrast = 1, g2x = 1, g2y = 1, gx_nms = 1;
+            for (uint32_t i = 0; i < n_images; i++) {
+                OrbJob &j = jobs[i];
+                j.img = imgs[i];
+                j.w = ws[i];
+                j.h = hs[i];
+                j.cap = cap;
+                j.out_xy = out_xy[i];
+                j.out_desc = out_desc[i];
+                j.out_n = &out_n[i];
+                j.n = (size_t)j.w * j.h;
+                j.nblocks = (uint32_t)((j.n + 255) / 256);
+                CVHIP_TRY_HIP(mem.alloc(&j.d_img, j.n + IMG_PAD));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_adj, j.n + IMG_PAD));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_score, j.n));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_mm, 2));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_counts, j.nblocks));
+                j.d_total = d_totals + i;
+                CVHIP_TRY_HIP(hipMemcpyAsync(j.d_img, j.img, j.n, dev_ptr(j.img) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+                OrbJobDev &t = h_tbl[i];
+                std::memset(&t, 0, sizeof(t));
+                t.img = j.d_img;
+                t.adj = j.d_adj;
+                t.score = j.d_score;
+                t.mm = j.d_mm;
+                t.counts = j.d_counts;
+                t.total = j.d_total;
+                t.w = j.w;
+                t.h = j.h;
+                t.nblocks = j.nblocks;
+                t.rblocks = (uint32_t)std::min<size_t>(2048, (j.n + 255) / 256);
+                t.g2x = (j.w + 63) / 64;
+                t.g2y = (j.h + 3) / 4;
+                t.n = j.n;
+                gx_contrast = std::max(gx_contrast, t.rblocks);
+                g2x = std::max(g2x, t.g2x);
+                g2y = std::max(g2y, t.g2y);
+                gx_nms = std::max(gx_nms, t.nblocks);
+            }
+            CVHIP_TRY_HIP(hipMemcpyAsync(d_tbl, h_tbl, (size_t)n_images * sizeof(OrbJobDev), hipMemcpyHostToDevice, s));
+            const OrbJobDev *tbl = d_tbl;
+            hipLaunchKernelGGL(orb_stage_a_init_jobs, dim3(1), dim3(256), 0, s, tbl, n_images);
+            hipLaunchKernelGGL(minmax_jobs, dim3(std::min(gx_contrast, 512u), 1, n_images), dim3(256), 0, s, tbl);
+            hipLaunchKernelGGL(contrast_jobs, dim3(gx_contrast, 1, n_images), dim3(256), 0, s, tbl);
+            hipLaunchKernelGGL(fast_score_jobs, dim3(g2x, g2y, n_images), dim3(256), 0, s, tbl);
+            hipLaunchKernelGGL(nms_count_jobs, dim3(gx_nms, 1, n_images), dim3(256), 0, s, tbl);
+            hipLaunchKernelGGL(exclusive_scan_jobs, dim3(1, 1, n_images), dim3(1024), 0, s, tbl);
+            CVHIP_TRY_HIP(hipMemcpyAsync(h_counts, d_totals, (size_t)n_images * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        } else {
+            CVHIP_TRY(fork());
+            for (uint32_t i = 0; i < n_images; i++) {
+                OrbJob &j = jobs[i];
+                hipStream_t s = lane_stream[i % lanes]; // (this image's chain)
+                j.img = imgs[i];
+                j.w = ws[i];
+                j.h = hs[i];
+                j.cap = cap;
+                j.out_xy = out_xy[i];
+                j.out_desc = out_desc[i];
+                j.out_n = &out_n[i];
+                j.n = (size_t)j.w * j.h;
+                j.nblocks = (uint32_t)((j.n + 255) / 256);
+                CVHIP_TRY_HIP(mem.alloc(&j.d_img, j.n + IMG_PAD));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_adj, j.n + IMG_PAD));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_score, j.n));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_mm, 2));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_counts, j.nblocks));
+                CVHIP_TRY_HIP(mem.alloc(&j.d_total, 1));
+                CVHIP_TRY_HIP(hipMemcpyAsync(j.d_img, j.img, j.n, dev_ptr(j.img) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+                CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(j.d_mm), 255, 1, s)); // {min, max} = {255, 0}
+                CVHIP_TRY_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(j.d_mm + 1), 0, 1, s));
+                const unsigned rblocks = (unsigned)std::min<size_t>(2048, (j.n + 255) / 256);
+                hipLaunchKernelGGL(minmax_kernel, dim3(std::min(rblocks, 512u)), dim3(256), 0, s, j.d_img, j.n, j.d_mm);
+                hipLaunchKernelGGL(contrast_kernel, dim3(rblocks), dim3(256), 0, s, j.d_img, j.n, j.d_mm, j.d_adj);
+                dim3 grid2d((j.w + 63) / 64, (j.h + 3) / 4);
+                hipLaunchKernelGGL(fast_score_kernel, grid2d, dim3(256), 0, s, j.d_adj, j.w, j.h, j.d_score);
+                hipLaunchKernelGGL(nms_count_kernel, dim3(j.nblocks), dim3(256), 0, s, j.d_score, j.w, j.h, j.d_counts);
+                hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, j.d_counts, j.nblocks, j.d_total);
+                CVHIP_TRY_HIP(hipMemcpyAsync(h_counts + i, j.d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            }
+            CVHIP_TRY(join());
         }
-        CVHIP_TRY(join());
         report(0.20f);
         CVHIP_TRY_HIP(hipStreamSynchronize(s));
         CVHIP_TRY_HIP(hipGetLastError());
@@ -933,25 +1189,32 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
         gaussian_kernel_host(HARRIS_KERNEL_WIDTH, k7.k);
         Taps11 k11;
         gaussian_kernel_host(ORB_GAUSS_KERNEL_WIDTH, k11.k);
-        size_t stage_bytes = 0;
-        for (uint32_t i = 0; i < n_images; i++) {
+        size_t stage_bytes = 0, packs_bytes = 0;
+        std::vector<uint32_t> n_fast_of(n_images);
+        for (uint32_t i = 0; i < n_images; i++) n_fast_of[i] = h_counts[i]; // (before the staging block may move)
+        for (uint32_t i = 0; i < n_images; i++) { // the packs of all images first - one contiguous block on both sides
             OrbJob &j = jobs[i];
-            j.n_fast = h_counts[i];
+            j.n_fast = n_fast_of[i];
             j.count = std::min(j.n_fast, MAX_KEYPOINTS); // entries past the Some(...) ones carry idx = ~0
             j.out_cap = std::min(j.cap, j.count);
-            // page-locked staging of this image: [moments + keypoint, 5 u64 per rank] [sin, cos, valid: 3 f64 per rank]
-            // (both only for the host-orientation path) [n_out, open count + outputs]
+            j.pack_bytes = (256 + (size_t)j.out_cap * 10 * sizeof(uint32_t) + 255) / 256 * 256; // [n_out, open count + outputs]
+            j.pack_off = packs_bytes;
+            packs_bytes += j.pack_bytes;
+        }
+        stage_bytes = packs_bytes;
+        for (uint32_t i = 0; i < n_images; i++) {
+            OrbJob &j = jobs[i];
+            // page-locked staging of the host-orientation path: [moments + keypoint, 5 u64 per rank] [sin, cos, valid: 3 f64 per rank]
             j.mom_bytes = (size_t)j.count * 5 * sizeof(unsigned long long);
             j.sc_bytes = (size_t)j.count * 3 * sizeof(double);
-            j.pack_bytes = 256 + (size_t)j.out_cap * 10 * sizeof(uint32_t);
             j.mom_off = stage_bytes;
             j.sc_off = j.mom_off + j.mom_bytes;
-            j.pack_off = j.sc_off + j.sc_bytes;
-            stage_bytes = (j.pack_off + j.pack_bytes + 255) / 256 * 256;
+            stage_bytes = (j.sc_off + j.sc_bytes + 255) / 256 * 256;
         }
-        // (pinned_scratch may move the block: h_counts is not used past this point)
-        char *stage = static_cast<char *>(pinned_scratch(dev->d, stage_bytes + 256));
+        // (pinned_scratch may move the block: h_counts / h_tbl of stage A are not used past this point)
+        char *stage = static_cast<char *>(pinned_scratch(dev->d, stage_bytes + 512 + (size_t)n_images * sizeof(OrbJobDev)));
         if (!stage) return fail(CVHIP_ERR_NOMEM, "cvhip_orb_extract: out of page-locked host memory");
+        h_tbl = reinterpret_cast<OrbJobDev *>(stage + ((stage_bytes + 256 + 15) & ~(size_t)15));
         if (!dev->d.orb_pattern) {
             CVHIP_TRY_HIP(hipMalloc(&dev->d.orb_pattern, 1024));
             CVHIP_TRY_HIP(hipMemcpyAsync(dev->d.orb_pattern, CVHIP_ORB_PATTERN, 1024, hipMemcpyHostToDevice, s));
@@ -970,6 +1233,111 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             CVHIP_TRY_HIP(hipMemcpyAsync(stage + j.pack_off, j.d_pack, back, hipMemcpyDeviceToHost, s));
             return CVHIP_OK;
         };
+        if (batched) {
+            // every image's buffers; the corner keys of all images in one array (image i at key_off), their packs in one block
+            uint32_t total_keys = 0, gx_nms = 1, gx_harris = 1, g2x = 1, g2y = 1, gx_count = 1;
+            uint32_t *d_packs = nullptr;
+            CVHIP_TRY_HIP(mem.alloc(&d_packs, packs_bytes / sizeof(uint32_t) + 64));
+            std::vector<uint32_t> key_off(n_images);
+            for (uint32_t i = 0; i < n_images; i++) {
+                key_off[i] = total_keys;
+                total_keys += jobs[i].n_fast;
+            }
+            unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
+            uint32_t *d_idx = nullptr, *d_idx_s1 = nullptr, *d_idx_s2 = nullptr, *d_idx_plain = nullptr, *d_rank = nullptr;
+            CVHIP_TRY_HIP(mem.alloc(&d_keys, std::max(total_keys, 1u)));
+            CVHIP_TRY_HIP(mem.alloc(&d_keys_sorted, std::max(total_keys, 1u)));
+            CVHIP_TRY_HIP(mem.alloc(&d_idx, std::max(total_keys, 1u)));
+            CVHIP_TRY_HIP(mem.alloc(&d_idx_s1, std::max(total_keys, 1u)));
+            CVHIP_TRY_HIP(mem.alloc(&d_idx_s2, std::max(total_keys, 1u)));
+            CVHIP_TRY_HIP(mem.alloc(&d_idx_plain, std::max(total_keys, 1u)));
+            CVHIP_TRY_HIP(mem.alloc(&d_rank, std::max(total_keys, 1u)));
+            for (uint32_t i = 0; i < n_images; i++) {
+                OrbJob &j = jobs[i];
+                OrbJobDev &t = h_tbl[i];
+                std::memset(&t, 0, sizeof(t));
+                j.d_pack = d_packs + j.pack_off / sizeof(uint32_t);
+                j.xy_dev = dev_ptr(j.out_xy);
+                j.desc_dev = dev_ptr(j.out_desc);
+                j.d_idx_sorted = d_idx_plain + key_off[i];
+                double *d_blur_h = nullptr;
+                if (j.n_fast) {
+                    CVHIP_TRY_HIP(mem.alloc(&j.d_kp, (size_t)j.n_fast * 2));
+                    CVHIP_TRY_HIP(mem.alloc(&d_blur_h, j.n));
+                    CVHIP_TRY_HIP(mem.alloc(&j.d_blur, j.n));
+                    CVHIP_TRY_HIP(mem.alloc(&j.d_mom, (size_t)j.count * 5));
+                    CVHIP_TRY_HIP(mem.alloc(&j.d_sc, (size_t)j.count * 3));
+                    CVHIP_TRY_HIP(mem.alloc(&j.d_desc, (size_t)j.count * 8));
+                    CVHIP_TRY_HIP(mem.alloc(&j.d_flags, j.count));
+                }
+                t.img = j.d_img;
+                t.score = j.d_score;
+                t.counts = j.d_counts;
+                t.total = j.d_total;
+                t.w = j.w;
+                t.h = j.h;
+                t.nblocks = j.nblocks;
+                t.g2x = (j.w + 63) / 64;
+                t.g2y = (j.h + 3) / 4;
+                t.n = j.n;
+                t.n_fast = j.n_fast;
+                t.count = j.count;
+                t.out_cap = j.out_cap;
+                t.key_off = key_off[i];
+                t.kp = j.d_kp;
+                t.idx_sorted = j.d_idx_sorted;
+                t.desc = j.d_desc;
+                t.flags = j.d_flags;
+                t.pack = j.d_pack;
+                t.out_xy = j.xy_dev ? j.out_xy : j.d_pack + 64;
+                t.out_desc = j.desc_dev ? j.out_desc : j.d_pack + 64 + (size_t)j.out_cap * 2;
+                t.keys = d_keys + key_off[i];
+                t.idx = d_idx + key_off[i];
+                t.mom = j.d_mom;
+                t.blur_h = d_blur_h;
+                t.blur = j.d_blur;
+                t.sc = j.d_sc;
+                if (j.n_fast) {
+                    gx_nms = std::max(gx_nms, j.nblocks);
+                    gx_harris = std::max(gx_harris, (j.n_fast + 63) / 64);
+                    g2x = std::max(g2x, t.g2x);
+                    g2y = std::max(g2y, t.g2y);
+                    gx_count = std::max(gx_count, j.count);
+                }
+            }
+            CVHIP_TRY_HIP(hipMemcpyAsync(d_tbl, h_tbl, (size_t)n_images * sizeof(OrbJobDev), hipMemcpyHostToDevice, s));
+            const OrbJobDev *tbl = d_tbl;
+            if (total_keys) {
+                hipLaunchKernelGGL(nms_write_jobs, dim3(gx_nms, 1, n_images), dim3(256), 0, s, tbl);
+                hipLaunchKernelGGL(harris_jobs, dim3(gx_harris, 1, n_images), dim3(64), 0, s, tbl, k7);
+                // All images' corners in two sorts: descending by the Harris key (stable: equal keys keep their scan order),
+                // then the ranks of that order by (image, rank) - which leaves every image's corners together, in descending
+                // key order: what the per-image sort produced.
+                size_t tmp1 = 0, tmp2 = 0;
+                CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp1, d_keys, d_keys_sorted, d_idx, d_idx_s1, (size_t)total_keys, 0u, 64u, s));
+                CVHIP_TRY_HIP(rocprim::radix_sort_keys(nullptr, tmp2, d_rank, d_idx_s2, (size_t)total_keys, 0u, 32u, s));
+                uint8_t *d_tmp = nullptr, *d_tmp2 = nullptr;
+                CVHIP_TRY_HIP(mem.alloc(&d_tmp, tmp1));
+                CVHIP_TRY_HIP(mem.alloc(&d_tmp2, tmp2));
+                const dim3 gk((total_keys + 255) / 256);
+                CVHIP_TRY_HIP(rocprim::radix_sort_pairs_desc(d_tmp, tmp1, d_keys, d_keys_sorted, d_idx, d_idx_s1, (size_t)total_keys, 0u, 64u, s));
+                hipLaunchKernelGGL(orb_rank_key_kernel, gk, dim3(256), 0, s, (const uint32_t *)d_idx_s1, total_keys, d_rank);
+                CVHIP_TRY_HIP(rocprim::radix_sort_keys(d_tmp2, tmp2, d_rank, d_idx_s2, (size_t)total_keys, 0u, 32u, s));
+                hipLaunchKernelGGL(orb_untag_kernel, gk, dim3(256), 0, s, (const uint32_t *)d_idx_s1, (const uint32_t *)d_idx_s2, total_keys, d_idx_plain);
+                hipLaunchKernelGGL(blur_h_jobs, dim3(g2x, g2y, n_images), dim3(256), 0, s, tbl, k11);
+                hipLaunchKernelGGL(blur_v_jobs, dim3(g2x, g2y, n_images), dim3(256), 0, s, tbl, k11);
+                hipLaunchKernelGGL(moments_jobs, dim3(gx_count, 1, n_images), dim3(64), 0, s, tbl);
+                report(0.35f);
+                if (guard > 0.0) {
+                    hipLaunchKernelGGL(brief_jobs, dim3(gx_count, 1, n_images), dim3(64), 0, s, tbl, (const signed char *)dev->d.orb_pattern, guard);
+                    hipLaunchKernelGGL(final_compact_jobs, dim3(1, 1, n_images), dim3(1024), 0, s, tbl);
+                    CVHIP_TRY_HIP(hipMemcpyAsync(stage, d_packs, packs_bytes, hipMemcpyDeviceToHost, s)); // every image's results
+                } else { // device orientations switched off (cvhip_orb_set_orientation_guard(dev, 0)): the host path for all
+                    for (OrbJob &j : jobs)
+                        if (j.n_fast) CVHIP_TRY_HIP(hipMemcpyAsync(stage + j.mom_off, j.d_mom, j.mom_bytes, hipMemcpyDeviceToHost, s));
+                }
+            }
+        } else {
         CVHIP_TRY(fork()); // (behind the pattern upload)
         for (uint32_t i = 0; i < n_images; i++) {
             OrbJob &j = jobs[i];
@@ -1015,6 +1383,7 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             }
         }
         CVHIP_TRY(join());
+        }
         report(0.70f);
         CVHIP_TRY_HIP(hipStreamSynchronize(s));
         CVHIP_TRY_HIP(hipGetLastError());
