@@ -58,8 +58,8 @@ def extract_points_batch(device, images, cap: int = MAX_KEYPOINTS, progress=None
             a = np.ascontiguousarray(img, dtype=np.uint8)
             ptrs[i], ws[i], hs[i] = a.ctypes.data, a.shape[1], a.shape[0]
             keep.append(a)
-    xys = [np.zeros((cap, 2), dtype=np.uint32) for _ in range(n)]
-    descs = [np.zeros((cap, 8), dtype=np.uint32) for _ in range(n)]
+    xys = [np.empty((cap, 2), dtype=np.uint32) for _ in range(n)]
+    descs = [np.empty((cap, 8), dtype=np.uint32) for _ in range(n)]
     pxy = (C.c_void_p * n)(*[a.ctypes.data for a in xys])
     pdesc = (C.c_void_p * n)(*[a.ctypes.data for a in descs])
     counts = (C.c_uint32 * n)()

@@ -608,6 +608,18 @@ def test_orb_batch_equals_single_extractions(gpu_device, oracle):
     assert len(c[1][0]) > 100
 
 
+def test_orb_batch_of_more_than_16_images(gpu_device):
+    """Up to 16 images go out as one launch per kernel, larger batches image by image over the handle's streams: both
+    forms give what single extractions give (several calls, so that the handle's choice of 3 / 2 / 1 chains is exercised)."""
+    sizes = [(200 + 13 * i, 150 + 7 * (i % 5)) for i in range(18)]
+    imgs = [orb_image(w, h, seed=40 + i, blocks=60) for i, (w, h) in enumerate(sizes)]
+    single = [orb.extract_points(gpu_device, im) for im in imgs]
+    assert sum(len(xy) for xy, _ in single) > 2000
+    for n in (16, 18, 18, 18, 18, 17):
+        for (xy_a, d_a), (xy_b, d_b) in zip(single[:n], orb.extract_points_batch(gpu_device, imgs[:n])):
+            assert xy_a.shape == xy_b.shape and (xy_a == xy_b).all() and (d_a == d_b).all()
+
+
 def test_orb_orientation_guard_settings_agree(gpu_device, oracle):
     """The orientation step: device atan2 / sin / cos where every rounded sample offset is provably the libm one, the
     host's libm otherwise (cvhip_orb_set_orientation_guard).  Default guard, a guard so wide that most images take the
