@@ -1678,12 +1678,17 @@ void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipS
 {
     uint32_t lds = 0;
     bool any = false;
+    size_t entries = 0; // the most entries one of the lists can hold (search3_worklist_capacity, for this pass's rows)
     for (int i = 0; i < n; i++) {
-        any = any || job_active(jobs[i]);
+        if (!job_active(jobs[i])) continue;
+        any = true;
         lds = std::max(lds, search2_lds_bytes(jobs[i].p));
+        entries = std::max(entries, search3_worklist_capacity(jobs[i].p.w1, jobs[i].p.row1 - jobs[i].p.row0));
     }
     if (!any) return;
-    const dim3 grid(LIST_GRID, 1, (unsigned)n);
+    // (the small levels' lists cannot hold as many tiles as the persistent grid has workgroups: 64^2 .. 256^2 then pay
+    // for the dispatch of 2 x 34 .. 325 workgroups instead of 2 x 768)
+    const dim3 grid((unsigned)std::min<size_t>(LIST_GRID, entries), 1, (unsigned)n);
     if (jobs[0].counters)
         hipLaunchKernelGGL(search3_fallback_kernel<true>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
     else
