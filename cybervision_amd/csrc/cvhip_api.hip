@@ -371,7 +371,8 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
 
 // n = 1, or the two passes of one level (independent: each reads its own direction's previous grid and writes its own
 // buffers); passes that need the same kernels go out in the same launches (blockIdx.z), anything else one by one.
-static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts, hipStream_t s)
+// stats_done (optional): an event the search kernels have to wait for, but not the search range (statistics ahead)
+static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts, hipStream_t s, hipEvent_t stats_done = nullptr)
 {
     const bool together = n == 2 && plans[0].kind == plans[1].kind && plans[0].kind != PassPlan::EXACT_V1 &&
                           plans[0].stepped == plans[1].stepped && plans[0].transposed == plans[1].transposed &&
@@ -383,6 +384,7 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
         const CorrParams &p = pl.job.p;
         if (!p.first_pass)
             CVHIP_TRY(timed(c, cvhip_ctx::K_RANGE, [&] { launch_search_range(jobs, m, c->range_mode, s); }, s));
+        if (stats_done && i == 0) CVHIP_TRY_HIP(hipStreamWaitEvent(s, stats_done, 0));
         if (pl.kind == PassPlan::EXACT_V1) {
             CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                 launch_search(p, pl.job.img1, pl.job.img2, pl.job.stats1, pl.job.stats2, pl.job.range, pl.job.out,
@@ -791,6 +793,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s));
     bool stats_ahead = false;
+    hipEvent_t stats_done = nullptr;
     {
         uint32_t sr0 = 0, sr1 = std::max(h1, h2);
         if (ctx->band_mode) {
@@ -847,7 +850,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
             launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev, nullptr, side,
                                      48u * 1024u);
             CVHIP_TRY_HIP(hipEventRecord(d.sa.done[k], side));
-            CVHIP_TRY_HIP(hipStreamWaitEvent(s, d.sa.done[k], 0));
+            stats_done = d.sa.done[k]; // (the search range does not read the statistics: the wait goes behind its launch)
         } else {
             ctx->stats_ahead_fenced = false;
             // both images in one launch, which also clears the work-list counts of the level's two search passes
@@ -886,7 +889,8 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     PassPlan plans[2];
     int rc = plan_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, plans[0]);                 // mod.rs:224-230
     if (rc == CVHIP_OK) rc = plan_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, plans[1]); // mod.rs:231-237
-    if (rc == CVHIP_OK) rc = launch_passes(ctx, plans, 2, false, s);
+    if (rc == CVHIP_OK) rc = launch_passes(ctx, plans, 2, false, s, stats_done);
+    else if (stats_done) (void)hipStreamWaitEvent(s, stats_done, 0); // (the side stream's work stays ordered before whatever follows)
     if (rc == CVHIP_OK) {
         commit_pass(ctx, plans[0]);
         commit_pass(ctx, plans[1]);
