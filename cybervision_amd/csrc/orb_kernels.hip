@@ -1308,6 +1308,17 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             CVHIP_TRY_HIP(hipMemcpyAsync(d_tbl, h_tbl, (size_t)n_images * sizeof(OrbJobDev), hipMemcpyHostToDevice, s));
             const OrbJobDev *tbl = d_tbl;
             if (total_keys) {
+                // The blur depends on the images only: on a side stream it runs under the corner chain, whose two sorts are
+                // ~40 launches of 5 us each.  (Streams that share a hardware queue run it in line, as before.)
+                hipStream_t side = nullptr;
+                CVHIP_TRY_HIP(aux_stream(dev->d, 0, &side));
+                for (int l = 0; l < 2; l++)
+                    if (!dev->d.orb_ev[l]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&dev->d.orb_ev[l], hipEventDisableTiming));
+                CVHIP_TRY_HIP(hipEventRecord(dev->d.orb_ev[0], s));
+                CVHIP_TRY_HIP(hipStreamWaitEvent(side, dev->d.orb_ev[0], 0));
+                hipLaunchKernelGGL(blur_h_jobs, dim3(g2x, g2y, n_images), dim3(256), 0, side, tbl, k11);
+                hipLaunchKernelGGL(blur_v_jobs, dim3(g2x, g2y, n_images), dim3(256), 0, side, tbl, k11);
+                CVHIP_TRY_HIP(hipEventRecord(dev->d.orb_ev[1], side));
                 hipLaunchKernelGGL(nms_write_jobs, dim3(gx_nms, 1, n_images), dim3(256), 0, s, tbl);
                 hipLaunchKernelGGL(harris_jobs, dim3(gx_harris, 1, n_images), dim3(64), 0, s, tbl, k7);
                 // All images' corners in two sorts: descending by the Harris key (stable: equal keys keep their scan order),
@@ -1324,8 +1335,7 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
                 hipLaunchKernelGGL(orb_rank_key_kernel, gk, dim3(256), 0, s, (const uint32_t *)d_idx_s1, total_keys, d_rank);
                 CVHIP_TRY_HIP(rocprim::radix_sort_keys(d_tmp2, tmp2, d_rank, d_idx_s2, (size_t)total_keys, 0u, 32u, s));
                 hipLaunchKernelGGL(orb_untag_kernel, gk, dim3(256), 0, s, (const uint32_t *)d_idx_s1, (const uint32_t *)d_idx_s2, total_keys, d_idx_plain);
-                hipLaunchKernelGGL(blur_h_jobs, dim3(g2x, g2y, n_images), dim3(256), 0, s, tbl, k11);
-                hipLaunchKernelGGL(blur_v_jobs, dim3(g2x, g2y, n_images), dim3(256), 0, s, tbl, k11);
+                CVHIP_TRY_HIP(hipStreamWaitEvent(s, dev->d.orb_ev[1], 0));
                 hipLaunchKernelGGL(moments_jobs, dim3(gx_count, 1, n_images), dim3(64), 0, s, tbl);
                 report(0.35f);
                 if (guard > 0.0) {

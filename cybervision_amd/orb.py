@@ -58,8 +58,12 @@ def extract_points_batch(device, images, cap: int = MAX_KEYPOINTS, progress=None
             a = np.ascontiguousarray(img, dtype=np.uint8)
             ptrs[i], ws[i], hs[i] = a.ctypes.data, a.shape[1], a.shape[0]
             keep.append(a)
-    xys = [np.empty((cap, 2), dtype=np.uint32) for _ in range(n)]
-    descs = [np.empty((cap, 8), dtype=np.uint32) for _ in range(n)]
+    # (output buffers are kept on the device object: fresh pages would be faulted in one by one under the library's copies)
+    cache = device.__dict__.setdefault("_orb_out", {})
+    if (n, cap) not in cache:
+        cache.clear()
+        cache[(n, cap)] = ([np.empty((cap, 2), dtype=np.uint32) for _ in range(n)], [np.empty((cap, 8), dtype=np.uint32) for _ in range(n)])
+    xys, descs = cache[(n, cap)]
     pxy = (C.c_void_p * n)(*[a.ctypes.data for a in xys])
     pdesc = (C.c_void_p * n)(*[a.ctypes.data for a in descs])
     counts = (C.c_uint32 * n)()
