@@ -1767,54 +1767,59 @@ __global__ __launch_bounds__(256) void cross_check_kernel(CrossJob ja, CrossJob 
     const uint32_t ow = job.ow, oh = job.oh, rw = job.rw, rh = job.rh, row0 = job.row0;
     // oh = end of the row range handled by this launch, row0 its start
     const TileId tid = xcd_tile();
-    const uint32_t x = tid.x * 64 + (threadIdx.x & 63);
-    const uint32_t y0 = row0 + (tid.y * 4 + (threadIdx.x >> 6)) * CC_ROWS;
-    if (x >= ow) return;
+    static_assert(CC_ROWS == 1, "one cell per thread");
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t x = tid.x * 64 + lane;
+    const uint32_t y = row0 + tid.y * 4 + (threadIdx.x >> 6); // (uniform in the wave)
     const uint32_t sa = CROSS_CHECK_SEARCH_AREA;
-    uint32_t cell[CC_ROWS], probe[CC_ROWS];
-#pragma unroll
-    for (int j = 0; j < CC_ROWS; j++) cell[j] = y0 + j < oh ? own[(size_t)(y0 + j) * ow + x] : CELL_NONE;
+    const bool in = x < ow && y < oh;
+    const uint32_t cell = in ? own[(size_t)y * ow + x] : CELL_NONE;
     // The result is an existence test (mod.rs:613-623 returns true at the first hit), so the scan
     // order is free: probe the window centre first — a consistent pair of matches points straight
-    // back — and fall back to the full row-major scan only when that fails.
+    // back — and fall back to the full scan only when that fails.
+    const uint32_t pmx = cell & 0xFFFFu, pmy = cell >> 16;
+    const uint32_t probe = (cell != CELL_NONE && pmx < rw && pmy < rh) ? other[(size_t)pmy * rw + pmx] : CELL_NONE;
+    // does reverse match rm lie within +-sa of own cell (cx, cy)?
+    auto points_back = [&](uint32_t rm, uint32_t cx, uint32_t cy) {
+        const uint32_t rx = rm & 0xFFFFu, ry = rm >> 16;
+        return rm != CELL_NONE && rx >= sat_sub_u32(cx, sa) && rx < cx + sa + 1 && ry >= sat_sub_u32(cy, sa) && ry < cy + sa + 1;
+    };
+    bool found = cell != CELL_NONE && points_back(probe, x, y);
+    // The cells whose probe failed: their (2 sa + 1)^2 windows of the other grid are scanned by the WHOLE wave, one cell
+    // of the window per lane (81 cells: two loads per lane), instead of by the failing lane alone while the others wait -
+    // a wave with a single failing lane used to issue 81 load instructions for it, and nearly every wave has one; the
+    // kernel's time was those instructions (it sat at the texture addresser's rate, VALU busy 0.18).  Two failing cells
+    // per round, so that four loads are in flight.
+    constexpr uint32_t CCW = 2 * CROSS_CHECK_SEARCH_AREA + 1, CCN = CCW * CCW;
+    static_assert(CCN > 64 && CCN <= 128, "two window cells per lane");
+    const uint32_t wy0 = lane / CCW, wx0 = lane - wy0 * CCW, t1 = lane + 64u, wy1 = t1 / CCW, wx1 = t1 - wy1 * CCW;
+    unsigned long long todo = __ballot(cell != CELL_NONE && !found);
+    while (todo) {
+        const int s0 = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const bool two = todo != 0ull;
+        const int s1 = two ? (int)__builtin_ctzll(todo) : s0;
+        if (two) todo &= todo - 1ull;
+        uint32_t rm[2][2], cxs[2];
 #pragma unroll
-    for (int j = 0; j < CC_ROWS; j++) {
-        const uint32_t mx = cell[j] & 0xFFFFu, my = cell[j] >> 16;
-        probe[j] = (cell[j] != CELL_NONE && mx < rw && my < rh) ? other[(size_t)my * rw + mx] : CELL_NONE;
-    }
-#pragma unroll
-    for (int j = 0; j < CC_ROWS; j++) {
-        if (cell[j] == CELL_NONE) continue;
-        const uint32_t y = y0 + j;
-        const uint32_t mx = cell[j] & 0xFFFFu, my = cell[j] >> 16;
-        const uint32_t min_x = min(sat_sub_u32(mx, sa), rw), max_x = min(mx + sa + 1, rw);
-        const uint32_t min_y = min(sat_sub_u32(my, sa), rh), max_y = min(my + sa + 1, rh);
-        const uint32_t r_min_x = sat_sub_u32(x, sa), r_max_x = x + sa + 1;
-        const uint32_t r_min_y = sat_sub_u32(y, sa), r_max_y = y + sa + 1;
-        auto points_back = [&](uint32_t rm) {
-            const uint32_t rx = rm & 0xFFFFu, ry = rm >> 16;
-            return rm != CELL_NONE && rx >= r_min_x && rx < r_max_x && ry >= r_min_y && ry < r_max_y;
-        };
-        bool found = points_back(probe[j]);
-        // fallback: three window rows at a time, 27 independent loads in flight (no per-cell early exit).  The
-        // kernel is a chain of dependent round trips - cell, probe, then these batches - so its time on small
-        // levels is (batches per cell) x (memory latency), not bytes.
-        constexpr uint32_t CCW = 2 * CROSS_CHECK_SEARCH_AREA + 1, CCB = 3;
-        for (uint32_t sy = min_y; sy < max_y && !found; sy += CCB) {
-            uint32_t cellsr[CCB][CCW];
-#pragma unroll
-            for (uint32_t b = 0; b < CCB; b++) {
-                const uint32_t *row = other + (size_t)min(sy + b, max_y - 1u) * rw;
-#pragma unroll
-                for (uint32_t t = 0; t < CCW; t++) cellsr[b][t] = (sy + b < max_y && min_x + t < max_x) ? row[min_x + t] : CELL_NONE;
-            }
-#pragma unroll
-            for (uint32_t b = 0; b < CCB; b++)
-#pragma unroll
-                for (uint32_t t = 0; t < CCW; t++) found = found || points_back(cellsr[b][t]);
+        for (int q = 0; q < 2; q++) {
+            const int src = q ? s1 : s0;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cell, src);
+            const uint32_t mx = c & 0xFFFFu, my = c >> 16;
+            const uint32_t min_x = min(sat_sub_u32(mx, sa), rw), max_x = min(mx + sa + 1, rw);
+            const uint32_t min_y = min(sat_sub_u32(my, sa), rh), max_y = min(my + sa + 1, rh);
+            cxs[q] = tid.x * 64 + (uint32_t)src;
+            const uint32_t ax = min_x + wx0, ay = min_y + wy0, bx = min_x + wx1, by = min_y + wy1;
+            rm[q][0] = (ax < max_x && ay < max_y) ? other[(size_t)ay * rw + ax] : CELL_NONE;
+            rm[q][1] = (t1 < CCN && bx < max_x && by < max_y) ? other[(size_t)by * rw + bx] : CELL_NONE;
         }
-        if (!found) own[(size_t)y * ow + x] = CELL_NONE; // (the score of a None cell is never looked at)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const bool any = __ballot(points_back(rm[q][0], cxs[q], y) || points_back(rm[q][1], cxs[q], y)) != 0ull;
+            if ((int)lane == (q ? s1 : s0)) found = any;
+        }
     }
+    if (cell != CELL_NONE && !found) own[(size_t)y * ow + x] = CELL_NONE; // (the score of a None cell is never looked at)
 }
 
 void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
