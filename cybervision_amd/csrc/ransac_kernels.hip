@@ -1609,17 +1609,20 @@ struct PerspPencil {
 };
 
 __global__ __launch_bounds__(64) void ransac_perspective_pencil_kernel(const uint4 *__restrict__ matches, uint32_t limit,
-                                                                        unsigned long long seed, uint32_t round, uint32_t H,
-                                                                        const uint32_t *__restrict__ sample_idx,
+                                                                        unsigned long long seed, uint32_t round0, uint32_t per_round,
+                                                                        uint32_t H, const uint32_t *__restrict__ sample_idx,
                                                                         PerspPencil *__restrict__ pencils)
 {
-    const uint32_t h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= H) return;
+    // H = per_round x (the rounds of this launch): sample g belongs to round round0 + g / per_round, and its random
+    // numbers depend on the round and on its index within the round only
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= H) return;
+    const uint32_t round = round0 + g / per_round, h = g - (g / per_round) * per_round;
     uint4 sm[7];
     int have = 0;
     if (sample_idx) {
 #pragma unroll
-        for (int i = 0; i < 7; i++) sm[i] = matches[sample_idx[(size_t)h * 7 + i]];
+        for (int i = 0; i < 7; i++) sm[i] = matches[sample_idx[(size_t)g * 7 + i]];
         have = 7;
     } else {
         unsigned long long state = mix64(seed ^ mix64(((unsigned long long)round << 32) | h));
@@ -1642,7 +1645,7 @@ __global__ __launch_bounds__(64) void ransac_perspective_pencil_kernel(const uin
             }
         }
     }
-    PerspPencil &out = pencils[h];
+    PerspPencil &out = pencils[g];
     double n1[9], n2[9], roots[3] = {0.0, 0.0, 0.0};
     int nr = 0;
     if (have == 7) nr = perspective_pencil(sm, n1, n2, roots);
@@ -1845,13 +1848,14 @@ __global__ __launch_bounds__(64) void ransac_perspective_lm_kernel(const PerspPe
 }
 
 // queue: 1 + 3 H words
-static void launch_generate_perspective(const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round,
-                                        uint32_t H, const uint32_t *sample_idx, PerspPencil *pencils, uint32_t *queue, double *d_F,
-                                        hipStream_t s)
+// H samples: `per_round` each of the rounds round0, round0 + 1, ... (H a multiple of per_round)
+static void launch_generate_perspective(const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round0,
+                                        uint32_t per_round, uint32_t H, const uint32_t *sample_idx, PerspPencil *pencils,
+                                        uint32_t *queue, double *d_F, hipStream_t s)
 {
     (void)hipMemsetAsync(queue, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(ransac_perspective_pencil_kernel, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round, H, sample_idx,
-                       pencils);
+    hipLaunchKernelGGL(ransac_perspective_pencil_kernel, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round0, per_round, H,
+                       sample_idx, pencils);
     hipLaunchKernelGGL(ransac_perspective_root_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, H, t,
                        d_F, queue);
     // a persistent grid of waves strides over the queue (one wave per queued root)
@@ -2267,7 +2271,10 @@ namespace {
 // and the refitted matrix' on return, d_F_out [9] the refitted matrix (the winner itself where the refit declines)
 hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double t, uint8_t *d_mask, const double *d_F_in,
                              double *d_F_out, hipStream_t s);
-constexpr uint32_t GEN_DEPTH = 3; // hypothesis buffers: the round being scored + the two being generated
+// Hypotheses are generated GEN_BATCH rounds at a time (the generator kernels are bound by the latency of their serial f64
+// work on too few threads for the chip - 50 000 samples are 782 waves - so two rounds in one launch take what one
+// takes), into one of GEN_DEPTH buffers: the batch being scored and the two that may be generated ahead of it.
+constexpr uint32_t GEN_BATCH = 2, GEN_DEPTH = 3;
 template <typename Generate>
 int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
                   double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
@@ -2280,7 +2287,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     RansacBest *d_best = nullptr;
     uint8_t *d_mask = nullptr;
     hipError_t e = mem.alloc(&d_m, (size_t)N * 4);
-    if (e == hipSuccess) e = mem.alloc(&d_F, GEN_DEPTH * (size_t)H * 9); // the hypotheses of the rounds in flight
+    if (e == hipSuccess) e = mem.alloc(&d_F, GEN_DEPTH * GEN_BATCH * (size_t)H * 9); // the hypotheses of the rounds in flight
     if (e == hipSuccess) e = mem.alloc(&d_cnt, (size_t)H);
     if (e == hipSuccess) e = mem.alloc(&d_err, (size_t)H);
     if (e == hipSuccess) e = mem.alloc(&d_best, 1);
@@ -2289,8 +2296,8 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // [2 + TIED_CAP] and the largest coordinate [1]
     const size_t live_words = (size_t)H + 1 + (H + 1023) / 1024;
     uint32_t *d_live = nullptr;
-    if (e == hipSuccess) e = mem.alloc(&d_live, GEN_DEPTH * live_words + 3 + TIED_CAP);
-    uint32_t *const d_tied = d_live + GEN_DEPTH * live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
+    if (e == hipSuccess) e = mem.alloc(&d_live, GEN_DEPTH * GEN_BATCH * live_words + 3 + TIED_CAP);
+    uint32_t *const d_tied = d_live + GEN_DEPTH * GEN_BATCH * live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
     float4 *d_mf = nullptr; // the counting kernel's copy of the list (f32 planes + u32), reordered as the best hypothesis changes
     uint32_t *d_mo = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_mf, ransac_padded(N));
@@ -2308,19 +2315,20 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
-    // Two streams, GEN_DEPTH hypothesis buffers: rounds r + 1 and r + 2 are GENERATED (stream g; samples depend on the
-    // seed and the round number only) while round r is SCORED (the handle's stream; the best-so-far chain lives
-    // there).  The generator's tail - a few long Levenberg-Marquardt loops on ~190 waves that need a whole SIMD's
-    // registers each - cannot get onto the chip while the counting kernel fills it; generated two rounds ahead, it is
-    // already queued when a counting kernel drains, starts in the gap that follows (ordered sums, best pick, the host's
-    // early-exit read) and finishes under the next counting kernel.  An early exit discards at most two generated rounds.
+    // Two streams, GEN_DEPTH hypothesis buffers of GEN_BATCH rounds: the batches after the one being SCORED (the handle's
+    // stream; the best-so-far chain lives there) are GENERATED on the side streams (samples depend on the seed and the
+    // round number only), one batch per stream at a time.  The generator's tail - a few long Levenberg-Marquardt loops
+    // on a few hundred waves that need a whole SIMD's registers each - cannot get onto the chip while the counting kernel
+    // fills it; generated ahead, it is already queued when a counting kernel drains, starts in the gap that follows
+    // (ordered sums, best pick, the host's early-exit read) and finishes under the next counting kernels.  With single
+    // rounds generated two ahead the scoring chain waited for its generators in most rounds (a round's generation took
+    // ~330 us, more with a long LM tail, against ~190 us of scoring: 7.3 ms per pair for 3.8 ms of scoring).  An early
+    // exit discards at most two generated batches.
     // The early exit (:135-141) needs more than `early_exit` inliers: with fewer matches than that it can never fire, and
     // the rounds are enqueued back to back with ONE host synchronisation at the end instead of a 4-byte read per round.
     const bool may_exit_early = N > early_exit;
-    // (one generator stream per round in flight: the LM tails of consecutive rounds - a couple of hundred waves each,
-    // bound by their longest loop - then run side by side instead of queueing behind each other)
-    constexpr uint32_t GEN_STREAMS = GEN_DEPTH - 1;
-    static_assert(GEN_STREAMS == 2 && GEN_DEPTH == 3, "Device holds two side streams, Device::RansacQueues three events of each kind");
+    constexpr uint32_t GEN_STREAMS = 2;
+    static_assert(GEN_DEPTH <= sizeof(Device::RansacQueues::ready) / sizeof(hipEvent_t), "Device holds two side streams and RansacQueues' events");
     Device::RansacQueues &rq = dev->d.rq; // (kept on the handle: created once)
     hipStream_t g[GEN_STREAMS] = {};
     for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = aux_stream(dev->d, (int)k, &g[k]);
@@ -2333,24 +2341,30 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     const hipEvent_t uploaded = rq.uploaded;
     if (e == hipSuccess) e = hipEventRecord(uploaded, s);
     for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = hipStreamWaitEvent(g[k], uploaded, 0);
-    const auto generate_round = [&](uint32_t r) { // into buffer r % GEN_DEPTH, once its last reader (round r - GEN_DEPTH) is done
-        const uint32_t b = r % GEN_DEPTH;
-        hipStream_t gs = g[r % GEN_STREAMS];
-        hipError_t ge = r >= GEN_DEPTH ? hipStreamWaitEvent(gs, scored[b], 0) : hipSuccess;
+    const uint32_t units = (rounds + GEN_BATCH - 1) / GEN_BATCH;
+    const auto generate_unit = [&](uint32_t u) { // into buffer u % GEN_DEPTH, once its last reader (batch u - GEN_DEPTH) is done
+        const uint32_t b = u % GEN_DEPTH, r0 = u * GEN_BATCH, nr = std::min(GEN_BATCH, rounds - r0);
+        hipStream_t gs = g[u % GEN_STREAMS];
+        hipError_t ge = u >= GEN_DEPTH ? hipStreamWaitEvent(gs, scored[b], 0) : hipSuccess;
         if (ge != hipSuccess) return ge;
-        generate(m4, r, (int)b, d_F + (size_t)b * H * 9, gs);
-        // the buffer's live list, right behind its generation: three small launches less on the scoring chain
-        uint32_t *lv = d_live + (size_t)b * live_words;
-        launch_ransac_live(d_F + (size_t)b * H * 9, H, lv, lv + H, lv + H + 1, gs);
+        double *F_unit = d_F + (size_t)b * GEN_BATCH * H * 9;
+        generate(m4, r0, nr, (int)b, F_unit, gs);
+        // the rounds' live lists, right behind their generation: three small launches less on the scoring chain
+        for (uint32_t q = 0; q < nr; q++) {
+            uint32_t *lv = d_live + ((size_t)b * GEN_BATCH + q) * live_words;
+            launch_ransac_live(F_unit + (size_t)q * H * 9, H, lv, lv + H, lv + H + 1, gs);
+        }
         return hipEventRecord(ready[b], gs);
     };
-    for (uint32_t r = 0; r + 1 < GEN_DEPTH && r < rounds && e == hipSuccess; r++) e = generate_round(r);
+    for (uint32_t u = 0; u + 1 < GEN_DEPTH && u < units && e == hipSuccess; u++) e = generate_unit(u);
     for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
-        const uint32_t b = round % GEN_DEPTH;
-        double *F_round = d_F + (size_t)b * H * 9;
-        if (round + GEN_DEPTH - 1 < rounds) e = generate_round(round + GEN_DEPTH - 1);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
-        uint32_t *lv = d_live + (size_t)b * live_words;
+        const uint32_t u = round / GEN_BATCH, q = round % GEN_BATCH, b = u % GEN_DEPTH;
+        double *F_round = d_F + ((size_t)b * GEN_BATCH + q) * H * 9;
+        if (q == 0) {
+            if (u + GEN_DEPTH - 1 < units) e = generate_unit(u + GEN_DEPTH - 1);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
+        }
+        uint32_t *lv = d_live + ((size_t)b * GEN_BATCH + q) * live_words;
         // The first round has no best hypothesis to be abandoned against and the list in the matcher's order: every
         // hypothesis would fold (nearly) the whole list - 0.48 ms against 0.2 for the later rounds.  Its first
         // ROUND0_HEAD live hypotheses therefore go first, as a round of their own: what they leave behind - a best count,
@@ -2366,7 +2380,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
                                reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
         }
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(scored[b], s);
+        if (e == hipSuccess && (q + 1 == GEN_BATCH || round + 1 == rounds)) e = hipEventRecord(scored[b], s);
         if (!may_exit_early && !g_listener.wants_counts() && round + 1 < rounds) {
             g_listener.round_done(round + 1, rounds, false, 0); // position only: the round is enqueued, not finished
             continue;
@@ -2421,16 +2435,17 @@ int ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, d
     const uint32_t limit = std::min(N, TOP_INLIERS);
     if (rounds == 0 || rounds > RANSAC_K / CHECK_INTERVAL) rounds = RANSAC_K / CHECK_INTERVAL;
     // per generated round (GEN_DEPTH buffers, see ransac_rounds): the pencils, then the LM queue
-    const size_t gen_bytes = (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + ((1 + 3 * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t gen_bytes = GEN_BATCH * (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + ((1 + 3 * GEN_BATCH * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256;
     DevAllocs mem(dev->d);
     char *d_gen = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_gen, GEN_DEPTH * gen_bytes));
     const int rc = ransac_rounds(dev, mem, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
                                  out_inlier_count, out_inlier_mask, "ransac_perspective", refit_tail,
-                                 [&](const uint4 *m4, uint32_t round, int buffer, double *d_F, hipStream_t s) {
+                                 [&](const uint4 *m4, uint32_t round0, uint32_t n_rounds, int buffer, double *d_F, hipStream_t s) {
                                      PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
-                                     launch_generate_perspective(m4, limit, t, (unsigned long long)seed, round, CHECK_INTERVAL,
-                                                                 nullptr, pencils, (uint32_t *)(pencils + CHECK_INTERVAL), d_F, s);
+                                     launch_generate_perspective(m4, limit, t, (unsigned long long)seed, round0, CHECK_INTERVAL,
+                                                                 n_rounds * CHECK_INTERVAL, nullptr, pencils,
+                                                                 (uint32_t *)(pencils + GEN_BATCH * (size_t)CHECK_INTERVAL), d_F, s);
                                  });
     return rc;
 }
@@ -2488,7 +2503,7 @@ extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t
     uint32_t *d_queue = (uint32_t *)(d_pencils + B);
     const int rc = models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
                                      [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
-                                         launch_generate_perspective(m4, N, t, 0ull, 0u, B, idx, d_pencils, d_queue, d_F, s);
+                                         launch_generate_perspective(m4, N, t, 0ull, 0u, B, B, idx, d_pencils, d_queue, d_F, s);
                                      });
     (void)hipFree(d_pencils); // (models_of_samples has synchronised the stream)
     return rc;
