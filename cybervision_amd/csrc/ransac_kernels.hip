@@ -2274,7 +2274,7 @@ hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double
 // Hypotheses are generated GEN_BATCH rounds at a time (the generator kernels are bound by the latency of their serial f64
 // work on too few threads for the chip - 50 000 samples are 782 waves - so two rounds in one launch take what one
 // takes), into one of GEN_DEPTH buffers: the batch being scored and the two that may be generated ahead of it.
-constexpr uint32_t GEN_BATCH = 2, GEN_DEPTH = 3;
+constexpr uint32_t GEN_BATCH = 2, GEN_DEPTH = 5;
 template <typename Generate>
 int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
                   double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
