@@ -2288,13 +2288,15 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     uint8_t *d_mask = nullptr;
     hipError_t e = mem.alloc(&d_m, (size_t)N * 4);
     if (e == hipSuccess) e = mem.alloc(&d_F, GEN_DEPTH * GEN_BATCH * (size_t)H * 9); // the hypotheses of the rounds in flight
-    if (e == hipSuccess) e = mem.alloc(&d_cnt, (size_t)H);
-    if (e == hipSuccess) e = mem.alloc(&d_err, (size_t)H);
+    if (e == hipSuccess) e = mem.alloc(&d_cnt, GEN_BATCH * (size_t)H);
+    if (e == hipSuccess) e = mem.alloc(&d_err, GEN_BATCH * (size_t)H);
     if (e == hipSuccess) e = mem.alloc(&d_best, 1);
     if (e == hipSuccess) e = mem.alloc(&d_mask, N);
     // per hypothesis buffer: the live list [H], its length [1] and the compaction's scratch; then the round's maximum list
     // [2 + TIED_CAP] and the largest coordinate [1]
+    // (a batch scored as ONE round - see below - has one list of GEN_BATCH x H slots: it fits the space of its rounds' lists)
     const size_t live_words = (size_t)H + 1 + (H + 1023) / 1024;
+    static_assert(GEN_BATCH >= 1, "");
     uint32_t *d_live = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_live, GEN_DEPTH * GEN_BATCH * live_words + 3 + TIED_CAP);
     uint32_t *const d_tied = d_live + GEN_DEPTH * GEN_BATCH * live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
@@ -2327,6 +2329,12 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // The early exit (:135-141) needs more than `early_exit` inliers: with fewer matches than that it can never fire, and
     // the rounds are enqueued back to back with ONE host synchronisation at the end instead of a 4-byte read per round.
     const bool may_exit_early = N > early_exit;
+    // Without the early exit (and without a listener that wants the count after every round) nothing observes the state
+    // between the rounds of a batch, and Ord's result over a batch is the same whether its rounds are scored one after
+    // the other or as ONE round of GEN_BATCH x H slots (a later hypothesis replaces the best only if strictly better, the
+    // smaller slot stays among equals - and round q's slots follow round q - 1's): half as many counting launches and
+    // round ends (the latter are single-workgroup kernels: 20 - 70 us of an otherwise idle chip each).
+    const bool score_batches = !may_exit_early && !g_listener.wants_counts();
     constexpr uint32_t GEN_STREAMS = 2;
     static_assert(GEN_DEPTH <= sizeof(Device::RansacQueues::ready) / sizeof(hipEvent_t), "Device holds two side streams and RansacQueues' events");
     Device::RansacQueues &rq = dev->d.rq; // (kept on the handle: created once)
@@ -2350,9 +2358,14 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         double *F_unit = d_F + (size_t)b * GEN_BATCH * H * 9;
         generate(m4, r0, nr, (int)b, F_unit, gs);
         // the rounds' live lists, right behind their generation: three small launches less on the scoring chain
-        for (uint32_t q = 0; q < nr; q++) {
-            uint32_t *lv = d_live + ((size_t)b * GEN_BATCH + q) * live_words;
-            launch_ransac_live(F_unit + (size_t)q * H * 9, H, lv, lv + H, lv + H + 1, gs);
+        if (score_batches) {
+            uint32_t *lv = d_live + (size_t)b * GEN_BATCH * live_words;
+            launch_ransac_live(F_unit, nr * H, lv, lv + nr * H, lv + nr * H + 1, gs);
+        } else {
+            for (uint32_t q = 0; q < nr; q++) {
+                uint32_t *lv = d_live + ((size_t)b * GEN_BATCH + q) * live_words;
+                launch_ransac_live(F_unit + (size_t)q * H * 9, H, lv, lv + H, lv + H + 1, gs);
+            }
         }
         return hipEventRecord(ready[b], gs);
     };
@@ -2365,6 +2378,12 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
             if (e == hipSuccess) e = hipStreamWaitEvent(s, ready[b], 0);
         }
         uint32_t *lv = d_live + ((size_t)b * GEN_BATCH + q) * live_words;
+        // (a batch as one round: its first round's turn scores all of it, the others only report their position)
+        const uint32_t nr = std::min(GEN_BATCH, rounds - u * GEN_BATCH), HS = score_batches ? nr * H : H;
+        if (score_batches && q != 0) {
+            if (round + 1 < rounds) g_listener.round_done(round + 1, rounds, false, 0);
+            if (round + 1 < rounds) continue;
+        }
         // The first round has no best hypothesis to be abandoned against and the list in the matcher's order: every
         // hypothesis would fold (nearly) the whole list - 0.48 ms against 0.2 for the later rounds.  Its first
         // ROUND0_HEAD live hypotheses therefore go first, as a round of their own: what they leave behind - a best count,
@@ -2372,16 +2391,16 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         // hypothesis replaces the carried best only if it is strictly better, the smaller slot stays among equals.)
         constexpr uint32_t ROUND0_HEAD = 2048;
         const uint32_t parts = round == 0 && H > 4 * ROUND0_HEAD ? 2u : 1u;
-        for (uint32_t part = 0; part < parts; part++) {
+        for (uint32_t part = 0; part < parts && !(score_batches && q != 0); part++) {
             const uint32_t first = part == 0 ? 0u : ROUND0_HEAD, end = parts == 2 && part == 0 ? ROUND0_HEAD : 0xFFFFFFFFu;
-            launch_ransac_score_round(F_round, H, d_m, d_mo, d_mf, N, t, lv, lv + H, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err,
+            launch_ransac_score_round(F_round, HS, d_m, d_mo, d_mf, N, t, lv, lv + HS, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err,
                                       s, d_cand, first, end);
             hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
                                reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
         }
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess && (q + 1 == GEN_BATCH || round + 1 == rounds)) e = hipEventRecord(scored[b], s);
-        if (!may_exit_early && !g_listener.wants_counts() && round + 1 < rounds) {
+        if (e == hipSuccess && (score_batches ? q == 0 : (q + 1 == GEN_BATCH || round + 1 == rounds))) e = hipEventRecord(scored[b], s);
+        if (score_batches && round + 1 < rounds) {
             g_listener.round_done(round + 1, rounds, false, 0); // position only: the round is enqueued, not finished
             continue;
         }
