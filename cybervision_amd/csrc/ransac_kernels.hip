@@ -1163,35 +1163,55 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const dou
 // kernel's candidates (its own atomic maximum, and whoever reached it), the tie-break sums where they decide, the pick, the
 // reordering of the counting list.  Three launches and their gaps less on a chain of twenty rounds (~30 us each).
 // cand: as ransac_count_kernel leaves it, cleared here for the next round; tied: [2 + TIED_CAP] words of workspace.
-__global__ __launch_bounds__(1024) void ransac_round_finish_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
-                                                                    uint32_t N, double t, double *__restrict__ err_sums,
-                                                                    uint32_t min_count, uint32_t *__restrict__ cand,
-                                                                    uint32_t *tied, RansacBest *best,
-                                                                    uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+// the round's maximum list from the counting kernel's candidates; clears `cand` for the next round.  One workgroup.
+__device__ void ransac_round_tied_list(uint32_t *__restrict__ cand, uint32_t *tied)
 {
+    // (the candidates that reached the final maximum, picked out by all threads - one thread alone pays a dependent global
+    // load per candidate - then ordered by slot: the list's order does not depend on who finished first)
+    __shared__ uint32_t s_n, s_slots[TIED_CAP];
+    const uint32_t top = cand[0], listed = cand[1];
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    if (listed <= TIED_CAP)
+        for (uint32_t i = threadIdx.x; i < listed; i += blockDim.x)
+            if (cand[3 + 2 * i] == top) s_slots[atomicAdd(&s_n, 1u)] = cand[2 + 2 * i];
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t top = cand[0], listed = cand[1];
         uint32_t n = 0;
         if (listed > TIED_CAP) {
             n = TIED_CAP + 1u; // (never seen: more record holders than the list takes; the round is skipped, as above)
         } else {
-            for (uint32_t i = 0; i < listed; i++)
-                if (cand[3 + 2 * i] == top) { // insertion by slot: the list's order does not depend on who finished first
-                    const uint32_t h = cand[2 + 2 * i];
-                    uint32_t at = n++;
-                    for (; at > 0 && tied[at] > h; at--) tied[1 + at] = tied[at];
-                    tied[1 + at] = h;
-                }
+            for (uint32_t i = 0; i < s_n; i++) { // insertion by slot
+                const uint32_t h = s_slots[i];
+                uint32_t at = n++;
+                for (; at > 0 && tied[at] > h; at--) tied[1 + at] = tied[at];
+                tied[1 + at] = h;
+            }
         }
         tied[0] = n;
         tied[1 + TIED_CAP] = top;
         cand[0] = 0u;
         cand[1] = 0u;
     }
+}
+__global__ __launch_bounds__(1024) void ransac_round_finish_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches,
+                                                                    uint32_t N, double t, double *__restrict__ err_sums,
+                                                                    uint32_t min_count, uint32_t *__restrict__ cand,
+                                                                    uint32_t *tied, RansacBest *best,
+                                                                    uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+{
+    ransac_round_tied_list(cand, tied);
     __syncthreads();
     ransac_tied_approx(F, matches, N, t, tied, best, err_sums, 0u, 1u);
     __syncthreads();
     ransac_pick_best_approx(F, matches, N, t, err_sums, min_count, tied, best, order_u32, order_planes);
+}
+// the same in three launches, for rounds with several hypotheses at the maximum count (a batch of rounds scored as one:
+// each costs ~10 us of one workgroup's time in the kernel above, ~100 us per batch): the list, the sums spread over
+// workgroups (20 - 35 us), the pick
+__global__ __launch_bounds__(1024) void ransac_round_tied_list_kernel(uint32_t *__restrict__ cand, uint32_t *tied)
+{
+    ransac_round_tied_list(cand, tied);
 }
 
 // The live slots of a round's hypothesis buffer, in slot order (count, scan, scatter).  Depends on the hypotheses only,
@@ -2274,7 +2294,7 @@ hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double
 // Hypotheses are generated GEN_BATCH rounds at a time (the generator kernels are bound by the latency of their serial f64
 // work on too few threads for the chip - 50 000 samples are 782 waves - so two rounds in one launch take what one
 // takes), into one of GEN_DEPTH buffers: the batch being scored and the two that may be generated ahead of it.
-constexpr uint32_t GEN_BATCH = 2, GEN_DEPTH = 5;
+constexpr uint32_t GEN_BATCH = 4, GEN_DEPTH = 3;
 template <typename Generate>
 int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
                   double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
@@ -2395,11 +2415,18 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
             const uint32_t first = part == 0 ? 0u : ROUND0_HEAD, end = parts == 2 && part == 0 ? ROUND0_HEAD : 0xFFFFFFFFu;
             launch_ransac_score_round(F_round, HS, d_m, d_mo, d_mf, N, t, lv, lv + HS, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err,
                                       s, d_cand, first, end);
-            hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
-                               reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+            if (score_batches) {
+                hipLaunchKernelGGL(ransac_round_tied_list_kernel, dim3(1), dim3(1024), 0, s, d_cand, d_tied);
+                hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)d_tied, d_best, d_err);
+                hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)nullptr, d_err,
+                                   min_count, (const uint32_t *)d_tied, d_best, reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+            } else {
+                hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
+                                   reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+            }
         }
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess && (score_batches ? q == 0 : (q + 1 == GEN_BATCH || round + 1 == rounds))) e = hipEventRecord(scored[b], s);
+        if (e == hipSuccess && (score_batches ? q == 0 : (q + 1 == nr || round + 1 == rounds))) e = hipEventRecord(scored[b], s);
         if (score_batches && round + 1 < rounds) {
             g_listener.round_done(round + 1, rounds, false, 0); // position only: the round is enqueued, not finished
             continue;
