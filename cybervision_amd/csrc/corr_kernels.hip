@@ -360,10 +360,21 @@ __device__ __forceinline__ void neighbor_window(const CorrParams &p, uint32_t x,
     // full-res X = x' << pk with x' < pw
     // v / scale in f32 with scale = 2^-k and v < 2^24: exact, equal to v * 2^k
     const float up = (float)(1u << p.k);
-    uint32_t x_min = f32_to_u32_sat(floorf((float)sat_sub_u32(x, NEIGHBOR_DISTANCE) * up));
-    uint32_t x_max = f32_to_u32_sat(ceilf((float)(x + NEIGHBOR_DISTANCE) * up));
-    uint32_t y_min = f32_to_u32_sat(floorf((float)sat_sub_u32(y, NEIGHBOR_DISTANCE) * up));
-    uint32_t y_max = f32_to_u32_sat(ceilf((float)(y + NEIGHBOR_DISTANCE) * up));
+    uint32_t x_min, x_max, y_min, y_max;
+    if (p.k <= 12u && p.w1 < 0x10000u && p.h1 < 0x10000u && x < 0x10000u && y < 0x10000u) {
+        // integers below 2^17 times 2^k <= 2^12: the f32 products are exact integers below 2^29, floor and ceil leave them
+        // alone and the casts do not saturate - the same values without the conversions (uniform test but for x, y, which
+        // only exceed 2^16 on the wrapped column -1 of block 0; that pixel is rejected before its window is looked at)
+        x_min = sat_sub_u32(x, NEIGHBOR_DISTANCE) << p.k;
+        x_max = (x + NEIGHBOR_DISTANCE) << p.k;
+        y_min = sat_sub_u32(y, NEIGHBOR_DISTANCE) << p.k;
+        y_max = (y + NEIGHBOR_DISTANCE) << p.k;
+    } else {
+        x_min = f32_to_u32_sat(floorf((float)sat_sub_u32(x, NEIGHBOR_DISTANCE) * up));
+        x_max = f32_to_u32_sat(ceilf((float)(x + NEIGHBOR_DISTANCE) * up));
+        y_min = f32_to_u32_sat(floorf((float)sat_sub_u32(y, NEIGHBOR_DISTANCE) * up));
+        y_max = f32_to_u32_sat(ceilf((float)(y + NEIGHBOR_DISTANCE) * up));
+    }
     x_min = min(x_min, p.gw);
     x_max = min(x_max, p.gw);
     y_min = min(y_min, p.gh);
@@ -408,10 +419,16 @@ __device__ __forceinline__ void search_range_body(const CorrParams &p, const uin
     // the offset -scale*f2/f{0|1} differs.  It is finite (mod.rs:338-345) whenever |f2| and the divisor are far
     // from the f64 range limits; then the two f64 divisions per pixel are skipped.  Anything else takes the
     // per-pixel path below.
-    const bool affine_f = p.F[0] == 0.0 && p.F[1] == 0.0 && p.F[3] == 0.0 && p.F[4] == 0.0;
-    const Line e0 = epipolar_line(p, 0u, 0u);
-    const double fdom = fabs(p.F[2]) > fabs(p.F[5]) ? fabs(p.F[2]) : fabs(p.F[5]);
-    const bool quick = affine_f && fdom > 1e-150 && fdom < 1e150 && finite_f64(e0.cx) && finite_f64(e0.cy);
+    // (CorrParams::range_quick, evaluated on the host: the direction constants are finite - p.affine - the divisor is far
+    // from the range limits, and |F20| x / scale + |F21| y / scale + |F22| stays below 1e149 over the whole image, so that
+    // no pixel's f2 needs looking at)
+    const bool quick = p.range_quick != 0;
+    Line e0;
+    e0.cx = p.affine == 1 ? p.aff_c : 1.0;
+    e0.cy = p.affine == 1 ? 1.0 : p.aff_c;
+    e0.ax = e0.ay = 0.0; // (the offset is not used here)
+    e0.ox = p.affine == 1 ? 1 : 0;
+    e0.oy = p.affine == 1 ? 0 : 1;
     // sum path (below) of an affine F: its cell loads do not depend on the per-pixel tests, so they are issued first
     // and the two round trips to memory overlap
     const bool params_ok = p.min_range >= 0.0 && p.min_range < 1e9 && p.extend_range >= 0.0 && p.extend_range < 1e9;
@@ -445,15 +462,7 @@ __device__ __forceinline__ void search_range_body(const CorrParams &p, const uin
         // pixel_setup BEFORE it reads this pixel's interval, so the interval of a rejected pixel is never looked at -
         // and not reading the statistics word saves 8 B per pixel of HBM traffic)
         Line e = e0;
-        bool line_ok = false;
-        if (quick) {
-            const double up = (double)(1u << p.k), p0 = (double)x * up, p1 = (double)y * up; // = x / scale, exact
-            double f2 = p.F[6] * p0;
-            f2 = p.F[7] * p1 + f2;
-            f2 = p.F[8] * 1.0 + f2;
-            line_ok = fabs(f2) < 1e150;
-        }
-        if (!line_ok) {
+        if (!quick) {
             e = epipolar_line(p, x, y);
             if (!line_finite(e)) continue;
         }

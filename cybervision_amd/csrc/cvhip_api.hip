@@ -265,6 +265,11 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
             p.aff_div = div;
         }
     }
+    {
+        const double up = (double)(1u << k), fdom = std::fabs(F[2]) > std::fabs(F[5]) ? std::fabs(F[2]) : std::fabs(F[5]);
+        const double f2_bound = std::fabs(F[6]) * ((double)lw1 * up) + std::fabs(F[7]) * ((double)lh1 * up) + std::fabs(F[8]);
+        p.range_quick = p.affine != 0 && fdom > 1e-150 && fdom < 1e150 && f2_bound < 1e149 ? 1 : 0; // (NaN: not quick)
+    }
 #ifdef CVHIP_ABLATIONS
     { // profiling ablations ("results are then wrong on purpose"): compiled only into -DCVHIP_ABLATIONS builds
         static const int dbg = [] { const char *v = std::getenv("CVHIP_DEBUG"); return v ? std::atoi(v) : 0; }();

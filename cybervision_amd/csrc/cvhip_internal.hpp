@@ -72,6 +72,10 @@ struct CorrParams {
     // 2: the other one, aff_c = -F02/F12, aff_div = F12;  0: not affine (or not finite) - the generic per-pixel path.
     int affine;
     double aff_c, aff_div;
+    // search_range_kernel: 1 = every pixel of this pass has a finite epipolar line with the direction constants above
+    // (p.affine != 0, the divisor and the largest possible |F2 . p| far from the f64 range limits) - the kernel then
+    // evaluates no line at all (the interval only needs the line's axis and the corridor's end)
+    int range_quick;
     // Profiling ablations (env CVHIP_DEBUG, applied to the full-resolution level only; results are then wrong on
     // purpose): 1 = skip the whole-corridor kernel, 2 = skip the filter kernels, 4 = the box kernel declines every
     // workgroup, 8 / 16 = the box kernel skips its walk / its exact phase, 32 = box statistics in counters 1 and 2, 64 = the walk never enters its hit branch,
