@@ -996,7 +996,10 @@ __device__ __forceinline__ void store_cell(const CorrParams &p, uint32_t *__rest
 // One tile: `width` (<= 64) pixels from x0 in the four rows of row tile `ytile`.
 // Returns (uniformly for the workgroup) whether the tile holds whole-corridor pixels; only then are its contender
 // words written (each lane reads back only its own) and, when a work list is given, the tile is queued on it.
-template <bool COUNT>
+// MODE (the first pass in two launches, search2_filter_split_kernel): 1 = this workgroup walks ONE stripe of the tile's
+// corridors (`stripe_sel`) and leaves its contenders in `split`; 2 = no walk: the stripes' contenders are merged and the
+// exact phase runs.  0 = everything in one workgroup.
+template <bool COUNT, int MODE = 0>
 __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const uint8_t *__restrict__ img1,
                                                     const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
                                                     const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2,
@@ -1005,7 +1008,8 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
                                                     float *__restrict__ out_score,
                                                     unsigned long long *__restrict__ counters, int only_fallback,
                                                     PixTile tl, WorkList whole_list, uint8_t *__restrict__ tile,
-                                                    uint32_t lds_bytes)
+                                                    uint32_t lds_bytes, int stripe_sel = 0, unsigned long long *split = nullptr,
+                                                    uint32_t tile_index = 0, uint32_t n_tiles = 0)
 {
     // `tile` is the launch's dynamic LDS (lds_bytes: S2_LDS_BYTES, or S2_LDS_BYTES_STEEP where the host expects
     // tall candidate boxes)
@@ -1120,6 +1124,73 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
     unsigned long long word = 0ull; // 0 = settled here, CW_WHOLE = left to the exact kernel
     uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
     uint32_t evaluated = 0, multi = 0, whole = 0, exact_evals = 0;
+    // the filter's result for this pixel: the contender list (walk order), and - SPLIT - the contenders' filter scores
+    float runmax = -__builtin_inff();
+    unsigned long long clist = 0ull;
+    uint32_t count = 0;
+    float gl[S2_K] = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr bool SPLIT = MODE == 1;
+    static_assert(S2_K == 4, "gl[] is written by explicit selects");
+    // what follows the walk: overflow to the whole-corridor kernel, or the exact re-evaluation of the contenders
+    // (a: the searched window's rows, 12th byte zero)
+    const auto settle = [&](const Row12 (&a)[KERNEL_WIDTH]) {
+
+        if (count > (uint32_t)S2_K) {
+            word = CW_WHOLE << 60;
+            whole = 1;
+            evaluated = 0; // the exact kernel walks (and counts) the whole corridor
+        } else {
+            // ---- exact re-evaluation of the contenders, right here: the tile and the candidate statistics
+            // are still in LDS.  mod.rs:442-464 — the reference's serial f32 chain and acceptance rule.
+            multi = count > 1 ? 1u : 0u;
+            bool have = false;
+            float bcorr = 0.0f;
+            uint32_t bxy = 0;
+            const float avg1 = ps.st1.x, sdev1 = ps.st1.y;
+            // positions-only pass (CorrParams::need_scores): a single contender clearly above the threshold IS the
+            // match - every other candidate has g < g* - 2 delta, hence f < f*, and f* >= g* - delta >= threshold
+            uint32_t ecount = count;
+            if (!p.need_scores && count == 1u && runmax >= p.threshold + S2_DELTA) {
+                const uint32_t code = (uint32_t)clist & 0x7FFFu;
+                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                cell = make_uint2(c.x | (c.y << 16), __float_as_uint(runmax));
+                ecount = 0u;
+            }
+            for (uint32_t j = 0; j < ecount; j++) {
+                const uint32_t code = (uint32_t)(clist >> (15u * j)) & 0x7FFFu;
+                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                const uint2 is2 = lds_is[(c.y - (uint32_t)cy0) * cw + (c.x - (uint32_t)cx0)];
+                const float avg2 = (float)is2.x / (float)KERNEL_POINT_COUNT; // == compute_point_avg (exact sum)
+                const float sdev2 = __uint_as_float(is2.y);
+                const uint32_t a0 = (uint32_t)((int)c.y - KERNEL_SIZE - by0) * P + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
+                const uint32_t phi = a0 & 7u;
+                const uint8_t *src = tile + phi * CS + (a0 - phi);
+                float corr = 0.0f;
+#pragma unroll
+                for (int r = 0; r < KERNEL_WIDTH; r++) {
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
+                    const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
+                    Row12 ar = a[r];
+                    // opaque per iteration: keeps the 121 searched-window deltas from being hoisted out of the
+                    // contender loop into 121 live registers
+                    asm volatile("" : "+v"(ar.a), "+v"(ar.b), "+v"(ar.c));
+                    Row12 br;
+                    br.a = lo.x;
+                    br.b = lo.y;
+                    br.c = hi;
+                    corr = row_corr_acc(corr, ar, br, avg1, avg2);
+                }
+                corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
+                exact_evals++;
+                if (corr >= p.threshold && (!have || corr > bcorr)) { // mod.rs:456-464
+                    have = true;
+                    bcorr = corr;
+                    bxy = c.x | (c.y << 16);
+                }
+            }
+            if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
+        }
+    };
     if (active && (!use_lds || len > CW_MAX_LEN)) {
         word = CW_WHOLE << 60;
         whole = 1;
@@ -1143,10 +1214,7 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
         const float k1 = ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT); // 121*121*sd1
         const float c1 = 1.0f / k1;
 
-        float runmax = -__builtin_inff();
         const float thr_lo = p.threshold - S2_DELTA;
-        unsigned long long clist = 0ull;
-        uint32_t count = 0;
         // Acceptance band in the integer domain.  g = N * c1 / sd2 >= lim  <=>  (float)N >= lim * k1 * sd2
         // (k1, sd2 > 0).  limk = lim * k1 shaved by 2^-20 keeps the cheap test free of false negatives
         // against the handful of f32 roundings on either side; a hit is then re-tested with g itself.
@@ -1163,6 +1231,12 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
                 runmax = fmaxf(runmax, g);
                 limk = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo) * k1 * (1.0f - 9.5367431640625e-7f);
                 if (count < (uint32_t)S2_K) clist |= (unsigned long long)code << (15u * count);
+                if (SPLIT) { // (the merge re-tests every contender against the tile-wide band)
+                    gl[0] = count == 0u ? g : gl[0];
+                    gl[1] = count == 1u ? g : gl[1];
+                    gl[2] = count == 2u ? g : gl[2];
+                    gl[3] = count == 3u ? g : gl[3];
+                }
                 count = min(count + 1u, (uint32_t)S2_K + 1u);
             }
         };
@@ -1173,6 +1247,7 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
             constexpr uint32_t PF = decltype(pitch_tag)::value;
             const uint32_t Pp = PF ? PF : P;
             for (int off = -cs; off <= cs; off++) {
+                if (SPLIT && off != stripe_sel) continue;
                 // The minor coordinate is monotone in i; if it is the same at both ends of the interval it
                 // is the same everywhere and the per-candidate f64 evaluation can be skipped.
                 const CandXY cf = candidate_xy(e, r0, off), cl = candidate_xy(e, r1 - 1, off);
@@ -1270,65 +1345,72 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
                 }
             }
         };
-        if (P == S2_FIXED_PITCH)
-            walk(std::integral_constant<uint32_t, S2_FIXED_PITCH>{});
-        else
-            walk(std::integral_constant<uint32_t, 0u>{});
-
-        if (count > (uint32_t)S2_K) {
-            word = CW_WHOLE << 60;
-            whole = 1;
-            evaluated = 0; // the exact kernel walks (and counts) the whole corridor
-        } else {
-            // ---- exact re-evaluation of the contenders, right here: the tile and the candidate statistics
-            // are still in LDS.  mod.rs:442-464 — the reference's serial f32 chain and acceptance rule.
-            multi = count > 1 ? 1u : 0u;
-            bool have = false;
-            float bcorr = 0.0f;
-            uint32_t bxy = 0;
-            const float avg1 = ps.st1.x, sdev1 = ps.st1.y;
-            // positions-only pass (CorrParams::need_scores): a single contender clearly above the threshold IS the
-            // match - every other candidate has g < g* - 2 delta, hence f < f*, and f* >= g* - delta >= threshold
-            uint32_t ecount = count;
-            if (!p.need_scores && count == 1u && runmax >= p.threshold + S2_DELTA) {
-                const uint32_t code = (uint32_t)clist & 0x7FFFu;
-                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
-                cell = make_uint2(c.x | (c.y << 16), __float_as_uint(runmax));
-                ecount = 0u;
-            }
-            for (uint32_t j = 0; j < ecount; j++) {
-                const uint32_t code = (uint32_t)(clist >> (15u * j)) & 0x7FFFu;
-                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
-                const uint2 is2 = lds_is[(c.y - (uint32_t)cy0) * cw + (c.x - (uint32_t)cx0)];
-                const float avg2 = (float)is2.x / (float)KERNEL_POINT_COUNT; // == compute_point_avg (exact sum)
-                const float sdev2 = __uint_as_float(is2.y);
-                const uint32_t a0 = (uint32_t)((int)c.y - KERNEL_SIZE - by0) * P + (uint32_t)((int)c.x - KERNEL_SIZE - bx0);
-                const uint32_t phi = a0 & 7u;
-                const uint8_t *src = tile + phi * CS + (a0 - phi);
-                float corr = 0.0f;
+        if (MODE != 2) {
+            if (P == S2_FIXED_PITCH)
+                walk(std::integral_constant<uint32_t, S2_FIXED_PITCH>{});
+            else
+                walk(std::integral_constant<uint32_t, 0u>{});
+        }
+        if (MODE == 0) settle(a);
+    }
+    if constexpr (MODE == 1) {
+        // This workgroup's contenders of its stripe, per pixel: {runmax | count << 32, list, scores} - 32 bytes at
+        // [(tile * stripes + stripe) * 256 + thread].  The merge is the next launch.
+        const uint32_t NS = (uint32_t)(2 * cs + 1), sub = (uint32_t)(stripe_sel + cs);
+        unsigned long long *const rec = split + ((size_t)(tile_index * NS + sub) * 256u + threadIdx.x) * 4u;
+        rec[0] = (unsigned long long)__float_as_uint(runmax) | ((unsigned long long)count << 32);
+        rec[1] = clist;
+        rec[2] = (unsigned long long)__float_as_uint(gl[0]) | ((unsigned long long)__float_as_uint(gl[1]) << 32);
+        rec[3] = (unsigned long long)__float_as_uint(gl[2]) | ((unsigned long long)__float_as_uint(gl[3]) << 32);
+        if (COUNT && counters) { // (the candidates it looked at are counted here)
+            uint32_t v0 = evaluated;
 #pragma unroll
-                for (int r = 0; r < KERNEL_WIDTH; r++) {
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(src + r * P);
-                    const uint32_t hi = *reinterpret_cast<const uint32_t *>(src + r * P + 8);
-                    Row12 ar = a[r];
-                    // opaque per iteration: keeps the 121 searched-window deltas from being hoisted out of the
-                    // contender loop into 121 live registers
-                    asm volatile("" : "+v"(ar.a), "+v"(ar.b), "+v"(ar.c));
-                    Row12 br;
-                    br.a = lo.x;
-                    br.b = lo.y;
-                    br.c = hi;
-                    corr = row_corr_acc(corr, ar, br, avg1, avg2);
-                }
-                corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
-                exact_evals++;
-                if (corr >= p.threshold && (!have || corr > bcorr)) { // mod.rs:456-464
-                    have = true;
-                    bcorr = corr;
-                    bxy = c.x | (c.y << 16);
+            for (int sft = 32; sft > 0; sft >>= 1) v0 += __shfl_down(v0, sft, 64);
+            if (lane == 0 && v0) atomicAdd(&counters[0], (unsigned long long)v0);
+        }
+        return false;
+    }
+    if constexpr (MODE == 2) {
+        if (active && !whole) {
+            // The tile-wide band: a contender within 2 delta of the best score of ALL stripes was recorded by its own
+            // stripe's walk (whose running maximum was never larger) and survived that walk's resets (a reset means a
+            // score more than 2 delta above it).  Stripes in corridor order, a stripe's list in walk order: the merged
+            // list is in the reference's order, as the one-workgroup walk leaves it.
+            const uint32_t NS = (uint32_t)(2 * cs + 1);
+            const unsigned long long *const base = split + ((size_t)tile_index * NS * 256u + threadIdx.x) * 4u;
+            float rg = -__builtin_inff();
+            bool overflow = false;
+            for (uint32_t q = 0; q < NS; q++) {
+                const unsigned long long w0 = base[(size_t)q * 256u * 4u];
+                rg = fmaxf(rg, __uint_as_float((uint32_t)w0));
+                overflow = overflow || (uint32_t)(w0 >> 32) > (uint32_t)S2_K;
+            }
+            const float lim = fmaxf(rg - 2.0f * S2_DELTA, p.threshold - S2_DELTA);
+            count = 0;
+            clist = 0ull;
+            for (uint32_t q = 0; q < NS; q++) {
+                const unsigned long long *r4 = base + (size_t)q * 256u * 4u;
+                const uint32_t n = min((uint32_t)(r4[0] >> 32), (uint32_t)S2_K);
+                const unsigned long long cl = r4[1], g01 = r4[2], g23 = r4[3];
+                for (uint32_t j = 0; j < n; j++) {
+                    const unsigned long long gw = j < 2u ? g01 : g23;
+                    const float g = __uint_as_float((uint32_t)(gw >> (32u * (j & 1u))));
+                    if (g >= lim) {
+                        if (count < (uint32_t)S2_K) clist |= ((cl >> (15u * j)) & 0x7FFFull) << (15u * count);
+                        count = min(count + 1u, (uint32_t)S2_K + 1u);
+                    }
                 }
             }
-            if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
+            if (overflow) count = (uint32_t)S2_K + 1u;
+            runmax = rg;
+            Row12 a[KERNEL_WIDTH];
+            const uint8_t *base1 = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
+#pragma unroll
+            for (int r = 0; r < KERNEL_WIDTH; r++) {
+                a[r] = load_row12(base1 + (size_t)r * p.w1);
+                a[r].c &= 0x00FFFFFFu;
+            }
+            settle(a);
         }
     }
     const int any_whole = __syncthreads_or(whole ? 1 : 0); // every thread of the workgroup is still here
@@ -1366,6 +1448,25 @@ __global__ __launch_bounds__(256, 3) void search2_filter_kernel(SearchJob ja, Se
     (void)search2_filter_tile<COUNT>(j.p, j.img1, j.img2, j.stats1, j.stats1, j.stats2, j.range, j.contenders, j.out, j.out_score,
                                      j.counters, 0, PixTile{tid.x * 64u, j.p.row0 + tid.y * 4u, 64u, false}, j.whole,
                                      dyn_lds, lds_bytes);
+}
+
+// The first pass (64^2 .. 127^2 pixels, every candidate of the whole line: 54 per stripe) in two launches: 2 cs + 1
+// workgroups per tile walk one stripe each, then one workgroup per tile merges their contenders and evaluates them.  The
+// one-launch form is 32 workgroups of one wave per SIMD that each walk 270 candidates in series - 73 us of dependent
+// latency on an idle chip, which every rank of a multi-GPU run pays in full.  (A single launch whose last workgroup
+// per tile does the merge needs a device-scope release / acquire between workgroups on different XCDs - a write-back of
+// the XCD's L2, 30 - 100 us with other kernels' dirty lines in it: measured slower than this.)
+// blockIdx.x = tile column * stripes + stripe (walk);  tile column (merge).
+template <bool COUNT, int MODE>
+__global__ __launch_bounds__(256, 3) void search2_filter_split_kernel(SearchJob ja, SearchJob jb, uint32_t lds_bytes, uint32_t tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    const SearchJob &j = this_job();
+    const uint32_t NS = MODE == 1 ? (uint32_t)(2 * j.p.corridor_size + 1) : 1u, tx = blockIdx.x / NS, sub = blockIdx.x - tx * NS;
+    const uint32_t tile_index = blockIdx.y * tiles_x + tx, n_tiles = gridDim.y * tiles_x;
+    (void)search2_filter_tile<COUNT, MODE>(j.p, j.img1, j.img2, j.stats1, j.stats1, j.stats2, j.range, j.contenders, j.out, j.out_score,
+                                           j.counters, 0, PixTile{tx * 64u, j.p.row0 + blockIdx.y * 4u, 64u, false}, j.whole, dyn_lds,
+                                           lds_bytes, (int)sub - j.p.corridor_size, j.split, tile_index, n_tiles);
 }
 
 // ---- kernel A3: displacement-plane box filter ------------------------------------------------------------
@@ -1676,11 +1777,34 @@ void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s)
         lds = std::max(lds, search2_lds_bytes(p));
     }
     if (!gx || !gy) return;
+    // the first pass, one workgroup per (tile, stripe) where every job has the scratch for it (search2_split_words)
+    bool split = true;
+    for (int i = 0; i < n; i++)
+        split = split && job_active(jobs[i]) && jobs[i].p.first_pass && jobs[i].split != nullptr &&
+                jobs[i].p.corridor_size == jobs[0].p.corridor_size && (jobs[i].p.w1 + 63) / 64 == gx && (jobs[i].p.row1 - jobs[i].p.row0 + 3) / 4 == gy;
+    if (split) {
+        const uint32_t NS = (uint32_t)(2 * jobs[0].p.corridor_size + 1);
+        const dim3 wgrid(gx * NS, gy, (unsigned)n), mgrid(gx, gy, (unsigned)n);
+        if (jobs[0].counters) {
+            hipLaunchKernelGGL((search2_filter_split_kernel<true, 1>), wgrid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds, gx);
+            hipLaunchKernelGGL((search2_filter_split_kernel<true, 2>), mgrid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds, gx);
+        } else {
+            hipLaunchKernelGGL((search2_filter_split_kernel<false, 1>), wgrid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds, gx);
+            hipLaunchKernelGGL((search2_filter_split_kernel<false, 2>), mgrid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds, gx);
+        }
+        return;
+    }
     const dim3 grid(gx, gy, (unsigned)n);
     if (jobs[0].counters)
         hipLaunchKernelGGL(search2_filter_kernel<true>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds);
     else
         hipLaunchKernelGGL(search2_filter_kernel<false>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], lds);
+}
+
+size_t search2_split_words(uint32_t w, uint32_t rows, uint32_t stripes)
+{
+    const size_t tiles = (size_t)((w + 63) / 64) * ((rows + 3) / 4);
+    return tiles * stripes * 256u * 4u; // one 32-byte record per (tile, stripe, thread)
 }
 
 void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s)

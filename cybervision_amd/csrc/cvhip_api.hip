@@ -305,6 +305,13 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
     uint32_t *items = c->work + 8 + (size_t)dir * 2 * c->work_cap; // per-direction item arrays
     j.declined = WorkList{wc, items};
     j.whole = WorkList{wc + 1, items + c->work_cap};
+    // The first pass as one workgroup per (tile, stripe): its scratch is the tail of the contender words - the level
+    // uses the first lw1 x lh1 of them - where the buffer is large enough for both (any context beyond ~300^2 pixels).
+    j.split = nullptr;
+    if (first_pass) {
+        const size_t own = (size_t)lw1 * lh1, need = search2_split_words(lw1, lh1, 2u * (uint32_t)c->corridor_size + 1u);
+        if (lw1 <= 256 && lh1 <= 256 && own + need <= c->max_px) j.split = j.contenders + own;
+    }
 
     // Which search kernel.  Version 3: the box filter is the search; the candidate filter only walks the workgroups it
     // declines (timed with the other fallback work, class K_EXACT).  The box walk pays where the candidate sets of

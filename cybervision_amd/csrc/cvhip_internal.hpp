@@ -106,7 +106,11 @@ struct SearchJob {
     float *out_score;             // ... and score plane
     unsigned long long *counters; // device counters or nullptr
     WorkList declined, whole;
+    // first pass, one workgroup per (tile, stripe): search2_split_words(...) 8-byte words of scratch, or nullptr
+    unsigned long long *split;
 };
+// scratch of the split first pass for a level of w x rows pixels with `stripes` stripes, in 8-byte words
+size_t search2_split_words(uint32_t w, uint32_t rows, uint32_t stripes);
 void launch_search_range(const SearchJob *jobs, int n, int mode, hipStream_t s);
 void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2, const uint2 *stats1,
                    const uint2 *stats2, const uint32_t *range, uint32_t *out, float *out_score,
