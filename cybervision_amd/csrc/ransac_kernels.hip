@@ -12,7 +12,7 @@
 //    the order that abandons hopeless hypotheses soonest), ransac_round_finish_kernel (the round's maximum, tie-break
 //    sums only where a tie in the count needs them, Ord (:623-649) as a reduction, the re-sort);
 //  * the generators: affine (4-point, one-sided Jacobi SVD) and perspective (7-point pencil / root / queued LM);
-//  * ransac_rounds: generation two rounds ahead of scoring on separate streams; optimize_result's tail on the device:
+//  * ransac_rounds: generation in batches of rounds ahead of scoring on separate streams; optimize_result's tail on the device:
 //    inlier compaction, ransac_refit_kernel (the refit, :246, on one workgroup, bit-equal to the host loop), second filter;
 //  * the C entry points (include/cvhip.h).
 // f64 throughout except the screen, contraction off; expression order follows nalgebra 0.35's
