@@ -2329,6 +2329,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = hipMemsetAsync(d_cand, 0, 2 * sizeof(uint32_t), s);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+    // (the generators need the list and nothing else of what follows: their event goes right behind the upload)
+    if (e == hipSuccess && !dev->d.rq.uploaded) e = hipEventCreateWithFlags(&dev->d.rq.uploaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(dev->d.rq.uploaded, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_best, 0, sizeof(RansacBest), s);
     if (e == hipSuccess) // the scale of the counting kernel's f32 screen: one word behind the round's maximum list
         hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
@@ -2364,10 +2367,8 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         if (!rq.ready[b]) e = hipEventCreateWithFlags(&rq.ready[b], hipEventDisableTiming);
         if (e == hipSuccess && !rq.scored[b]) e = hipEventCreateWithFlags(&rq.scored[b], hipEventDisableTiming);
     }
-    if (e == hipSuccess && !rq.uploaded) e = hipEventCreateWithFlags(&rq.uploaded, hipEventDisableTiming);
     hipEvent_t *const ready = rq.ready, *const scored = rq.scored;
     const hipEvent_t uploaded = rq.uploaded;
-    if (e == hipSuccess) e = hipEventRecord(uploaded, s);
     for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = hipStreamWaitEvent(g[k], uploaded, 0);
     const uint32_t units = (rounds + GEN_BATCH - 1) / GEN_BATCH;
     const auto generate_unit = [&](uint32_t u) { // into buffer u % GEN_DEPTH, once its last reader (batch u - GEN_DEPTH) is done
