@@ -531,6 +531,7 @@ void device_free(cvhip_device *dev)
         for (hipEvent_t ev : rq.scored)
             if (ev) (void)hipEventDestroy(ev);
         if (rq.uploaded) (void)hipEventDestroy(rq.uploaded);
+        if (rq.started) (void)hipEventDestroy(rq.started);
     }
     for (hipEvent_t &ev : dev->d.orb_ev)
         if (ev) {

@@ -230,7 +230,7 @@ struct Device {
     // the RANSAC loops' generator streams and round events (created on first use: creating two streams and seven events
     // per find_ransac call cost 1.5 ms of every ~9 ms call)
     struct RansacQueues {
-        hipEvent_t ready[8] = {}, scored[8] = {}, uploaded = nullptr; // (per hypothesis buffer in flight)
+        hipEvent_t ready[8] = {}, scored[8] = {}, uploaded = nullptr, started = nullptr; // (per hypothesis buffer in flight)
     } rq;
     // cvhip_ctx_set_stats_ahead: the side stream the window statistics of the finer levels run on while the coarse levels'
     // (launch-latency bound) search chain occupies the main stream, one "done" event per level, one fence (created on

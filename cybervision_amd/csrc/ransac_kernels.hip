@@ -26,6 +26,7 @@
 #include <functional>
 #include <new>
 #include <utility>
+#include <thread>
 #include <vector>
 
 namespace cvhip {
@@ -423,6 +424,10 @@ struct RansacBest {
     uint32_t valid;
     uint32_t err_known; // best_error has been computed (it is only ever needed to break a tie in matches_count)
     uint32_t pad;       // (ransac_pick_best_approx_kernel's note of the count its match order was made for)
+    // Position of this hypothesis in the reference's iteration order (round x slots + slot), where the caller says it
+    // (slot_base): batches of rounds may then be scored in any order - among hypotheses that are EQUAL under Ord the one
+    // the reference meets first stays.  Scored in order it changes nothing (a later hypothesis never precedes the best).
+    uint32_t origin, origin_pad;
 };
 
 // The fold of validate_f (:210-216) for a batch of hypotheses, one lane per hypothesis.
@@ -1051,7 +1056,8 @@ __device__ void ransac_reorder_matches(const double *best_f, const uint4 *__rest
 
 __device__ void ransac_pick_best_approx(const double *__restrict__ F, const uint4 *__restrict__ matches, uint32_t N, double t,
                                         double *__restrict__ err_sums, uint32_t min_count, const uint32_t *tied,
-                                        RansacBest *best, uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+                                        RansacBest *best, uint4 *__restrict__ order_u32, float *__restrict__ order_planes,
+                                        uint32_t slot_base = 0u)
 {
     __shared__ double errs[1024];
     __shared__ uint32_t s_replaced;
@@ -1133,12 +1139,17 @@ __device__ void ransac_pick_best_approx(const double *__restrict__ F, const uint
     if (threadIdx.x == 0) {
         const uint32_t w = s_winner;
         s_replaced = 0u;
-        if (!best->valid || ransac_better(top, s_winner_err, best->matches_count, best->best_error)) {
+        // (equal under Ord - same count, and error sums that the ordered fold made bit-equal, or both not finite: the one
+        // met first in the reference's iteration order stays; only an out-of-order caller can bring an earlier one later)
+        const bool better = !best->valid || ransac_better(top, s_winner_err, best->matches_count, best->best_error);
+        const bool equal = best->valid && !better && !ransac_better(best->matches_count, best->best_error, top, s_winner_err);
+        if (better || (equal && slot_base + w < best->origin)) {
             for (int i = 0; i < 9; i++) best->f[i] = F[(size_t)w * 9 + i];
             best->matches_count = top;
             best->best_error = s_winner_err;
             best->valid = 1;
             best->err_known = errors ? (s_exact ? 2u : 1u) : 0u;
+            best->origin = slot_base + w;
             s_replaced = 1u;
         }
     }
@@ -1153,10 +1164,11 @@ __global__ __launch_bounds__(1024) void ransac_pick_best_approx_kernel(const dou
                                                                         uint32_t N, double t, const uint32_t *__restrict__ counts,
                                                                         double *__restrict__ err_sums, uint32_t min_count,
                                                                         const uint32_t *__restrict__ tied, RansacBest *best,
-                                                                        uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+                                                                        uint4 *__restrict__ order_u32, float *__restrict__ order_planes,
+                                                                        uint32_t slot_base)
 {
     (void)counts;
-    ransac_pick_best_approx(F, matches, N, t, err_sums, min_count, tied, best, order_u32, order_planes);
+    ransac_pick_best_approx(F, matches, N, t, err_sums, min_count, tied, best, order_u32, order_planes, slot_base);
 }
 
 // The device loops' round end in ONE launch behind the counting kernel: the round's maximum list from the counting
@@ -1198,13 +1210,14 @@ __global__ __launch_bounds__(1024) void ransac_round_finish_kernel(const double 
                                                                     uint32_t N, double t, double *__restrict__ err_sums,
                                                                     uint32_t min_count, uint32_t *__restrict__ cand,
                                                                     uint32_t *tied, RansacBest *best,
-                                                                    uint4 *__restrict__ order_u32, float *__restrict__ order_planes)
+                                                                    uint4 *__restrict__ order_u32, float *__restrict__ order_planes,
+                                                                    uint32_t slot_base)
 {
     ransac_round_tied_list(cand, tied);
     __syncthreads();
     ransac_tied_approx(F, matches, N, t, tied, best, err_sums, 0u, 1u);
     __syncthreads();
-    ransac_pick_best_approx(F, matches, N, t, err_sums, min_count, tied, best, order_u32, order_planes);
+    ransac_pick_best_approx(F, matches, N, t, err_sums, min_count, tied, best, order_u32, order_planes, slot_base);
 }
 // the same in three launches, for rounds with several hypotheses at the maximum count (a batch of rounds scored as one:
 // each costs ~10 us of one workgroup's time in the kernel above, ~100 us per batch): the list, the sums spread over
@@ -2167,7 +2180,7 @@ extern "C" int cvhip_ransac_rounds_pick(cvhip_device *dev, const double *F, uint
         launch_ransac_score_round(F_round, n, d_m, d_mo, d_mf, N, t, d_live, d_live + per, d_tied, d_coord_max, true, true, min_count, d_best,
                                   d_cnt, d_err, s, d_cand);
         hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
-                           reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+                           reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf), first);
     }
     CVHIP_TRY_HIP(hipGetLastError());
     RansacBest h_best;
@@ -2249,7 +2262,8 @@ extern "C" int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, u
                                   d_live + CHECK_INTERVAL + 1, d_live + CHECK_INTERVAL + 3 + TIED_CAP, false, true, RANSAC_D + RANSAC_N, d_best,
                                   d_cnt, d_err, s);
         hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, d_F, m4, N, RANSAC_T, (const uint32_t *)d_cnt, d_err,
-                           RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best, (uint4 *)nullptr, (float *)nullptr);
+                           RANSAC_D + RANSAC_N, (const uint32_t *)(d_live + CHECK_INTERVAL + 1), d_best, (uint4 *)nullptr, (float *)nullptr,
+                           round * CHECK_INTERVAL);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -2371,10 +2385,11 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     const hipEvent_t uploaded = rq.uploaded;
     for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = hipStreamWaitEvent(g[k], uploaded, 0);
     const uint32_t units = (rounds + GEN_BATCH - 1) / GEN_BATCH;
-    const auto generate_unit = [&](uint32_t u) { // into buffer u % GEN_DEPTH, once its last reader (batch u - GEN_DEPTH) is done
-        const uint32_t b = u % GEN_DEPTH, r0 = u * GEN_BATCH, nr = std::min(GEN_BATCH, rounds - r0);
-        hipStream_t gs = g[u % GEN_STREAMS];
-        hipError_t ge = u >= GEN_DEPTH ? hipStreamWaitEvent(gs, scored[b], 0) : hipSuccess;
+    // batch u into buffer b on generator stream k, once the buffer's last reader is done (wait_scored: it had one)
+    const auto generate_unit_on = [&](uint32_t u, uint32_t b, uint32_t k, bool wait_scored) {
+        const uint32_t r0 = u * GEN_BATCH, nr = std::min(GEN_BATCH, rounds - r0);
+        hipStream_t gs = g[k];
+        hipError_t ge = wait_scored ? hipStreamWaitEvent(gs, scored[b], 0) : hipSuccess;
         if (ge != hipSuccess) return ge;
         double *F_unit = d_F + (size_t)b * GEN_BATCH * H * 9;
         generate(m4, r0, nr, (int)b, F_unit, gs);
@@ -2390,8 +2405,109 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         }
         return hipEventRecord(ready[b], gs);
     };
-    for (uint32_t u = 0; u + 1 < GEN_DEPTH && u < units && e == hipSuccess; u++) e = generate_unit(u);
-    for (uint32_t round = 0; e == hipSuccess && round < rounds; round++) {
+    const auto generate_unit = [&](uint32_t u) { return generate_unit_on(u, u % GEN_DEPTH, u % GEN_STREAMS, u >= GEN_DEPTH); };
+    if (score_batches) {
+        // Batches are scored AS THEY BECOME READY, not in order.  A batch whose generator is held up - one
+        // Levenberg-Marquardt loop that runs to the reference's cap of 1000 iterations keeps its wave busy for 1.6 ms -
+        // is passed over until it is done or its buffer is needed; scored in order, the chain stood still behind it
+        // (~0.5 ms per pair on config 5, where such a loop sits in the second batch).  Ord's maximum does not depend on
+        // the order: more matches win, then the smaller mean error, and among EQUAL hypotheses the one the reference
+        // meets first - RansacBest::origin, the hypothesis' position in iteration order, decides that
+        // (ransac_pick_best_approx).  The counting kernel's bound only needs SOME best-so-far.  The host enqueues a
+        // batch as soon as it is ready - usually while the previous one is still being scored.
+        // Buffers and generator streams are handed out as they come free: the stream behind a long loop is not given
+        // the next batch while the other one is idle, and the batch that is passed over does not block the buffer of the
+        // batch three further on.
+        std::vector<char> done(units, 0);
+        std::vector<uint32_t> buf_of(units, 0);
+        uint32_t next_gen = 0, n_done = 0, reported = 0, turn = 0;
+        int buf_unit[GEN_DEPTH], stream_unit[GEN_STREAMS]; // the batch a buffer holds / a stream generated last (-1: none yet)
+        bool buf_used[GEN_DEPTH];
+        for (uint32_t b = 0; b < GEN_DEPTH; b++) {
+            buf_unit[b] = -1;
+            buf_used[b] = false;
+        }
+        for (uint32_t k = 0; k < GEN_STREAMS; k++) stream_unit[k] = -1;
+        const auto generated = [&](int u) { // has batch u left its generator stream?
+            if (u < 0 || done[(uint32_t)u]) return true;
+            const bool ok = hipEventQuery(ready[buf_of[(uint32_t)u]]) == hipSuccess;
+            (void)hipGetLastError();
+            return ok;
+        };
+        const auto top_up = [&]() {
+            while (e == hipSuccess && next_gen < units) {
+                uint32_t b = GEN_DEPTH;
+                for (uint32_t c = 0; c < GEN_DEPTH && b == GEN_DEPTH; c++)
+                    if (buf_unit[c] < 0 || done[(uint32_t)buf_unit[c]]) b = c; // never used, or its batch has been scored
+                if (b == GEN_DEPTH) break;
+                uint32_t k = GEN_STREAMS;
+                for (uint32_t c = 0; c < GEN_STREAMS && k == GEN_STREAMS; c++)
+                    if (generated(stream_unit[(turn + c) % GEN_STREAMS])) k = (turn + c) % GEN_STREAMS; // an idle stream, in turn
+                if (k == GEN_STREAMS) break; // both are busy - one of them perhaps for long: decided when one comes free
+                turn = k + 1;
+                e = generate_unit_on(next_gen, b, k, buf_used[b]);
+                buf_of[next_gen] = b;
+                buf_unit[b] = (int)next_gen;
+                buf_used[b] = true;
+                stream_unit[k] = (int)next_gen;
+                next_gen++;
+            }
+        };
+        top_up();
+        while (e == hipSuccess && n_done < units) {
+            // the oldest batch that is ready; with several to choose from and none ready yet, the host polls (the
+            // scoring chain has nothing to run then anyway); a single candidate is simply enqueued behind its event
+            uint32_t pick = 0xFFFFFFFFu, pending = 0, oldest = 0xFFFFFFFFu;
+            for (uint32_t u = 0; u < next_gen; u++)
+                if (!done[u]) {
+                    pending++;
+                    if (oldest == 0xFFFFFFFFu) oldest = u;
+                }
+            while (pick == 0xFFFFFFFFu && e == hipSuccess) {
+                for (uint32_t u = 0; u < next_gen && pick == 0xFFFFFFFFu; u++)
+                    if (!done[u] && generated((int)u)) pick = u;
+                if (pick == 0xFFFFFFFFu && pending == 1 && next_gen == units) pick = oldest; // the last one: nothing to decide
+                if (pick == 0xFFFFFFFFu) {
+                    std::this_thread::yield();
+                    const uint32_t before = next_gen;
+                    top_up(); // (a generator stream may have come free)
+                    pending += next_gen - before;
+                    if (oldest == 0xFFFFFFFFu && next_gen > before) oldest = before;
+                }
+            }
+            if (e != hipSuccess) break;
+            const uint32_t b = buf_of[pick], r0 = pick * GEN_BATCH, nr = std::min(GEN_BATCH, rounds - r0), HS = nr * H;
+            double *F_unit = d_F + (size_t)b * GEN_BATCH * H * 9;
+            uint32_t *lv = d_live + (size_t)b * GEN_BATCH * live_words;
+            e = hipStreamWaitEvent(s, ready[b], 0);
+            // (the first batch scored has no best hypothesis to be abandoned against: its first live hypotheses go
+            // first, as a round of their own - see the round-by-round loop below)
+            constexpr uint32_t HEAD = 2048;
+            const uint32_t parts = n_done == 0 && HS > 4 * HEAD ? 2u : 1u;
+            for (uint32_t part = 0; part < parts && e == hipSuccess; part++) {
+                const uint32_t first = part == 0 ? 0u : HEAD, end = parts == 2 && part == 0 ? HEAD : 0xFFFFFFFFu;
+                launch_ransac_score_round(F_unit, HS, d_m, d_mo, d_mf, N, t, lv, lv + HS, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt,
+                                          d_err, s, d_cand, first, end);
+                hipLaunchKernelGGL(ransac_round_tied_list_kernel, dim3(1), dim3(1024), 0, s, d_cand, d_tied);
+                hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, F_unit, m4, N, t, (const uint32_t *)d_tied, d_best, d_err);
+                hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, F_unit, m4, N, t, (const uint32_t *)nullptr, d_err,
+                                   min_count, (const uint32_t *)d_tied, d_best, reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf),
+                                   r0 * H);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipEventRecord(scored[b], s);
+            done[pick] = 1;
+            n_done++;
+            for (uint32_t q = 0; q < nr; q++)
+                if (++reported < rounds) g_listener.round_done(reported, rounds, false, 0); // position only: enqueued, not finished
+            top_up();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) g_listener.round_done(rounds, rounds, true, h_best.valid ? h_best.matches_count : 0);
+    }
+    for (uint32_t u = 0; !score_batches && u + 1 < GEN_DEPTH && u < units && e == hipSuccess; u++) e = generate_unit(u);
+    for (uint32_t round = 0; !score_batches && e == hipSuccess && round < rounds; round++) {
         const uint32_t u = round / GEN_BATCH, q = round % GEN_BATCH, b = u % GEN_DEPTH;
         double *F_round = d_F + ((size_t)b * GEN_BATCH + q) * H * 9;
         if (q == 0) {
@@ -2420,10 +2536,11 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
                 hipLaunchKernelGGL(ransac_round_tied_list_kernel, dim3(1), dim3(1024), 0, s, d_cand, d_tied);
                 hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)d_tied, d_best, d_err);
                 hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)nullptr, d_err,
-                                   min_count, (const uint32_t *)d_tied, d_best, reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+                                   min_count, (const uint32_t *)d_tied, d_best, reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf),
+                                   round * H);
             } else {
                 hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
-                                   reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf));
+                                   reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf), round * H);
             }
         }
         if (e == hipSuccess) e = hipGetLastError();
