@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Randomised check of the perspective RANSAC's two scoring schedules: with a listener that wants the count after every
+round the rounds are scored one by one, in order; without one, batches of rounds are scored as one round each and in the
+order their generators finish.  Both must give the same matrix and the same inlier mask for every match
+set, seed and run.   usage: fuzz_ransac.py [cases] [seed]"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import torch  # noqa: E402,F401
+
+import cases  # noqa: E402
+from cybervision_amd import correlation, fundamentalmatrix  # noqa: E402
+
+
+class Listener:
+    def __init__(self):
+        self.matches = []
+
+    def report_status(self, p):
+        pass
+
+    def report_matches(self, c):
+        self.matches.append(c)
+
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = correlation.create_gpu_context()
+bad = 0
+for it in range(N):
+    n = int(rng.integers(600, 30000))
+    frac = float(rng.uniform(0.1, 0.6))
+    size = int(rng.choice([1024, 2048, 4096]))
+    m, truth, _, _ = cases.perspective_matches(n=n, outlier_frac=frac, seed=int(rng.integers(1, 10000)), size=size)
+    seed = int(rng.integers(0, 1 << 30))
+    fmx = fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Perspective, float(size))
+    try:
+        F0, _, mask0 = fmx.find_ransac(dev, m, seed=seed, progress_listener=Listener())
+    except Exception as ex:  # no model: both schedules must agree on that too
+        F0, mask0 = None, str(ex)
+    for rep in range(2):
+        try:
+            F1, _, mask1 = fmx.find_ransac(dev, m, seed=seed)
+        except Exception as ex:
+            F1, mask1 = None, str(ex)
+        same = (F0 is None and F1 is None and mask0 == mask1) or (
+            F0 is not None and F1 is not None and np.array_equal(F0, F1) and np.array_equal(mask0, mask1))
+        if not same:
+            bad += 1
+            print(f"MISMATCH case {it} rep {rep}: n={n} outliers={frac:.2f} size={size} seed={seed}")
+    inl = int(np.asarray(mask0).sum()) if F0 is not None else -1
+    print(f"case {it}: n={n} outliers={frac:.2f} size={size} inliers={inl} of {int(truth.sum())} true", flush=True)
+dev.close()
+print(f"done: {N} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
