@@ -2430,9 +2430,10 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         for (uint32_t k = 0; k < GEN_STREAMS; k++) stream_unit[k] = -1;
         const auto generated = [&](int u) { // has batch u left its generator stream?
             if (u < 0 || done[(uint32_t)u]) return true;
-            const bool ok = hipEventQuery(ready[buf_of[(uint32_t)u]]) == hipSuccess;
+            const hipError_t qe = hipEventQuery(ready[buf_of[(uint32_t)u]]);
             (void)hipGetLastError();
-            return ok;
+            if (qe != hipSuccess && qe != hipErrorNotReady && e == hipSuccess) e = qe; // (a device error: the polling loops below end on it)
+            return qe == hipSuccess;
         };
         const auto top_up = [&]() {
             while (e == hipSuccess && next_gen < units) {
