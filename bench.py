@@ -124,7 +124,7 @@ def valu_profile(world):
             "cycles_per_valu_instr": big.get("cycles_per_valu_instr")}
 
 
-def measure_sfm3(size, steps, warmup, dev=None):
+def measure_sfm3(size, steps, warmup, dev=None, pencil=0):
     """BASELINE config 5 ("3-image perspective SFM: ORB + RANSAC F-matrix on GPU + pairwise dense correlation"):
     three synthetic size^2 perspective views, resident in HBM as u8 pyramids; one step = per-level ORB on the three
     images, 3 x matcher (threshold 48), 3 x perspective find_ransac (device RANSAC + LM refit), 3 x dense correlation
@@ -132,7 +132,7 @@ def measure_sfm3(size, steps, warmup, dev=None):
     the sparse stage does not shard)."""
     import torch
 
-    from cybervision_amd import correlation, reconstruction, synth
+    from cybervision_amd import correlation, fundamentalmatrix, reconstruction, synth
     from cybervision_amd.fundamentalmatrix import ProjectionMode
 
     views, K, poses = synth.make_sfm_views(size)
@@ -144,6 +144,8 @@ def measure_sfm3(size, steps, warmup, dev=None):
     pyr = [[torch.from_numpy(l).cuda() for l in synth.box_pyramid(v, lsteps)] for v in views]
     # (resident, padded, complete before the timed region: the dense stage uses the levels in place)
     pyr = [reconstruction.padded_pyramid(p)[0] for p in pyr]
+    # the 7-point pencil: 0 = rows 5 / 6 of the thin SVD as the reference writes it (the library's default), 1 = null space
+    fundamentalmatrix.set_pencil(dev, pencil)
     acc, n_pairs, matches, inliers, dense_cells = {}, 0, [], [], []
     t0 = time.perf_counter()
     for it in range(warmup + steps):
@@ -161,10 +163,11 @@ def measure_sfm3(size, steps, warmup, dev=None):
         matches.append(int(len(e["matches"])))
         inliers.append(int(len(e["inliers"])) if e["inliers"] is not None else 0)
         dense_cells.append(reconstruction.match_count(e["xy"]) if "xy" in e else 0)
+    fundamentalmatrix.set_pencil(dev, fundamentalmatrix.PENCIL_THIN_SVD)
     if own_dev:
         dev.close()
     stage_ms = {k: round(v / steps, 3) for k, v in acc.items()}
-    return {"size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
+    return {"pencil": "thin_svd_rows_5_6 (reference)" if pencil == 0 else "null_space (textbook)", "size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
             "dense_mpixels_per_s": round(n_pairs * size * size / 1e6 / (stage_ms["dense"] / 1e3), 2),
             "whole_pipeline_mpixels_per_s": round(3 * size * size / 1e6 / (dt / steps), 2),
             "keypoints": [int(len(k[0])) for k in res["keypoints"]], "matches": matches, "ransac_inliers": inliers,
@@ -174,7 +177,7 @@ def measure_sfm3(size, steps, warmup, dev=None):
 def bench_sfm3(args):
     """`--config sfm3`: config 5 as a line of its own (a secondary line, not the headline metric)."""
     size = 2048 if args.size == 4096 else args.size
-    m = measure_sfm3(size, args.steps, args.warmup)
+    m = measure_sfm3(size, args.steps, args.warmup, pencil=args.pencil)
     print(json.dumps({
         "metric": f"Mpixels/s dense correlation, 3 x {size}x{size} perspective views (3 pairs), config 5", "secondary": True,
         "value": m["dense_mpixels_per_s"], "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
@@ -183,7 +186,7 @@ def bench_sfm3(args):
         "config": {"workload": f"3 perspective views {size}x{size} of one depth surface (synth.make_sfm_views), per-level ORB, "
                                "matcher thr 48, perspective RANSAC (20 x 50 000 samples, early exit) + LM refit, 3 pairwise "
                                f"dense correlations (9 stripes, thr 0.5, {m['levels']} levels)", "parallelism": "single GPU"},
-        "stage_ms_per_step": m["stage_ms"],
+        "stage_ms_per_step": m["stage_ms"], "pencil": m["pencil"],
         "whole_pipeline_mpixels_per_s": m["whole_pipeline_mpixels_per_s"],
         "keypoints": m["keypoints"], "matches": m["matches"], "ransac_inliers": m["ransac_inliers"],
         "dense_matches": m["dense_matches"],
@@ -212,6 +215,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512, help="side of the first crop timed on the CPU")
     ap.add_argument("--config", default="dense4096", choices=["dense4096", "sfm3"],
                     help="dense4096 (default): the headline metric; sfm3: BASELINE config 5, a secondary line")
+    ap.add_argument("--pencil", type=int, default=0, choices=[0, 1], help="--config sfm3: 7-point pencil (0 = the reference's thin-SVD rows, 1 = null space)")
     ap.add_argument("--no-extras", action="store_true", help="skip readback / geometry_sweep / sfm3 in the headline line")
     ap.add_argument("--sweep-tilts", default="3,10,30,60,90", help="tilts (degrees) of geometry_sweep")
     args = ap.parse_args()

@@ -76,6 +76,7 @@ SIGNATURES = {
     "cvhip_match_points": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cvhip_ransac_affine": (C.c_int, [_vp, _vp, _u32, C.c_uint64, _vp, C.POINTER(_u32), _vp]),
     "cvhip_ransac_perspective": (C.c_int, [_vp, _vp, _u32, C.c_double, C.c_uint64, _u32, _vp, C.POINTER(_u32), _vp]),
+    "cvhip_ransac_set_pencil": (C.c_int, [_vp, C.c_int]),
     "cvhip_ransac_perspective_models": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp]),
     "cvhip_ransac_affine_models": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp]),
     "cvhip_fits_model": (C.c_int, [_vp, _vp, _vp, _u32, C.c_double, _vp]),

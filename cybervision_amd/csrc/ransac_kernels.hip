@@ -263,7 +263,7 @@ __host__ __device__ inline void singular3(const double (&M)[9], double (&sv)[3])
 #pragma clang diagnostic ignored "-Wpass-failed" // (the unroll requests are for N = 7; N = 0 has run-time trip counts)
 template <int N>
 __host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt(double (&q)[7], const Obs *obs, uint32_t n_obs, double *r,
-                                                             double *r_new, double *J)
+                                                             double *r_new, double *J, int budget = 1000, bool *exhausted = nullptr)
 {
     const uint32_t n = N > 0 ? (uint32_t)N : n_obs;
     double M[9], g[7];
@@ -300,6 +300,10 @@ __host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt(double (&q)[7], con
     mu *= 1e-3;
     double nu = 2.0;
     for (int iteration = 0; iteration < 1000; iteration++) {
+        if (iteration >= budget) { // (a caller that continues the root elsewhere; the reference's cap is the 1000 above)
+            *exhausted = true;
+            return false;
+        }
         double A[49];
 #pragma unroll
         for (int i = 0; i < 7; i++) {
@@ -367,12 +371,15 @@ __host__ __device__ inline bool converged_at_start7(const double (&q)[7], const 
     return fabs(m) <= 1e-12;
 }
 
-// validate_f's call (n = 7), run by the device's LM kernel for the roots that fail the start test (it re-evaluates
-// the start: same values)
-__host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt7(double (&q)[7], const Obs *obs)
+// validate_f's call (n = 7), run by the device's thread-per-root LM kernel for the roots that fail the start test (it
+// re-evaluates the start: same values).  -> 1 = Ok, 0 = Err, 2 = still running after `budget` iterations (q is then
+// unspecified: the caller restarts the root elsewhere)
+__host__ __device__ CVHIP_LM_INLINE int levenberg_marquardt7(double (&q)[7], const Obs *obs, int budget)
 {
     double r[7], r_new[7], J[49];
-    return levenberg_marquardt<7>(q, obs, 7, r, r_new, J);
+    bool exhausted = false;
+    const bool ok = levenberg_marquardt<7>(q, obs, 7, r, r_new, J, budget, &exhausted);
+    return exhausted ? 2 : (ok ? 1 : 0);
 }
 
 // optimize_perspective_f (:391-426): F (normalised by F[2][2]) -> out, false = None
@@ -1470,10 +1477,112 @@ __device__ int cubic_real_roots(double c0, double c1, double c2, double c3, doub
     return n;
 }
 
-// -> number of candidate F's written (each normalised by F[2][2]); ok[k] tells which survived the checks
-// The pencil of a sample: the two null vectors of the 7x9 system and the real roots of det(a n1 + (1 - a) n2) = 0
-// (:293-358); returns the number of roots.
-__device__ int perspective_pencil(const uint4 (&sm)[7], double (&n1)[9], double (&n2)[9], double (&roots)[3])
+// The pencil's basis as the reference WRITES it (fundamentalmatrix.rs:309-322): `a.svd(false, true)` on an
+// SMatrix<f64, 7, 9> is nalgebra's THIN decomposition - v_t is DimMinimum<7, 9> x 9 = 7 x 9, singular values descending -
+// so v_t.row(nrows - 2) and v_t.row(nrows - 1) are rows 5 and 6: the right singular vectors of the two SMALLEST of the
+// seven singular values, not the null space of A (that would be rows 7 and 8 of a full V').  The pencil's members
+// therefore have det 0 but do not fit the sample; validate_f's optimize_perspective_f (:201-205) starts from them.
+// One-sided (Hestenes) Jacobi on W = A' (9 x 7): pairs of columns are rotated until mutually orthogonal, then
+// W J = V S - column norms = singular values, normalised columns = right singular vectors of A, each to full relative
+// accuracy (an eigen-decomposition of A A' would square a condition number of ~1e7).  n1 = the vector of the second
+// smallest singular value (row 5), n2 = of the smallest (row 6).  SIGN: a singular vector is defined up to sign and
+// nalgebra's choice falls out of its bidiagonalisation (source not in this image); the roots of the cubic in
+// `a` and the scale the rank test :365-370 sees depend on it (projectively the pencil is the same).  Convention here
+// (the CPU checker of the tests uses the same one): the entry of largest magnitude, the first of equals, is positive.
+__device__ void perspective_basis_thin_svd(const uint4 (&sm)[7], double (&n1)[9], double (&n2)[9])
+{
+    double W[9][7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const double x1 = (double)sm[i].x, y1 = (double)sm[i].y, x2 = (double)sm[i].z, y2 = (double)sm[i].w;
+        W[0][i] = x2 * x1;
+        W[1][i] = x2 * y1;
+        W[2][i] = x2;
+        W[3][i] = y2 * x1;
+        W[4][i] = y2 * y1;
+        W[5][i] = y2;
+        W[6][i] = x1;
+        W[7][i] = y1;
+        W[8][i] = 1.0;
+    }
+    for (int sweep = 0; sweep < 30; sweep++) { // fixed pivot order (static indices: W stays in registers)
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 7; p++)
+#pragma unroll
+            for (int q = p + 1; q < 7; q++) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    alpha += W[k][p] * W[k][p];
+                    beta += W[k][q] * W[k][q];
+                    gamma += W[k][p] * W[k][q];
+                }
+                if (!(fabs(gamma) > 1e-300) || !(fabs(gamma) > 1e-15 * sqrt(alpha * beta))) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double tt = __builtin_copysign(1.0, zeta) / (fabs(zeta) + sqrt(zeta * zeta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const double wp = W[k][p], wq = W[k][q];
+                    W[k][p] = c * wp - sn * wq;
+                    W[k][q] = sn * wp + c * wq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double nrm[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) ss += W[k][j] * W[k][j];
+        nrm[j] = sqrt(ss);
+    }
+    int i7 = 0; // smallest, then the smallest of the rest (a later column only replaces an earlier one if strictly smaller)
+#pragma unroll
+    for (int j = 1; j < 7; j++)
+        if (nrm[j] < nrm[i7]) i7 = j;
+    int i6 = i7 == 0 ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        if (j != i7 && nrm[j] < nrm[i6]) i6 = j;
+    double s6 = 0.0, s7 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        if (j == i6) s6 = nrm[j];
+        if (j == i7) s7 = nrm[j];
+    }
+    double big1 = -1.0, big2 = -1.0, sg1 = 1.0, sg2 = 1.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            if (j == i6) a = W[k][j];
+            if (j == i7) b = W[k][j];
+        }
+        n1[k] = a / s6;
+        n2[k] = b / s7;
+        if (fabs(n1[k]) > big1) {
+            big1 = fabs(n1[k]);
+            sg1 = n1[k] < 0.0 ? -1.0 : 1.0;
+        }
+        if (fabs(n2[k]) > big2) {
+            big2 = fabs(n2[k]);
+            sg2 = n2[k] < 0.0 ? -1.0 : 1.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        n1[k] *= sg1;
+        n2[k] *= sg2;
+    }
+}
+
+// The textbook basis (cvhip_ransac_set_pencil(dev, CVHIP_PENCIL_NULL_SPACE)): the two-dimensional null space of A.
+__device__ void perspective_basis_null_space(const uint4 (&sm)[7], double (&n1)[9], double (&n2)[9])
 {
     // M = A^T (9 x 7), fundamentalmatrix.rs:293-309; Householder QR, reflectors kept in place
     double M[9][7], beta[7];
@@ -1512,12 +1621,8 @@ __device__ int perspective_pencil(const uint4 (&sm)[7], double (&n1)[9], double 
             for (int r = k; r < 9; r++) M[r][c] -= dot * M[r][k];
         }
     }
-    // null space of A = last two columns of Q = H0 H1 ... H6 applied to e7, e8.
-    // DELIBERATE DEVIATION from fundamentalmatrix.rs:309-322 as written: the reference takes rows nrows-2, nrows-1 of
-    // nalgebra's v_t, which for a 7x9 matrix is 7x9 (DimMinimum<R, C> x C) - the singular vectors of the two smallest of
-    // the seven singular values, not the null space; its pencil only fits the sample after validate_f's LM.  Those rows
-    // cannot be reproduced from the crate's published interface (the rank test :362-366 depends on the sign the
-    // decomposition gives each vector); the 7-point algorithm's own null space is used instead.  DESIGN.md section 2.
+    // null space of A = last two columns of Q = H0 H1 ... H6 applied to e7, e8: NOT what fundamentalmatrix.rs:309-322
+    // takes (see perspective_basis_thin_svd) - the 7-point algorithm as published, whose pencil fits the sample exactly.
 #pragma unroll
     for (int r = 0; r < 9; r++) {
         n1[r] = r == 7 ? 1.0 : 0.0;
@@ -1539,6 +1644,15 @@ __device__ int perspective_pencil(const uint4 (&sm)[7], double (&n1)[9], double 
             n2[r] -= d2 * M[r][k];
         }
     }
+}
+
+// The pencil of a sample: its basis (n1, n2) in the mode the handle is in (CVHIP_PENCIL_THIN_SVD, the reference's and the
+// default; CVHIP_PENCIL_NULL_SPACE) and the real roots of det(a n1 + (1 - a) n2) = 0 (:324-358); returns the number of roots.
+template <bool THIN>
+__device__ int perspective_pencil(const uint4 (&sm)[7], double (&n1)[9], double (&n2)[9], double (&roots)[3])
+{
+    if (THIN) perspective_basis_thin_svd(sm, n1, n2);
+    else perspective_basis_null_space(sm, n1, n2);
     // d[i][j][k] = det([F_i col 0, F_j col 1, F_k col 2]) (vgg_singF_from_FF, :326-337)
     double d[2][2][2];
 #pragma unroll
@@ -1641,6 +1755,7 @@ struct PerspPencil {
     int nr, pad;
 };
 
+template <bool THIN>
 __global__ __launch_bounds__(64) void ransac_perspective_pencil_kernel(const uint4 *__restrict__ matches, uint32_t limit,
                                                                         unsigned long long seed, uint32_t round0, uint32_t per_round,
                                                                         uint32_t H, const uint32_t *__restrict__ sample_idx,
@@ -1681,7 +1796,7 @@ __global__ __launch_bounds__(64) void ransac_perspective_pencil_kernel(const uin
     PerspPencil &out = pencils[g];
     double n1[9], n2[9], roots[3] = {0.0, 0.0, 0.0};
     int nr = 0;
-    if (have == 7) nr = perspective_pencil(sm, n1, n2, roots);
+    if (have == 7) nr = perspective_pencil<THIN>(sm, n1, n2, roots);
     out.nr = nr;
     if (nr > 0) {
 #pragma unroll
@@ -1880,20 +1995,70 @@ __global__ __launch_bounds__(64) void ransac_perspective_lm_kernel(const PerspPe
     }
 }
 
-// queue: 1 + 3 H words
-// H samples: `per_round` each of the rounds round0, round0 + 1, ... (H a multiple of per_round)
-static void launch_generate_perspective(const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round0,
-                                        uint32_t per_round, uint32_t H, const uint32_t *sample_idx, PerspPencil *pencils,
-                                        uint32_t *queue, double *d_F, hipStream_t s)
+// The same loop, one THREAD per queued root: the form for the reference's own pencil (CVHIP_PENCIL_THIN_SVD), where
+// EVERY root that passes the rank and sign tests enters least_squares away from a solution - ~80 000 roots per round
+// instead of ~6 000 - and the loops are short: the Jacobian as the reference writes it (:473-512; c = d = a plain sum of
+// the four linear forms) is not the derivative of the residual, steps are rejected until mu has grown enough for the
+// step to vanish (mu x 2, x 4, x 8, ...: `delta.norm() <= 1e-12 (params.norm() + 1e-12)` after ~5-25 iterations, "found").
+// With that many independent short loops the chip is filled by roots, not by the inside of one loop: lm::levenberg_marquardt7
+// (register-resident, the scalar loop itself) on 64 roots per wave.  A root that has not finished within `budget`
+// iterations is handed to the wave-per-root kernel through `late` (which runs it from its start: same values), so one
+// long loop does not hold 63 finished lanes.
+__global__ __launch_bounds__(64) void ransac_perspective_lm_thread_kernel(const PerspPencil *__restrict__ pencils, double t,
+                                                                           double *__restrict__ F, const uint32_t *__restrict__ queue,
+                                                                           uint32_t *__restrict__ late, int budget)
 {
+    const uint32_t item = blockIdx.x * 64 + threadIdx.x;
+    if (item >= queue[0]) return;
+    const uint32_t g = queue[1u + item];
+    const PerspPencil &pc = pencils[g / 3u];
+    uint4 sm[7];
+    lm::Obs obs[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        sm[i] = pc.sm[i];
+        obs[i] = lm::make_obs(sm[i].x, sm[i].y, sm[i].z, sm[i].w);
+    }
+    double q[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
+    const int status = lm::levenberg_marquardt7(q, obs, budget); // 1 = Ok, 0 = Err, 2 = budget exhausted
+    if (status == 2) {
+        late[1u + atomicAdd(&late[0], 1u)] = g; // (F[g] still holds the start parameters)
+        return;
+    }
+    double f[9];
+    const bool ok = status == 1 && perspective_root_accept(q, sm, t, f);
+    const double nan = __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = ok ? f[i] : nan;
+}
+
+// queue, late: 1 + 3 H words each
+// H samples: `per_round` each of the rounds round0, round0 + 1, ... (H a multiple of per_round)
+constexpr int LM_THREAD_BUDGET = 48; // iterations a root gets in the thread-per-root kernel (thin-SVD pencil: 99.9 % need < 25)
+static void launch_generate_perspective(int pencil, const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round0,
+                                        uint32_t per_round, uint32_t H, const uint32_t *sample_idx, PerspPencil *pencils,
+                                        uint32_t *queue, uint32_t *late, double *d_F, hipStream_t s)
+{
+    const bool thin = pencil == CVHIP_PENCIL_THIN_SVD;
     (void)hipMemsetAsync(queue, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(ransac_perspective_pencil_kernel, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round0, per_round, H,
-                       sample_idx, pencils);
+    if (thin) {
+        (void)hipMemsetAsync(late, 0, sizeof(uint32_t), s);
+        hipLaunchKernelGGL(ransac_perspective_pencil_kernel<true>, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round0, per_round, H,
+                           sample_idx, pencils);
+    } else {
+        hipLaunchKernelGGL(ransac_perspective_pencil_kernel<false>, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round0, per_round, H,
+                           sample_idx, pencils);
+    }
     hipLaunchKernelGGL(ransac_perspective_root_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, H, t,
                        d_F, queue);
+    if (thin) // every queued root on a lane of its own; the stragglers go on to the wave-per-root kernel below
+        hipLaunchKernelGGL(ransac_perspective_lm_thread_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, t, d_F,
+                           (const uint32_t *)queue, late, LM_THREAD_BUDGET);
     // a persistent grid of waves strides over the queue (one wave per queued root)
     hipLaunchKernelGGL(ransac_perspective_lm_kernel, dim3(std::min<uint32_t>(3 * H, 4096u)), dim3(64), 0, s, (const PerspPencil *)pencils, t, d_F,
-                       (const uint32_t *)queue);
+                       (const uint32_t *)(thin ? late : queue));
 }
 
 // Ord for RansacIterationResult (fundamentalmatrix.rs:623-649)
@@ -2600,7 +2765,9 @@ int ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, d
     const uint32_t limit = std::min(N, TOP_INLIERS);
     if (rounds == 0 || rounds > RANSAC_K / CHECK_INTERVAL) rounds = RANSAC_K / CHECK_INTERVAL;
     // per generated round (GEN_DEPTH buffers, see ransac_rounds): the pencils, then the LM queue
-    const size_t gen_bytes = GEN_BATCH * (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + ((1 + 3 * GEN_BATCH * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t queue_bytes = ((1 + 3 * GEN_BATCH * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256; // every root can be queued
+    const size_t gen_bytes = GEN_BATCH * (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + 2 * queue_bytes;
+    const int pencil = dev->d.ransac_pencil;
     DevAllocs mem(dev->d);
     char *d_gen = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_gen, GEN_DEPTH * gen_bytes));
@@ -2608,13 +2775,22 @@ int ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, d
                                  out_inlier_count, out_inlier_mask, "ransac_perspective", refit_tail,
                                  [&](const uint4 *m4, uint32_t round0, uint32_t n_rounds, int buffer, double *d_F, hipStream_t s) {
                                      PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
-                                     launch_generate_perspective(m4, limit, t, (unsigned long long)seed, round0, CHECK_INTERVAL,
-                                                                 n_rounds * CHECK_INTERVAL, nullptr, pencils,
-                                                                 (uint32_t *)(pencils + GEN_BATCH * (size_t)CHECK_INTERVAL), d_F, s);
+                                     char *queues = (char *)(pencils + GEN_BATCH * (size_t)CHECK_INTERVAL);
+                                     launch_generate_perspective(pencil, m4, limit, t, (unsigned long long)seed, round0, CHECK_INTERVAL,
+                                                                 n_rounds * CHECK_INTERVAL, nullptr, pencils, (uint32_t *)queues,
+                                                                 (uint32_t *)(queues + queue_bytes), d_F, s);
                                  });
     return rc;
 }
 } // namespace
+
+extern "C" int cvhip_ransac_set_pencil(cvhip_device *dev, int pencil)
+{
+    if (!dev) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_pencil: null device");
+    if (pencil != CVHIP_PENCIL_THIN_SVD && pencil != CVHIP_PENCIL_NULL_SPACE) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_pencil: unknown mode");
+    dev->d.ransac_pencil = pencil;
+    return CVHIP_OK;
+}
 
 extern "C" int cvhip_ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, double max_dimension,
                                         uint64_t seed, uint32_t rounds, double *out_F, uint32_t *out_inlier_count,
@@ -2664,11 +2840,12 @@ extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t
                                                  [](const uint4 *, const uint32_t *, double *, hipStream_t) {});
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     PerspPencil *d_pencils = nullptr;
-    CVHIP_TRY_HIP(hipMalloc(&d_pencils, (size_t)B * sizeof(PerspPencil) + (1 + 3 * (size_t)B) * sizeof(uint32_t)));
-    uint32_t *d_queue = (uint32_t *)(d_pencils + B);
+    CVHIP_TRY_HIP(hipMalloc(&d_pencils, (size_t)B * sizeof(PerspPencil) + 2 * (1 + 3 * (size_t)B) * sizeof(uint32_t)));
+    uint32_t *d_queue = (uint32_t *)(d_pencils + B), *d_late = d_queue + 1 + 3 * (size_t)B;
+    const int pencil = dev->d.ransac_pencil;
     const int rc = models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
                                      [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
-                                         launch_generate_perspective(m4, N, t, 0ull, 0u, B, B, idx, d_pencils, d_queue, d_F, s);
+                                         launch_generate_perspective(pencil, m4, N, t, 0ull, 0u, B, B, idx, d_pencils, d_queue, d_late, d_F, s);
                                      });
     (void)hipFree(d_pencils); // (models_of_samples has synchronised the stream)
     return rc;

@@ -16,6 +16,14 @@ RANSAC_T_AFFINE = 0.1                 # fundamentalmatrix.rs:22
 RANSAC_T_PERSPECTIVE = 10.0 / 1000.0  # fundamentalmatrix.rs:23 (times max_dimension)
 
 
+PENCIL_THIN_SVD, PENCIL_NULL_SPACE = 0, 1  # cvhip_ransac_set_pencil (include/cvhip.h); default: the reference's thin-SVD rows
+
+
+def set_pencil(device, pencil: int):
+    """cvhip_ransac_set_pencil: the basis of the 7-point pencil (fundamentalmatrix.rs:309-322) for this device handle."""
+    _lib.check(_lib.lib().cvhip_ransac_set_pencil(device.handle, int(pencil)), "cvhip_ransac_set_pencil")
+
+
 class ProjectionMode(IntEnum):  # fundamentalmatrix.rs:35-39
     Affine = 0
     Perspective = 1

@@ -358,11 +358,22 @@ int cvhip_ransac_score(cvhip_device *dev, const double *F, uint32_t H, const uin
 int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, uint64_t seed, double *out_F,
                         uint32_t *out_inlier_count, uint8_t *out_inlier_mask);
 
+/* The basis of the 7-point pencil in calculate_model_perspective (fundamentalmatrix.rs:309-322).
+ * CVHIP_PENCIL_THIN_SVD (default) is the reference as written: `a.svd(false, true)` on the 7 x 9 system is nalgebra's
+ * thin decomposition (v_t: 7 x 9, singular values descending), so `v_t.row(nrows - 2)` / `.row(nrows - 1)` are rows 5 and
+ * 6 - the right singular vectors of the two SMALLEST of the seven singular values, not the null space.  Its hypotheses
+ * do not fit their own sample until validate_f's optimize_perspective_f (:201-205) has run on EVERY root, which the
+ * device does.  Sign convention of a singular vector (nalgebra's is not observable from its published interface): the
+ * entry of largest magnitude is positive.  CVHIP_PENCIL_NULL_SPACE is the 7-point algorithm as published (the true
+ * null space of A: rounds 2-3 of this build), kept as an option: better hypotheses, and ~3x cheaper - not the reference's. */
+#define CVHIP_PENCIL_THIN_SVD 0
+#define CVHIP_PENCIL_NULL_SPACE 1
+int cvhip_ransac_set_pencil(cvhip_device *dev, int pencil);
+
 /* Perspective RANSAC on the device — FundamentalMatrix::new(Perspective, max_dimension).find_ransac
- * (fundamentalmatrix.rs:72-147, 155-229, 289-389): per sample the 7-point model (null space of the 7x9
- * system - the one documented deviation from the reference as written, which takes the last two rows of nalgebra's
- * 7x9 thin v_t, DESIGN.md section 2 - the determinant cubic, the reference's rank and sign-consistency checks, up to
- * three roots),
+ * (fundamentalmatrix.rs:72-147, 155-229, 289-389): per sample the 7-point model (the pencil's basis as
+ * cvhip_ransac_set_pencil says - default: rows 5 and 6 of the thin SVD, as the reference writes it -, the
+ * determinant cubic, the reference's rank and sign-consistency checks, up to three roots),
  * every surviving root scored against ALL matches, best = most inliers then smallest mean error, early
  * exit above 50 000 inliers; t = 0.01 * max_dimension.  `rounds` = number of 50 000-sample rounds (0 or
  * more than 20 = the reference's 20).  validate_f's per-hypothesis optimize_perspective_f (:201-205: the LM

@@ -81,17 +81,38 @@ def _real_cubic_roots(c0, c1, c2, c3):
     return sorted(float(z.real) for z in r if abs(z.imag) <= 1e-9 * max(1.0, abs(z.real)))
 
 
-def calculate_model_perspective(sample):
-    """:289-389.  sample [7, 4] -> list of F [3, 3] (normalised by F[2][2], rank and sign checks applied)."""
+PENCIL_THIN_SVD, PENCIL_NULL_SPACE = 0, 1   # cvhip_ransac_set_pencil's modes (include/cvhip.h)
+
+
+def canonical_sign(v):
+    """The sign convention of the thin-SVD pencil, shared with the device generator: a singular vector is only defined
+    up to sign, nalgebra's choice falls out of its bidiagonalisation (source not in this image), and the pencil
+    `root f1 + (1 - root) f2` - its roots and the SCALE the rank test :365-370 sees - depends on it.  Convention here:
+    the entry of largest magnitude (the first of equals) is positive."""
+    v = np.asarray(v, dtype=np.float64)
+    return -v if v[int(np.argmax(np.abs(v)))] < 0.0 else v
+
+
+def perspective_pencil(sample, pencil=PENCIL_THIN_SVD):
+    """:289-323 -> (f1, f2) as [3, 3].  PENCIL_THIN_SVD (default) is the reference as written: `a.svd(false, true)` on
+    an SMatrix<7, 9> gives nalgebra's THIN decomposition - v_t is DimMinimum<7, 9> x 9 = 7 x 9, singular values
+    descending - so v_t.row(nrows - 2) and v_t.row(nrows - 1) are rows 5 and 6: the right singular vectors of the
+    two SMALLEST of the seven singular values, NOT the two-dimensional null space of A.  PENCIL_NULL_SPACE is the
+    7-point algorithm as published (rows 7 and 8 of the full 9 x 9 V'), kept as an option."""
     p1, p2 = _h(sample)
     x1, y1, x2, y2 = p1[:, 0], p1[:, 1], p2[:, 0], p2[:, 1]
     A = np.stack([x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, np.ones(7)], axis=1)
-    # DELIBERATE DEVIATION from :309-322 as written (shared with the device generator, DESIGN.md section 2): the
-    # reference takes v_t.row(nrows - 2), v_t.row(nrows - 1) of nalgebra's svd(false, true), whose v_t is 7 x 9 for a
-    # 7 x 9 matrix - rows 5 and 6, the singular vectors of the two smallest of the SEVEN singular values, not the null
-    # space.  The true null space (rows 7 and 8 of the full V') is used here: the 7-point algorithm as published.
+    if pencil == PENCIL_THIN_SVD:
+        _, _, vt = np.linalg.svd(A, full_matrices=False)          # [7, 9]
+        return canonical_sign(vt[5]).reshape(3, 3), canonical_sign(vt[6]).reshape(3, 3)
     _, _, vt = np.linalg.svd(A, full_matrices=True)
-    f1, f2 = vt[7].reshape(3, 3), vt[8].reshape(3, 3)
+    return vt[7].reshape(3, 3), vt[8].reshape(3, 3)
+
+
+def calculate_model_perspective(sample, pencil=PENCIL_THIN_SVD):
+    """:289-389.  sample [7, 4] -> list of F [3, 3] (normalised by F[2][2], rank and sign checks applied)."""
+    p1, p2 = _h(sample)
+    f1, f2 = perspective_pencil(sample, pencil)
     ff = (f1, f2)
     d = np.empty((2, 2, 2))
     for i in range(2):
@@ -252,12 +273,12 @@ def choose_inliers(matches, n, rng):
     return np.array(idx, dtype=np.int64)
 
 
-def ransac_iteration(matches, sample_idx, t, min_count, perspective):
+def ransac_iteration(matches, sample_idx, t, min_count, perspective, pencil=PENCIL_THIN_SVD):
     """:177-190 for one given sample -> list of (F, count, error)."""
     m = np.asarray(matches).reshape(-1, 4)
     sample = m[np.asarray(sample_idx)]
     if perspective:
-        models = calculate_model_perspective(sample)
+        models = calculate_model_perspective(sample, pencil)
     else:
         f = calculate_model_affine(sample)
         models = [] if f is None else [f]
@@ -269,7 +290,8 @@ def ransac_iteration(matches, sample_idx, t, min_count, perspective):
     return out
 
 
-def find_ransac(matches, perspective, max_dimension=0.0, rng=None, iterations=RANSAC_K, check_interval=RANSAC_CHECK_INTERVAL):
+def find_ransac(matches, perspective, max_dimension=0.0, rng=None, iterations=RANSAC_K, check_interval=RANSAC_CHECK_INTERVAL,
+                pencil=PENCIL_THIN_SVD):
     """:103-147 + optimize_result (:231-257) -> (F, inlier mask) or raises ValueError with the reference's text."""
     m = np.asarray(matches).reshape(-1, 4)
     n = RANSAC_N_PERSPECTIVE if perspective else RANSAC_N_AFFINE
@@ -282,7 +304,7 @@ def find_ransac(matches, perspective, max_dimension=0.0, rng=None, iterations=RA
     best = None
     for _ in range(max(iterations // check_interval, 1)):
         for _ in range(check_interval):
-            for r in ransac_iteration(m, choose_inliers(m, n, rng), t, d + n, perspective):
+            for r in ransac_iteration(m, choose_inliers(m, n, rng), t, d + n, perspective, pencil):
                 if best is None or better((r[1], r[2]), (best[1], best[2])):
                     best = r
         if best is not None and best[1] > early:

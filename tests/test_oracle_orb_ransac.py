@@ -158,15 +158,16 @@ def test_ransac_score_counts(oracle):
 
 
 def test_perspective_seven_point_solver_recovers_exact_geometry(oracle, oracle_fm):
-    """The oracle's numpy restatement of calculate_model_perspective (fundamentalmatrix.rs:289-389): on exact
-    correspondences one of the cubic's roots is the true F (zero reprojection error on every point), it passes the
-    reference's rank and sign checks, and the vectorised reprojection error agrees with the C restatement."""
+    """The oracle's numpy restatement of calculate_model_perspective (fundamentalmatrix.rs:289-389) with the textbook
+    null-space pencil (PENCIL_NULL_SPACE, the optional mode): on exact correspondences one of the cubic's roots is
+    the true F (zero reprojection error on every point), it passes the reference's rank and sign checks, and the
+    vectorised reprojection error agrees with the C restatement."""
     import cases
 
     fm = oracle_fm
     m, _, exact, F_true = cases.perspective_matches(n=400, outlier_frac=0.0)
     for k in range(5):
-        F = fm.calculate_model_perspective(exact[7 * k:7 * k + 7])
+        F = fm.calculate_model_perspective(exact[7 * k:7 * k + 7], fm.PENCIL_NULL_SPACE)
         assert len(F) >= 1
         errs = np.array([np.abs(fm.reprojection_error(Fi, exact)).max() for Fi in F])
         assert errs.min() < 1e-12
@@ -185,6 +186,69 @@ def test_perspective_seven_point_solver_recovers_exact_geometry(oracle, oracle_f
         d = np.abs(pts[:, None, :] - pts[None, :, :])
         d[np.arange(7), np.arange(7)] = 1000
         assert (d >= fm.MIN_INLIER_DISTANCE).all()
+
+
+def _hestenes_svd(W):
+    """One-sided Jacobi on the columns of W [m, n] -> (column norms = singular values, normalised columns = left
+    singular vectors of W).  Plain Python; the device generator uses the same method."""
+    W = np.array(W, dtype=np.float64)
+    n = W.shape[1]
+    for _ in range(60):
+        rotated = False
+        for p in range(n):
+            for q in range(p + 1, n):
+                al, be, ga = W[:, p] @ W[:, p], W[:, q] @ W[:, q], W[:, p] @ W[:, q]
+                if abs(ga) <= 1e-17 * np.sqrt(al * be):
+                    continue
+                rotated = True
+                ze = (be - al) / (2.0 * ga)
+                t = np.copysign(1.0, ze) / (abs(ze) + np.sqrt(ze * ze + 1.0))
+                c = 1.0 / np.sqrt(t * t + 1.0)
+                sn = t * c
+                W[:, p], W[:, q] = c * W[:, p] - sn * W[:, q], sn * W[:, p] + c * W[:, q]
+        if not rotated:
+            break
+    sv = np.linalg.norm(W, axis=0)
+    return sv, W / sv
+
+
+def test_reference_pencil_is_rows_5_and_6_of_the_thin_svd(oracle_fm):
+    """calculate_model_perspective as the reference WRITES it (:309-322): `a.svd(false, true)` of the 7 x 9 system is
+    nalgebra's thin decomposition (v_t: 7 x 9), so rows nrows-2 / nrows-1 are rows 5 and 6 - the right singular
+    vectors of the two smallest of the SEVEN singular values.  Pinned here without LAPACK: a plain-Python one-sided
+    Jacobi SVD gives the same two vectors (modulo sign) and singular values; orthonormal, canonical sign; they are NOT
+    null vectors (|A v| = sigma > 0), so the pencil's members have det 0 but do not fit the sample - validate_f's LM
+    (:201-205) starts from there for every root.  The null-space mode differs and does fit."""
+    import cases
+
+    fm = oracle_fm
+    m, _, exact, _ = cases.perspective_matches(n=400, outlier_frac=0.0)
+    for k in range(8):
+        sample = m[7 * k:7 * k + 7]
+        p1, p2 = fm._h(sample)
+        A = np.stack([p2[:, 0] * p1[:, 0], p2[:, 0] * p1[:, 1], p2[:, 0], p2[:, 1] * p1[:, 0], p2[:, 1] * p1[:, 1], p2[:, 1],
+                      p1[:, 0], p1[:, 1], np.ones(7)], axis=1)
+        f1, f2 = fm.perspective_pencil(sample)                       # default = the reference's
+        v1, v2 = f1.reshape(9), f2.reshape(9)
+        assert abs(v1 @ v1 - 1) < 1e-12 and abs(v2 @ v2 - 1) < 1e-12 and abs(v1 @ v2) < 1e-9
+        assert v1[np.argmax(np.abs(v1))] > 0 and v2[np.argmax(np.abs(v2))] > 0
+        s1, s2 = np.linalg.norm(A @ v1), np.linalg.norm(A @ v2)     # = sigma_6, sigma_7
+        sv, V = _hestenes_svd(A.T)                                   # independent of LAPACK: one-sided Jacobi
+        order = np.argsort(-sv)
+        assert s1 >= s2 > 0 and abs(s1 - sv[order[5]]) <= 1e-9 * sv[order[5]] and abs(s2 - sv[order[6]]) <= 1e-9 * sv[order[6]]
+        for v, col in ((v1, order[5]), (v2, order[6])):
+            assert min(np.abs(v - V[:, col]).max(), np.abs(v + V[:, col]).max()) < 1e-8
+        n1, n2 = fm.perspective_pencil(sample, fm.PENCIL_NULL_SPACE)
+        assert np.linalg.norm(A @ n1.reshape(9)) < 1e-6 and np.linalg.norm(A @ n2.reshape(9)) < 1e-6
+        for F in fm.calculate_model_perspective(sample):
+            assert F[2, 2] == 1.0 and abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-9
+    # on EXACT correspondences A has rank <= 7 with a genuine null space, yet the thin rows still skip it: the textbook
+    # mode recovers the geometry (test above), the reference's mode does not
+    fits = 0
+    for k in range(5):
+        for F in fm.calculate_model_perspective(exact[7 * k:7 * k + 7]):
+            fits += int(np.abs(fm.reprojection_error(F, exact)).max() < 1e-9)
+    assert fits == 0
 
 
 def test_affine_four_point_model_known_answers(oracle_fm):
@@ -232,7 +296,7 @@ def test_validate_f_and_result_ordering(oracle_fm):
             d[np.arange(7), np.arange(7)] = 1000
             if (d >= 10).all():
                 break
-        for F in fm.calculate_model_perspective(m[idx]):
+        for F in fm.calculate_model_perspective(m[idx], fm.PENCIL_NULL_SPACE):
             r = fm.validate_f(F, m[idx], m, t, 207, True)
             if r is None:
                 continue
@@ -388,7 +452,7 @@ def test_perspective_refit_is_the_identity_on_an_exact_fit(oracle, oracle_fm):
     # a generic exact case: the planted geometry with sub-pixel-exact (unrounded would be exact) points replaced by
     # points that satisfy the integer-rounded F exactly is not constructible; use the 7-point property instead:
     mm, truth, _, _ = cases.perspective_matches(n=400, outlier_frac=0.0, seed=9)
-    Fs = oracle_fm.calculate_model_perspective(mm[:7])
+    Fs = oracle_fm.calculate_model_perspective(mm[:7], oracle_fm.PENCIL_NULL_SPACE)
     assert len(Fs) >= 1
     for F7 in Fs:
         got = fundamentalmatrix.optimize_perspective_f(F7, mm[:7])

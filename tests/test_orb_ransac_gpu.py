@@ -331,24 +331,23 @@ def test_device_affine_generator_matches_oracle_per_sample(gpu_device, oracle_fm
     del deg
 
 
-def test_device_perspective_generator_and_validate_f_match_oracle_per_sample(gpu_device, oracle_fm):
-    """The device's 7-point generator INCLUDING validate_f's per-hypothesis part (finite test, optimize_perspective_f
-    over the sample with its rank test on the re-parametrised matrix, sample-fit test; fundamentalmatrix.rs:192-209,
-    391-426) against the oracle's numpy restatement (LAPACK SVD, np.roots, np.linalg.solve) on identical samples:
-    the same hypotheses survive - up to a handful that sit on a rank / sign threshold - and the surviving matrices
-    agree to 1e-7 of their largest entry."""
-    import cases
+@pytest.fixture
+def null_space_pencil(gpu_device):
+    """The textbook pencil (CVHIP_PENCIL_NULL_SPACE) for one test; the handle goes back to the reference's default."""
+    fundamentalmatrix.set_pencil(gpu_device, fundamentalmatrix.PENCIL_NULL_SPACE)
+    yield gpu_device
+    fundamentalmatrix.set_pencil(gpu_device, fundamentalmatrix.PENCIL_THIN_SVD)
 
-    m, _, _, _ = cases.perspective_matches(n=3000, outlier_frac=0.2, seed=11)
-    idx = _samples(m, 7, 2500, seed=4)
-    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+
+def _compare_generator_with_oracle(gpu_device, oracle_fm, m, idx, t, pencil):
+    """-> (oracle hypotheses, device hypotheses, matched to 1e-7 of the largest entry, unmatched examples, device array)"""
     got = fundamentalmatrix.perspective_models_device(gpu_device, m, idx, t)          # [B, 3, 3, 3]
     n_ref = n_dev = matched = 0
     unmatched = []
     for b, s_idx in enumerate(idx):
         sample = m[s_idx]
         want = []
-        for F in oracle_fm.calculate_model_perspective(sample):
+        for F in oracle_fm.calculate_model_perspective(sample, pencil):
             if not np.isfinite(F).all():
                 continue
             Fo = oracle_fm.optimize_perspective_f(F, sample)
@@ -363,6 +362,22 @@ def test_device_perspective_generator_and_validate_f_match_oracle_per_sample(gpu
                 matched += 1
             else:
                 unmatched.append((b, min(rel) if rel else None))
+    return n_ref, n_dev, matched, unmatched, got
+
+
+def test_device_perspective_generator_and_validate_f_match_oracle_per_sample(null_space_pencil, oracle_fm):
+    """The device's 7-point generator in the TEXTBOOK mode (null-space pencil) INCLUDING validate_f's per-hypothesis part
+    (finite test, optimize_perspective_f over the sample with its rank test on the re-parametrised matrix, sample-fit
+    test; fundamentalmatrix.rs:192-209, 391-426) against the oracle's numpy restatement (LAPACK SVD, np.roots,
+    np.linalg.solve) on identical samples: the same hypotheses survive - up to a handful that sit on a rank / sign
+    threshold - and the surviving matrices agree to 1e-7 of their largest entry."""
+    import cases
+
+    gpu_device = null_space_pencil
+    m, _, _, _ = cases.perspective_matches(n=3000, outlier_frac=0.2, seed=11)
+    idx = _samples(m, 7, 2500, seed=4)
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+    n_ref, n_dev, matched, unmatched, got = _compare_generator_with_oracle(gpu_device, oracle_fm, m, idx, t, oracle_fm.PENCIL_NULL_SPACE)
     assert n_ref > 300, n_ref
     assert abs(n_dev - n_ref) <= max(3, 0.005 * n_ref), (n_dev, n_ref)
     assert matched >= n_ref - max(3, 0.005 * n_ref), (matched, n_ref, unmatched[:5])
@@ -371,6 +386,42 @@ def test_device_perspective_generator_and_validate_f_match_oracle_per_sample(gpu
     assert (alive[:, 2, 2] == 1.0).all()
     dets = np.abs(np.linalg.det(alive / np.abs(alive).max(axis=(1, 2), keepdims=True)))
     assert dets.max() < 1e-9
+
+
+def test_device_reference_pencil_matches_thin_svd_rows_per_sample(gpu_device, oracle_fm):
+    """calculate_model_perspective AS THE REFERENCE WRITES IT (:309-322: rows 5 and 6 of nalgebra's thin 7 x 9 v_t, the
+    default mode) + validate_f's per-hypothesis part on the device against the oracle on identical samples.  The
+    oracle takes np.linalg.svd(A, full_matrices=False) rows 5 / 6 in the same sign convention; everything downstream
+    is the reference's: cubic, rank test before the F22 scale, sign test, then optimize_perspective_f's LM on EVERY
+    root (none of them fits its sample at the start), rank test on the re-parametrised matrix, sample-fit test.
+    (a) with the sample-fit test disarmed (t = 1e300) every root that leaves the LM is compared - the pencil, the roots
+    and the LM trajectory (all steps rejected until the step vanishes, or accepted ones) to 1e-7;
+    (b) with the reference's t the few hypotheses that fit their own sample are the same ones."""
+    import cases
+
+    m, _, _, _ = cases.perspective_matches(n=3000, outlier_frac=0.2, seed=11)
+    idx = _samples(m, 7, 1500, seed=4)
+    n_ref, n_dev, matched, unmatched, got = _compare_generator_with_oracle(gpu_device, oracle_fm, m, idx, 1e300, oracle_fm.PENCIL_THIN_SVD)
+    print(f"thin-SVD pencil, t = inf: oracle {n_ref}, device {n_dev}, matched {matched}; unmatched e.g. {unmatched[:8]}")
+    assert n_ref > 1500, n_ref
+    assert abs(n_dev - n_ref) <= max(3, 0.01 * n_ref), (n_dev, n_ref)
+    assert matched >= n_ref - max(3, 0.02 * n_ref), (matched, n_ref, unmatched[:5])
+    alive = got[np.isfinite(got[:, :, 0, 0])]
+    assert (alive[:, 2, 2] == 1.0).all()
+    t = fundamentalmatrix.RANSAC_T_PERSPECTIVE * 2048.0
+    idx = _samples(m, 7, 6000, seed=5)
+    n_ref, n_dev, matched, unmatched, got = _compare_generator_with_oracle(gpu_device, oracle_fm, m, idx, t, oracle_fm.PENCIL_THIN_SVD)
+    print(f"thin-SVD pencil, reference t: oracle {n_ref}, device {n_dev}, matched {matched}; unmatched e.g. {unmatched[:8]}")
+    assert n_ref >= 20, n_ref                      # ~0.6 % of the roots fit their own sample
+    assert abs(n_dev - n_ref) <= max(2, 0.05 * n_ref), (n_dev, n_ref)
+    assert matched >= n_ref - max(2, 0.05 * n_ref), (matched, n_ref, unmatched[:5])
+    # the two modes are different algorithms: the null-space pencil's survivors are many
+    fundamentalmatrix.set_pencil(gpu_device, fundamentalmatrix.PENCIL_NULL_SPACE)
+    try:
+        other = fundamentalmatrix.perspective_models_device(gpu_device, m, idx[:500], t)
+    finally:
+        fundamentalmatrix.set_pencil(gpu_device, fundamentalmatrix.PENCIL_THIN_SVD)
+    assert np.isfinite(other[:, :, 0, 0]).sum() > 2 * np.isfinite(got[:500, :, 0, 0]).sum()
 
 
 def test_find_ransac_one_call_both_models(gpu_device, oracle, oracle_fm):
