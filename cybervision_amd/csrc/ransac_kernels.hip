@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -261,9 +262,14 @@ __host__ __device__ inline void singular3(const double (&M)[9], double (&sv)[3])
 // the workspace lives in registers), 0 = n_obs at run time (the refit over the inliers).  Same statements either way.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed" // (the unroll requests are for N = 7; N = 0 has run-time trip counts)
+// `event` (optional, for callers that continue the root elsewhere): with a `budget` below the reference's 1000 trips the
+// function returns false with *event = LM_EVENT_BUDGET when the budget is used up, and with stop_on_accept it returns
+// false with *event = LM_EVENT_ACCEPTED at the first ACCEPTED step (before that step's linearisation); q is unspecified then.
+constexpr int LM_EVENT_BUDGET = 2, LM_EVENT_ACCEPTED = 3;
 template <int N>
 __host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt(double (&q)[7], const Obs *obs, uint32_t n_obs, double *r,
-                                                             double *r_new, double *J, int budget = 1000, bool *exhausted = nullptr)
+                                                             double *r_new, double *J, int budget = 1000, int *event = nullptr,
+                                                             bool stop_on_accept = false)
 {
     const uint32_t n = N > 0 ? (uint32_t)N : n_obs;
     double M[9], g[7];
@@ -300,8 +306,8 @@ __host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt(double (&q)[7], con
     mu *= 1e-3;
     double nu = 2.0;
     for (int iteration = 0; iteration < 1000; iteration++) {
-        if (iteration >= budget) { // (a caller that continues the root elsewhere; the reference's cap is the 1000 above)
-            *exhausted = true;
+        if (iteration >= budget) { // (the reference's cap is the 1000 above)
+            *event = LM_EVENT_BUDGET;
             return false;
         }
         double A[49];
@@ -327,6 +333,10 @@ __host__ __device__ CVHIP_LM_INLINE bool levenberg_marquardt(double (&q)[7], con
         for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + g[j];
         const double rho = (before - after) / long_dot(step, 1, damped, 1, 7);
         if (rho > 0.0) {
+            if (stop_on_accept) {
+                *event = LM_EVENT_ACCEPTED;
+                return false;
+            }
             const bool converged = sqrt(before) - sqrt(after) < 0.0 * sqrt(before);
 #pragma unroll
             for (uint32_t i = 0; i < n; i++) r[i] = r_new[i];
@@ -371,15 +381,15 @@ __host__ __device__ inline bool converged_at_start7(const double (&q)[7], const 
     return fabs(m) <= 1e-12;
 }
 
-// validate_f's call (n = 7), run by the device's thread-per-root LM kernel for the roots that fail the start test (it
-// re-evaluates the start: same values).  -> 1 = Ok, 0 = Err, 2 = still running after `budget` iterations (q is then
-// unspecified: the caller restarts the root elsewhere)
-__host__ __device__ CVHIP_LM_INLINE int levenberg_marquardt7(double (&q)[7], const Obs *obs, int budget)
+// validate_f's call (n = 7), run by the device's thread-per-root LM kernels for the roots that fail the start test (it
+// re-evaluates the start: same values).  -> 1 = Ok, 0 = Err, LM_EVENT_BUDGET = still running after `budget` iterations,
+// LM_EVENT_ACCEPTED = (stop_on_accept) a step was accepted (q is then unspecified: the caller restarts the root elsewhere)
+__host__ __device__ CVHIP_LM_INLINE int levenberg_marquardt7(double (&q)[7], const Obs *obs, int budget, bool stop_on_accept = false)
 {
     double r[7], r_new[7], J[49];
-    bool exhausted = false;
-    const bool ok = levenberg_marquardt<7>(q, obs, 7, r, r_new, J, budget, &exhausted);
-    return exhausted ? 2 : (ok ? 1 : 0);
+    int event = 0;
+    const bool ok = levenberg_marquardt<7>(q, obs, 7, r, r_new, J, budget, &event, stop_on_accept);
+    return event ? event : (ok ? 1 : 0);
 }
 
 // optimize_perspective_f (:391-426): F (normalised by F[2][2]) -> out, false = None
@@ -1749,6 +1759,11 @@ __device__ bool perspective_root_accept(const double (&q)[7], const uint4 (&sm)[
 // neither kernel has to hold the other's registers (as one kernel this was 512 VGPRs + 1 KB of scratch per thread at
 // one wave per SIMD: 1.4 ms per round).  Three hypothesis slots per sample; slots without a surviving root hold NaN.
 // sample_idx != nullptr: the caller's samples (7 match indices each) instead of choose_inliers (test hook).
+struct LateRoot { // a root whose loop outlasted the thread kernel's budget, for the call-level list of the batched rounds
+    uint4 sm[7];
+    double q[7];
+};
+
 struct PerspPencil {
     uint4 sm[7];
     double n1[9], n2[9], roots[3];
@@ -1868,23 +1883,27 @@ __global__ __launch_bounds__(64) void ransac_perspective_root_kernel(const Persp
 // element, with lm's own functions (same operations, same order: the values are the scalar loop's), and made
 // wave-uniform through LDS; the short serial parts (the 7x7 LU, norms, control flow) run redundantly in every lane on
 // uniform values.  J'J is kept (in LDS) while steps are rejected (J does not change then).  ~1 500 cycles per iteration.
+// late_list == nullptr: the roots of `queue` (slots of F, samples in `pencils`); otherwise the call's list of stragglers
+// (LateRoot entries behind late_list + 64; late_list[0] = count, clamped to late_cap), results to F[entry].
 __global__ __launch_bounds__(64) void ransac_perspective_lm_kernel(const PerspPencil *__restrict__ pencils, double t,
-                                                                    double *__restrict__ F, const uint32_t *__restrict__ queue)
+                                                                    double *__restrict__ F, const uint32_t *__restrict__ queue,
+                                                                    const uint32_t *__restrict__ late_list, uint32_t late_cap)
 {
     __shared__ double sJ[49], sA[49], sV[8];
-    const uint32_t lane = threadIdx.x, n_queued = queue[0];
+    const uint32_t lane = threadIdx.x, n_queued = late_list ? min(late_list[0], late_cap) : queue[0];
     const int k = lane < 49u ? (int)(lane / 7u) : 6, e = lane < 49u ? (int)(lane % 7u) : 6; // this lane's observation / parameter
+    const LateRoot *const roots = reinterpret_cast<const LateRoot *>(late_list + 64);
     for (uint32_t item = blockIdx.x; item < n_queued; item += gridDim.x) {
-        const uint32_t g = queue[1u + item];
-        const PerspPencil &pc = pencils[g / 3u];
+        const uint32_t g = late_list ? item : queue[1u + item];
+        const uint4 *const smp = late_list ? roots[item].sm : pencils[g / 3u].sm;
         uint4 sm[7];
 #pragma unroll
-        for (int kk = 0; kk < 7; kk++) sm[kk] = pc.sm[kk];
-        const uint4 mine = pc.sm[k];
+        for (int kk = 0; kk < 7; kk++) sm[kk] = smp[kk];
+        const uint4 mine = smp[k];
         const lm::Obs ob = lm::make_obs(mine.x, mine.y, mine.z, mine.w);
         double q[7], r[7], gv[7], M[9];
 #pragma unroll
-        for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
+        for (int j = 0; j < 7; j++) q[j] = late_list ? roots[item].q[j] : F[(size_t)g * 9 + j];
         __syncthreads(); // (the previous item's LDS reads are done)
 
         // r = residuals at `at` (lane (k, 0) computes r_k), uniform in every lane afterwards
@@ -2034,31 +2053,131 @@ __global__ __launch_bounds__(64) void ransac_perspective_lm_thread_kernel(const 
     for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = ok ? f[i] : nan;
 }
 
-// queue, late: 1 + 3 H words each
+// The thin-SVD pencil's roots fall into two classes (census on config 5's matches, scripts/lm_census.py; oracle: the same):
+// ~2/3 never have a step accepted - 0-7 trips until the step vanishes - and ~1/3 accept step after step (8-25 trips, mean
+// 14).  One launch over all of them runs every wave for its slowest lane: ~25 trips for a mean of ~6.  So the classes are
+// separated: ransac_lm_start_kernel runs the scalar loop for EVERY queued root but leaves it at the first accepted step
+// (the first class finishes here, in uniform short loops; the others go onto a second queue), ransac_lm_run_kernel runs
+// the second class, densely packed, from its start.  Same function, same values (lm::levenberg_marquardt<7>).
+// (Tried and dropped: the loop cut into a linearise and an iterate piece with the root's state - q, r, J'r, J'J - in
+// memory between them and the sample re-read per observation, at two waves per SIMD instead of one: bit-identical, but
+// every trip then waited for ~10 dependent loads: 19 ns per root against 8.)
+__global__ __launch_bounds__(64) void ransac_lm_start_kernel(const PerspPencil *__restrict__ pencils, double t, double *__restrict__ F,
+                                                              const uint32_t *__restrict__ queue, uint32_t *__restrict__ next)
+{
+    const uint32_t item = blockIdx.x * 64 + threadIdx.x;
+    if (item >= queue[0]) return;
+    const uint32_t g = queue[1u + item];
+    const PerspPencil &pc = pencils[g / 3u];
+    uint4 sm[7];
+    lm::Obs obs[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        sm[i] = pc.sm[i];
+        obs[i] = lm::make_obs(sm[i].x, sm[i].y, sm[i].z, sm[i].w);
+    }
+    double q[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
+    const int status = lm::levenberg_marquardt7(q, obs, 1000, true);
+    if (status == lm::LM_EVENT_ACCEPTED) {
+        next[1u + atomicAdd(&next[0], 1u)] = g; // (F[g] still holds the start parameters)
+        return;
+    }
+    double f[9];
+    const bool ok = status == 1 && perspective_root_accept(q, sm, t, f);
+    const double nan = __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = ok ? f[i] : nan;
+}
+
+// late_list != nullptr: a straggler is copied (sample, start parameters) onto the CALL's list - late_list[0] = count,
+// entries behind 256 bytes, late_cap of them at most (beyond: counted, not stored; the host fails the call) - and its slot
+// holds NaN; otherwise its slot goes onto the batch's `late` queue.
+__global__ __launch_bounds__(64) void ransac_lm_run_kernel(const PerspPencil *__restrict__ pencils, double t, double *__restrict__ F,
+                                                            const uint32_t *__restrict__ queue, uint32_t *__restrict__ late, int budget,
+                                                            uint32_t *__restrict__ late_list, uint32_t late_cap)
+{
+    const uint32_t item = blockIdx.x * 64 + threadIdx.x;
+    if (item >= queue[0]) return;
+    const uint32_t g = queue[1u + item];
+    const PerspPencil &pc = pencils[g / 3u];
+    uint4 sm[7];
+    lm::Obs obs[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        sm[i] = pc.sm[i];
+        obs[i] = lm::make_obs(sm[i].x, sm[i].y, sm[i].z, sm[i].w);
+    }
+    double q[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
+    const int status = lm::levenberg_marquardt7(q, obs, budget);
+    const double nan = __builtin_nan("");
+    if (status == lm::LM_EVENT_BUDGET) {
+        if (!late_list) {
+            late[1u + atomicAdd(&late[0], 1u)] = g; // (F[g] still holds the start parameters)
+            return;
+        }
+        const uint32_t at = atomicAdd(&late_list[0], 1u);
+        if (at < late_cap) {
+            LateRoot &lr = reinterpret_cast<LateRoot *>(late_list + 64)[at];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                lr.sm[i] = sm[i];
+                lr.q[i] = F[(size_t)g * 9 + i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = nan;
+        return;
+    }
+    double f[9];
+    const bool ok = status == 1 && perspective_root_accept(q, sm, t, f);
+#pragma unroll
+    for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = ok ? f[i] : nan;
+}
+
+// queues: LM_QUEUES lists of 1 + 3 H words, `stride` words apart (the root kernel's queue, the roots whose first step was
+// accepted, the stragglers)
 // H samples: `per_round` each of the rounds round0, round0 + 1, ... (H a multiple of per_round)
-constexpr int LM_THREAD_BUDGET = 48; // iterations a root gets in the thread-per-root kernel (thin-SVD pencil: 99.9 % need < 25)
-static void launch_generate_perspective(int pencil, const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round0,
+constexpr int LM_THREAD_BUDGET = 48; // iterations a root gets in a thread-per-root kernel (thin-SVD pencil: the oracle's longest of 3 000 was 30)
+constexpr int LM_QUEUES = 3;
+static void launch_generate_perspective(int pencil, bool lm_pipeline, const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round0,
                                         uint32_t per_round, uint32_t H, const uint32_t *sample_idx, PerspPencil *pencils,
-                                        uint32_t *queue, uint32_t *late, double *d_F, hipStream_t s)
+                                        uint32_t *queues, size_t stride, uint32_t *late_list, uint32_t late_cap, double *d_F, hipStream_t s)
 {
     const bool thin = pencil == CVHIP_PENCIL_THIN_SVD;
+    const dim3 roots_grid((3 * H + 63) / 64);
+    const PerspPencil *pc = pencils;
+    uint32_t *queue = queues;
     (void)hipMemsetAsync(queue, 0, sizeof(uint32_t), s);
     if (thin) {
-        (void)hipMemsetAsync(late, 0, sizeof(uint32_t), s);
+        for (int k = 1; k < LM_QUEUES; k++) (void)hipMemsetAsync(queues + k * stride, 0, sizeof(uint32_t), s);
         hipLaunchKernelGGL(ransac_perspective_pencil_kernel<true>, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round0, per_round, H,
                            sample_idx, pencils);
     } else {
         hipLaunchKernelGGL(ransac_perspective_pencil_kernel<false>, dim3((H + 63) / 64), dim3(64), 0, s, m4, limit, seed, round0, per_round, H,
                            sample_idx, pencils);
     }
-    hipLaunchKernelGGL(ransac_perspective_root_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, H, t,
-                       d_F, queue);
-    if (thin) // every queued root on a lane of its own; the stragglers go on to the wave-per-root kernel below
-        hipLaunchKernelGGL(ransac_perspective_lm_thread_kernel, dim3((3 * H + 63) / 64), dim3(64), 0, s, (const PerspPencil *)pencils, t, d_F,
-                           (const uint32_t *)queue, late, LM_THREAD_BUDGET);
+    hipLaunchKernelGGL(ransac_perspective_root_kernel, roots_grid, dim3(64), 0, s, pc, H, t, d_F, queue);
+    if (thin) {
+        // every queued root runs least_squares: the start and the rejected steps after it for all of them, the roots that
+        // have a step accepted densely packed after that, the stragglers on a wave of their own
+        uint32_t *late = queues + (LM_QUEUES - 1) * stride;
+        if (lm_pipeline) {
+            hipLaunchKernelGGL(ransac_lm_start_kernel, roots_grid, dim3(64), 0, s, pc, t, d_F, (const uint32_t *)queue, queue + stride);
+            hipLaunchKernelGGL(ransac_lm_run_kernel, roots_grid, dim3(64), 0, s, pc, t, d_F, (const uint32_t *)(queue + stride), late, LM_THREAD_BUDGET,
+                               late_list, late_cap);
+            if (late_list) return; // (the call's stragglers run once, behind its last batch: ransac_rounds)
+        } else {
+            hipLaunchKernelGGL(ransac_perspective_lm_thread_kernel, roots_grid, dim3(64), 0, s, pc, t, d_F, (const uint32_t *)queue, late, LM_THREAD_BUDGET);
+        }
+        queue = late;
+    }
     // a persistent grid of waves strides over the queue (one wave per queued root)
-    hipLaunchKernelGGL(ransac_perspective_lm_kernel, dim3(std::min<uint32_t>(3 * H, 4096u)), dim3(64), 0, s, (const PerspPencil *)pencils, t, d_F,
-                       (const uint32_t *)(thin ? late : queue));
+    hipLaunchKernelGGL(ransac_perspective_lm_kernel, dim3(std::min<uint32_t>(3 * H, 4096u)), dim3(64), 0, s, pc, t, d_F, (const uint32_t *)queue,
+                       (const uint32_t *)nullptr, 0u);
 }
 
 // Ord for RansacIterationResult (fundamentalmatrix.rs:623-649)
@@ -2374,6 +2493,12 @@ struct RansacListener {
     void *user = nullptr;
     uint64_t max_matches = 0;
     bool wants_counts() const { return matches != nullptr; }
+    void count_seen(uint64_t best_count) // max_matches.fetch_max(count), :126-131
+    {
+        if (!matches) return;
+        max_matches = std::max(max_matches, best_count);
+        matches(user, max_matches);
+    }
     void round_done(uint32_t finished, uint32_t total, bool have_count, uint64_t best_count)
     {
         if (progress) progress(user, (float)finished / (float)total); // counter / ransac_k, :119-123
@@ -2474,10 +2599,22 @@ hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double
 // work on too few threads for the chip - 50 000 samples are 782 waves - so two rounds in one launch take what one
 // takes), into one of GEN_DEPTH buffers: the batch being scored and the two that may be generated ahead of it.
 constexpr uint32_t GEN_BATCH = 4, GEN_DEPTH = 3;
+// The call's stragglers (thin-SVD pencil; batched scoring only): roots whose Levenberg-Marquardt loop outlasts the thread
+// kernels' budget - a handful per 100 000, but each keeps ONE wave busy for up to 1000 trips (~5 ms), and run inside their
+// batch they held that batch's generator stream, and with it every later batch, for that long (2.6 of the 6.7 ms a batch
+// spent on its stream).  They are collected on one list per call (sample + start parameters), run ONCE behind the last
+// batch's generation - under the scoring of the last batches - and their hypotheses are scored as one more small round.
+// Ord's maximum does not depend on when a hypothesis is met (see below); among EQUAL ones a straggler counts as met last.
+struct LateStage {
+    uint32_t *list = nullptr; // [0] = count; LateRoot entries behind 256 bytes
+    uint32_t cap = 0;
+    double *F = nullptr;      // cap x 9: the stragglers' hypotheses (NaN = none)
+    std::function<void(hipStream_t)> run;
+};
 template <typename Generate>
 int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, uint32_t N, uint32_t rounds, uint32_t per_round, uint32_t slots,
                   double t, uint32_t min_count, uint32_t early_exit, double *out_F, uint32_t *out_inlier_count,
-                  uint8_t *out_inlier_mask, const char *what, bool refit_tail, Generate generate)
+                  uint8_t *out_inlier_mask, const char *what, bool refit_tail, Generate generate, const LateStage *late = nullptr)
 {
     hipStream_t s = dev->d.stream;
     const uint32_t H = per_round * slots;
@@ -2499,6 +2636,8 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     uint32_t *d_live = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_live, GEN_DEPTH * GEN_BATCH * live_words + 3 + TIED_CAP);
     uint32_t *const d_tied = d_live + GEN_DEPTH * GEN_BATCH * live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
+    uint32_t *d_late_live = nullptr; // the stragglers' round: live list [cap], its length, the compaction's scratch
+    if (e == hipSuccess && late) e = mem.alloc(&d_late_live, (size_t)late->cap + 1 + (late->cap + 1023) / 1024);
     float4 *d_mf = nullptr; // the counting kernel's copy of the list (f32 planes + u32), reordered as the best hypothesis changes
     uint32_t *d_mo = nullptr;
     if (e == hipSuccess) e = mem.alloc(&d_mf, ransac_padded(N));
@@ -2508,6 +2647,8 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = hipMemsetAsync(d_cand, 0, 2 * sizeof(uint32_t), s);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && late) e = hipMemsetAsync(late->list, 0, sizeof(uint32_t), s);
+    if (e == hipSuccess && late) e = hipMemsetAsync(late->F, 0xFF, (size_t)late->cap * 9 * sizeof(double), s); // (all ones: NaN)
     // (the generators need the list and nothing else of what follows: their event goes right behind the upload)
     if (e == hipSuccess && !dev->d.rq.uploaded) e = hipEventCreateWithFlags(&dev->d.rq.uploaded, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(dev->d.rq.uploaded, s);
@@ -2518,6 +2659,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = hipMemcpyAsync(d_mo, d_m, (size_t)N * 16, hipMemcpyDeviceToDevice, s);
     RansacBest h_best;
     std::memset(&h_best, 0, sizeof(h_best));
+    uint32_t late_count = 0;
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
     // Two streams, GEN_DEPTH hypothesis buffers of GEN_BATCH rounds: the batches after the one being SCORED (the handle's
     // stream; the best-so-far chain lives there) are GENERATED on the side streams (samples depend on the seed and the
@@ -2536,7 +2678,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // the other or as ONE round of GEN_BATCH x H slots (a later hypothesis replaces the best only if strictly better, the
     // smaller slot stays among equals - and round q's slots follow round q - 1's): half as many counting launches and
     // round ends (the latter are single-workgroup kernels: 20 - 70 us of an otherwise idle chip each).
-    const bool score_batches = !may_exit_early && !g_listener.wants_counts();
+    const bool score_batches = !may_exit_early;
     constexpr uint32_t GEN_STREAMS = 2;
     static_assert(GEN_DEPTH <= sizeof(Device::RansacQueues::ready) / sizeof(hipEvent_t), "Device holds two side streams and RansacQueues' events");
     Device::RansacQueues &rq = dev->d.rq; // (kept on the handle: created once)
@@ -2557,7 +2699,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         hipError_t ge = wait_scored ? hipStreamWaitEvent(gs, scored[b], 0) : hipSuccess;
         if (ge != hipSuccess) return ge;
         double *F_unit = d_F + (size_t)b * GEN_BATCH * H * 9;
-        generate(m4, r0, nr, (int)b, F_unit, gs);
+        generate(m4, r0, nr, (int)b, F_unit, gs, score_batches && late != nullptr);
         // the rounds' live lists, right behind their generation: three small launches less on the scoring chain
         if (score_batches) {
             uint32_t *lv = d_live + (size_t)b * GEN_BATCH * live_words;
@@ -2619,24 +2761,81 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
                 next_gen++;
             }
         };
+        // The call's stragglers (LateStage): once the last batch is on its generator stream, the list is complete when both
+        // generator streams have drained; the wave-per-root kernel goes onto stream 0 behind them, under the scoring of the
+        // last batches.
+        bool late_enqueued = false;
+        const auto enqueue_late = [&]() {
+            if (!late || late_enqueued || next_gen < units || e != hipSuccess) return;
+            late_enqueued = true;
+            for (uint32_t k = 1; k < GEN_STREAMS && e == hipSuccess; k++) {
+                if (!rq.ready[6]) e = hipEventCreateWithFlags(&rq.ready[6], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(rq.ready[6], g[k]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(g[0], rq.ready[6], 0);
+            }
+            if (e != hipSuccess) return;
+            late->run(g[0]);
+            launch_ransac_live(late->F, late->cap, d_late_live, d_late_live + late->cap, d_late_live + late->cap + 1, g[0]);
+            if (!rq.ready[7]) e = hipEventCreateWithFlags(&rq.ready[7], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(rq.ready[7], g[0]);
+        };
+        // A report_matches listener (fundamentalmatrix.rs:126-131: the running maximum of the inlier counts, shown in the
+        // progress bar's message, reconstruction.rs:859-863) gets its count per scored BATCH: the best count goes to
+        // page-locked memory behind the batch's pick, an event marks it, and the host reports what has arrived whenever it
+        // is here anyway - no synchronisation per round, the batched path survives the listener the reference always passes.
+        uint32_t *h_counts = nullptr;
+        std::vector<hipEvent_t> count_ev;
+        uint32_t counts_reported = 0;
+        if (g_listener.wants_counts()) {
+            h_counts = static_cast<uint32_t *>(pinned_scratch(dev->d, (size_t)units * sizeof(uint32_t)));
+            if (!h_counts) e = hipErrorOutOfMemory;
+            count_ev.resize(units, nullptr);
+            for (uint32_t u = 0; u < units && e == hipSuccess; u++) e = hipEventCreateWithFlags(&count_ev[u], hipEventDisableTiming);
+        }
+        uint32_t scored_order = 0; // batches in the order they were scored: their counts are reported in that order
+        const auto report_counts = [&](bool wait) {
+            while (h_counts && counts_reported < scored_order && e == hipSuccess) {
+                const hipError_t qe = wait ? hipEventSynchronize(count_ev[counts_reported]) : hipEventQuery(count_ev[counts_reported]);
+                if (qe == hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                if (qe != hipSuccess) {
+                    e = qe;
+                    break;
+                }
+                g_listener.count_seen(h_counts[counts_reported]);
+                counts_reported++;
+            }
+        };
         top_up();
+        enqueue_late();
         while (e == hipSuccess && n_done < units) {
             // the oldest batch that is ready; with several to choose from and none ready yet, the host polls (the
-            // scoring chain has nothing to run then anyway); a single candidate is simply enqueued behind its event
+            // scoring chain has nothing to run then anyway); a single candidate is simply enqueued behind its event.
+            // The polling is bounded: after POLL_LIMIT_MS without a ready batch the oldest pending one is enqueued behind
+            // its event - in-order waiting on the stream, no spinning - so a generator that is stuck (not failed: a device
+            // error ends the loop through `e`) cannot keep a host core busy without bound.
+            constexpr double POLL_LIMIT_MS = 50.0;
             uint32_t pick = 0xFFFFFFFFu, pending = 0, oldest = 0xFFFFFFFFu;
             for (uint32_t u = 0; u < next_gen; u++)
                 if (!done[u]) {
                     pending++;
                     if (oldest == 0xFFFFFFFFu) oldest = u;
                 }
+            const auto poll_start = std::chrono::steady_clock::now();
             while (pick == 0xFFFFFFFFu && e == hipSuccess) {
                 for (uint32_t u = 0; u < next_gen && pick == 0xFFFFFFFFu; u++)
                     if (!done[u] && generated((int)u)) pick = u;
                 if (pick == 0xFFFFFFFFu && pending == 1 && next_gen == units) pick = oldest; // the last one: nothing to decide
+                if (pick == 0xFFFFFFFFu && (dev->d.ransac_in_order || std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - poll_start).count() > POLL_LIMIT_MS))
+                    pick = oldest; // (cvhip_ransac_set_in_order: the test hook that forces this branch)
                 if (pick == 0xFFFFFFFFu) {
                     std::this_thread::yield();
+                    report_counts(false);
                     const uint32_t before = next_gen;
                     top_up(); // (a generator stream may have come free)
+                    enqueue_late();
                     pending += next_gen - before;
                     if (oldest == 0xFFFFFFFFu && next_gen > before) oldest = before;
                 }
@@ -2662,14 +2861,36 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipEventRecord(scored[b], s);
+            if (e == hipSuccess && h_counts) { // (matches_count of an invalid best is 0)
+                e = hipMemcpyAsync(&h_counts[scored_order], &d_best->matches_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipEventRecord(count_ev[scored_order], s);
+            }
+            scored_order++;
             done[pick] = 1;
             n_done++;
             for (uint32_t q = 0; q < nr; q++)
                 if (++reported < rounds) g_listener.round_done(reported, rounds, false, 0); // position only: enqueued, not finished
+            report_counts(false);
             top_up();
+            enqueue_late();
+        }
+        enqueue_late();
+        if (e == hipSuccess && late && late_enqueued) { // the stragglers' hypotheses: one more round, met last
+            e = hipStreamWaitEvent(s, rq.ready[7], 0);
+            launch_ransac_score_round(late->F, late->cap, d_m, d_mo, d_mf, N, t, d_late_live, d_late_live + late->cap, d_tied, d_coord_max, true, true,
+                                      min_count, d_best, d_cnt, d_err, s, d_cand, 0u, 0xFFFFFFFFu);
+            hipLaunchKernelGGL(ransac_round_tied_list_kernel, dim3(1), dim3(1024), 0, s, d_cand, d_tied);
+            hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, late->F, m4, N, t, (const uint32_t *)d_tied, d_best, d_err);
+            hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, late->F, m4, N, t, (const uint32_t *)nullptr, d_err, min_count,
+                               (const uint32_t *)d_tied, d_best, reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf), rounds * H);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&late_count, late->list, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(&h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
+        report_counts(true);
+        for (hipEvent_t ev : count_ev)
+            if (ev) (void)hipEventDestroy(ev);
         if (e == hipSuccess) g_listener.round_done(rounds, rounds, true, h_best.valid ? h_best.matches_count : 0);
     }
     for (uint32_t u = 0; !score_batches && u + 1 < GEN_DEPTH && u < units && e == hipSuccess; u++) e = generate_unit(u);
@@ -2723,7 +2944,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     for (uint32_t k = 0; k < GEN_STREAMS; k++)
         if (g[k]) (void)hipStreamSynchronize(g[k]); // rounds generated ahead of an early exit, or of an error
     int rc = CVHIP_OK;
-    if (e == hipSuccess && !h_best.valid) rc = fail(CVHIP_ERR_NO_MODEL, "No reliable matches found"); // :145
+    if (e == hipSuccess && late && late_count > late->cap)
+        rc = fail(CVHIP_ERR_DEVICE, std::string(what) + ": more Levenberg-Marquardt stragglers than the call's list holds");
+    if (e == hipSuccess && rc == CVHIP_OK && !h_best.valid) rc = fail(CVHIP_ERR_NO_MODEL, "No reliable matches found"); // :145
     if (e == hipSuccess && rc == CVHIP_OK) {
         std::memcpy(out_F, h_best.f, sizeof(h_best.f));
         hipLaunchKernelGGL(ransac_inlier_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d_best, m4, N, t, d_mask);
@@ -2765,21 +2988,39 @@ int ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, d
     const uint32_t limit = std::min(N, TOP_INLIERS);
     if (rounds == 0 || rounds > RANSAC_K / CHECK_INTERVAL) rounds = RANSAC_K / CHECK_INTERVAL;
     // per generated round (GEN_DEPTH buffers, see ransac_rounds): the pencils, then the LM queue
-    const size_t queue_bytes = ((1 + 3 * GEN_BATCH * (size_t)CHECK_INTERVAL) * sizeof(uint32_t) + 255) / 256 * 256; // every root can be queued
-    const size_t gen_bytes = GEN_BATCH * (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + 2 * queue_bytes;
     const int pencil = dev->d.ransac_pencil;
+    const size_t batch_roots = 3 * GEN_BATCH * (size_t)CHECK_INTERVAL;
+    const size_t queue_bytes = ((1 + batch_roots) * sizeof(uint32_t) + 255) / 256 * 256; // every root can be queued
+    const size_t gen_bytes = (GEN_BATCH * (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + 255) / 256 * 256 + LM_QUEUES * queue_bytes;
     DevAllocs mem(dev->d);
     char *d_gen = nullptr;
     CVHIP_TRY_HIP(mem.alloc(&d_gen, GEN_DEPTH * gen_bytes));
-    const int rc = ransac_rounds(dev, mem, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F,
-                                 out_inlier_count, out_inlier_mask, "ransac_perspective", refit_tail,
-                                 [&](const uint4 *m4, uint32_t round0, uint32_t n_rounds, int buffer, double *d_F, hipStream_t s) {
-                                     PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
-                                     char *queues = (char *)(pencils + GEN_BATCH * (size_t)CHECK_INTERVAL);
-                                     launch_generate_perspective(pencil, m4, limit, t, (unsigned long long)seed, round0, CHECK_INTERVAL,
-                                                                 n_rounds * CHECK_INTERVAL, nullptr, pencils, (uint32_t *)queues,
-                                                                 (uint32_t *)(queues + queue_bytes), d_F, s);
-                                 });
+    // the call's stragglers (LateStage): thin-SVD pencil with the two-pass LM only
+    constexpr uint32_t LATE_CAP = 65536; // (config 5 produces ~150 per call; beyond the cap the call fails, it never drops one)
+    LateStage late;
+    const bool use_late = pencil == CVHIP_PENCIL_THIN_SVD && dev->d.ransac_lm_pipeline != 0;
+    if (use_late) {
+        char *d_late = nullptr;
+        CVHIP_TRY_HIP(mem.alloc(&d_late, 256 + (size_t)LATE_CAP * sizeof(LateRoot)));
+        CVHIP_TRY_HIP(mem.alloc(&late.F, (size_t)LATE_CAP * 9));
+        late.list = reinterpret_cast<uint32_t *>(d_late);
+        late.cap = LATE_CAP;
+        late.run = [&late, t](hipStream_t s) {
+            hipLaunchKernelGGL(ransac_perspective_lm_kernel, dim3(4096), dim3(64), 0, s, (const PerspPencil *)nullptr, t, late.F, (const uint32_t *)nullptr,
+                               (const uint32_t *)late.list, late.cap);
+        };
+    }
+    const int rc = ransac_rounds(
+        dev, mem, matches, N, rounds, CHECK_INTERVAL, 3, t, RANSAC_D + RANSAC_N, EARLY_EXIT, out_F, out_inlier_count, out_inlier_mask,
+        "ransac_perspective", refit_tail,
+        [&](const uint4 *m4, uint32_t round0, uint32_t n_rounds, int buffer, double *d_F, hipStream_t s, bool defer_late) {
+            PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
+            char *queues = (char *)pencils + (GEN_BATCH * (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + 255) / 256 * 256;
+            launch_generate_perspective(pencil, dev->d.ransac_lm_pipeline != 0, m4, limit, t, (unsigned long long)seed, round0, CHECK_INTERVAL,
+                                        n_rounds * CHECK_INTERVAL, nullptr, pencils, (uint32_t *)queues, queue_bytes / sizeof(uint32_t),
+                                        defer_late ? late.list : nullptr, late.cap, d_F, s);
+        },
+        use_late ? &late : nullptr);
     return rc;
 }
 } // namespace
@@ -2789,6 +3030,20 @@ extern "C" int cvhip_ransac_set_pencil(cvhip_device *dev, int pencil)
     if (!dev) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_pencil: null device");
     if (pencil != CVHIP_PENCIL_THIN_SVD && pencil != CVHIP_PENCIL_NULL_SPACE) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_pencil: unknown mode");
     dev->d.ransac_pencil = pencil;
+    return CVHIP_OK;
+}
+
+extern "C" int cvhip_ransac_set_in_order(cvhip_device *dev, int enable)
+{
+    if (!dev) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_in_order: null device");
+    dev->d.ransac_in_order = enable ? 1 : 0;
+    return CVHIP_OK;
+}
+
+extern "C" int cvhip_ransac_set_lm_pipeline(cvhip_device *dev, int enable)
+{
+    if (!dev) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_lm_pipeline: null device");
+    dev->d.ransac_lm_pipeline = enable ? 1 : 0;
     return CVHIP_OK;
 }
 
@@ -2840,12 +3095,22 @@ extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t
                                                  [](const uint4 *, const uint32_t *, double *, hipStream_t) {});
     CVHIP_TRY_HIP(hipSetDevice(dev->d.ordinal));
     PerspPencil *d_pencils = nullptr;
-    CVHIP_TRY_HIP(hipMalloc(&d_pencils, (size_t)B * sizeof(PerspPencil) + 2 * (1 + 3 * (size_t)B) * sizeof(uint32_t)));
-    uint32_t *d_queue = (uint32_t *)(d_pencils + B), *d_late = d_queue + 1 + 3 * (size_t)B;
+    const size_t stride = (1 + 3 * (size_t)B + 63) / 64 * 64; // words per queue
+    const size_t pencil_bytes = ((size_t)B * sizeof(PerspPencil) + 255) / 256 * 256;
+    CVHIP_TRY_HIP(hipMalloc(&d_pencils, pencil_bytes + LM_QUEUES * stride * sizeof(uint32_t)));
+    uint32_t *d_queue = (uint32_t *)((char *)d_pencils + pencil_bytes);
     const int pencil = dev->d.ransac_pencil;
     const int rc = models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
                                      [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
-                                         launch_generate_perspective(pencil, m4, N, t, 0ull, 0u, B, B, idx, d_pencils, d_queue, d_late, d_F, s);
+                                         launch_generate_perspective(pencil, dev->d.ransac_lm_pipeline != 0, m4, N, t, 0ull, 0u, B, B, idx, d_pencils, d_queue, stride, nullptr, 0u, d_F, s);
+                                         if (getenv("CVHIP_LM_CENSUS")) { // (diagnostic: how many roots each stage of the LM funnel received)
+                                             uint32_t n[LM_QUEUES] = {};
+                                             for (int k = 0; k < LM_QUEUES; k++) (void)hipMemcpyAsync(&n[k], d_queue + k * stride, 4, hipMemcpyDeviceToHost, s);
+                                             (void)hipStreamSynchronize(s);
+                                             fprintf(stderr, "[cvhip] LM census (%u samples): queued", B);
+                                             for (int k = 0; k < LM_QUEUES; k++) fprintf(stderr, " %u", n[k]);
+                                             fprintf(stderr, "\n");
+                                         }
                                      });
     (void)hipFree(d_pencils); // (models_of_samples has synchronised the stream)
     return rc;

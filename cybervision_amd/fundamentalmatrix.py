@@ -24,6 +24,16 @@ def set_pencil(device, pencil: int):
     _lib.check(_lib.lib().cvhip_ransac_set_pencil(device.handle, int(pencil)), "cvhip_ransac_set_pencil")
 
 
+def set_lm_pipeline(device, enable: bool):
+    """cvhip_ransac_set_lm_pipeline (test hook): validate_f's LM as two kernels (default) or as the scalar loop."""
+    _lib.check(_lib.lib().cvhip_ransac_set_lm_pipeline(device.handle, int(bool(enable))), "cvhip_ransac_set_lm_pipeline")
+
+
+def set_in_order(device, enable: bool):
+    """cvhip_ransac_set_in_order (test hook): score the batches of rounds in order behind their events, without polling."""
+    _lib.check(_lib.lib().cvhip_ransac_set_in_order(device.handle, int(bool(enable))), "cvhip_ransac_set_in_order")
+
+
 class ProjectionMode(IntEnum):  # fundamentalmatrix.rs:35-39
     Affine = 0
     Perspective = 1

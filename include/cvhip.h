@@ -369,6 +369,14 @@ int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, 
 #define CVHIP_PENCIL_THIN_SVD 0
 #define CVHIP_PENCIL_NULL_SPACE 1
 int cvhip_ransac_set_pencil(cvhip_device *dev, int pencil);
+/* Test hook: with the thin-SVD pencil validate_f's least_squares runs as two kernels (linearise / iterate while steps are
+ * rejected; enable = 1, default) or as the scalar loop itself, one thread per root (0).  Same values, bit for bit. */
+int cvhip_ransac_set_lm_pipeline(cvhip_device *dev, int enable);
+/* Test hook of the round scheduler: batches of rounds are normally scored as their generators finish (the host polls
+ * their events, for at most 50 ms per decision); enable = 1 takes the branch that polling falls back to - the oldest
+ * pending batch is enqueued behind its event, in order, no polling.  Same result (Ord's maximum does not depend on the
+ * order; equal hypotheses are settled by their position in iteration order). */
+int cvhip_ransac_set_in_order(cvhip_device *dev, int enable);
 
 /* Perspective RANSAC on the device — FundamentalMatrix::new(Perspective, max_dimension).find_ransac
  * (fundamentalmatrix.rs:72-147, 155-229, 289-389): per sample the 7-point model (the pencil's basis as

@@ -412,7 +412,17 @@ def test_device_reference_pencil_matches_thin_svd_rows_per_sample(gpu_device, or
     idx = _samples(m, 7, 6000, seed=5)
     n_ref, n_dev, matched, unmatched, got = _compare_generator_with_oracle(gpu_device, oracle_fm, m, idx, t, oracle_fm.PENCIL_THIN_SVD)
     print(f"thin-SVD pencil, reference t: oracle {n_ref}, device {n_dev}, matched {matched}; unmatched e.g. {unmatched[:8]}")
-    assert n_ref >= 20, n_ref                      # ~0.6 % of the roots fit their own sample
+    # the two-kernel form of the loop gives the scalar loop's values, bit for bit (NaN slots included)
+    fundamentalmatrix.set_lm_pipeline(gpu_device, False)
+    try:
+        scalar = fundamentalmatrix.perspective_models_device(gpu_device, m, idx, t)
+        scalar_inf = fundamentalmatrix.perspective_models_device(gpu_device, m, idx[:1500], 1e300)
+    finally:
+        fundamentalmatrix.set_lm_pipeline(gpu_device, True)
+    assert (scalar.view(np.uint64) == got.view(np.uint64)).all()
+    piped_inf = fundamentalmatrix.perspective_models_device(gpu_device, m, idx[:1500], 1e300)
+    assert (scalar_inf.view(np.uint64) == piped_inf.view(np.uint64)).all() and np.isfinite(piped_inf[:, :, 0, 0]).sum() > 1500
+    assert n_ref >= 20, n_ref                      # a few per cent of the roots fit their own sample
     assert abs(n_dev - n_ref) <= max(2, 0.05 * n_ref), (n_dev, n_ref)
     assert matched >= n_ref - max(2, 0.05 * n_ref), (matched, n_ref, unmatched[:5])
     # the two modes are different algorithms: the null-space pencil's survivors are many
@@ -622,12 +632,55 @@ def test_progress_listeners_of_orb_and_ransac(gpu_device):
     F0, _, mask0 = fmx.find_ransac(gpu_device, m, seed=3)
     assert (F == F0).all() and (mask == mask0).all()
     assert len(pl.status) == 20 and pl.status == sorted(pl.status) and pl.status[-1] == 1.0  # 20 rounds, no early exit
-    assert len(pl.matches) == 20 and pl.matches == sorted(pl.matches) and 0.9 * truth.sum() < pl.matches[-1] <= len(m)
+    # the early exit cannot fire (4000 matches < 50 000): the rounds are scored in batches of four, the listener gets the
+    # running maximum once per scored batch (five) and once more with the final result
+    assert len(pl.matches) == 6 and pl.matches == sorted(pl.matches) and 0.9 * truth.sum() < pl.matches[-1] <= len(m)
+    assert pl.matches[-1] >= mask0.sum() * 0.9  # (the last count is the winner's before the refit)
     ma, truth_a, _ = affine_matches()
     pl = Listener()
     fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Affine, 2000.0).find_ransac(gpu_device, ma, seed=7, progress_listener=pl)
     assert 1 <= len(pl.status) <= 20 and pl.status == sorted(pl.status)   # early exit above 1000 inliers (:135-141)
     assert pl.matches == sorted(pl.matches) and pl.matches[-1] > 1000
+
+
+def test_ransac_scheduler_paths_agree(gpu_device):
+    """The round scheduler of the perspective loop (ransac_rounds): batches scored as their generators finish (the host
+    polls, bounded), in order behind their events (the branch the bounded polling falls back to, forced through
+    cvhip_ransac_set_in_order), and with the reference's listener attached (fundamentalmatrix.rs:112-142,
+    reconstruction.rs:510-518 always passes one) - the same matrix and mask every way, for both pencils."""
+    import cases
+
+    class Listener:
+        def __init__(self):
+            self.status, self.matches = [], []
+
+        def report_status(self, p):
+            self.status.append(p)
+
+        def report_matches(self, c):
+            self.matches.append(c)
+
+    m, truth, _, _ = cases.perspective_matches(n=6000, outlier_frac=0.4, seed=21)
+    fmx = fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Perspective, 2048.0)
+    for pencil in (fundamentalmatrix.PENCIL_THIN_SVD, fundamentalmatrix.PENCIL_NULL_SPACE):
+        fundamentalmatrix.set_pencil(gpu_device, pencil)
+        try:
+            F0, _, mask0 = fmx.find_ransac(gpu_device, m, seed=9)
+            fundamentalmatrix.set_in_order(gpu_device, True)
+            try:
+                F1, _, mask1 = fmx.find_ransac(gpu_device, m, seed=9)
+                pl = Listener()
+                F2, _, mask2 = fmx.find_ransac(gpu_device, m, seed=9, progress_listener=pl)
+            finally:
+                fundamentalmatrix.set_in_order(gpu_device, False)
+            pl3 = Listener()
+            F3, _, mask3 = fmx.find_ransac(gpu_device, m, seed=9, progress_listener=pl3)
+        finally:
+            fundamentalmatrix.set_pencil(gpu_device, fundamentalmatrix.PENCIL_THIN_SVD)
+        for F, mask in ((F1, mask1), (F2, mask2), (F3, mask3)):
+            assert (F.view(np.uint64) == F0.view(np.uint64)).all() and (mask == mask0).all(), pencil
+        assert len(pl.matches) == 6 and len(pl3.matches) == 6 and pl.matches[-1] == pl3.matches[-1]
+        assert (mask0 & truth).sum() > 0.9 * truth.sum(), (pencil, (mask0 & truth).sum(), truth.sum())
 
 
 def test_orb_batch_equals_single_extractions(gpu_device, oracle):
