@@ -124,7 +124,7 @@ def valu_profile(world):
             "cycles_per_valu_instr": big.get("cycles_per_valu_instr")}
 
 
-def measure_sfm3(size, steps, warmup, dev=None, pencil=0):
+def measure_sfm3(size, steps, warmup, dev=None, pencil=0, listener=True):
     """BASELINE config 5 ("3-image perspective SFM: ORB + RANSAC F-matrix on GPU + pairwise dense correlation"):
     three synthetic size^2 perspective views, resident in HBM as u8 pyramids; one step = per-level ORB on the three
     images, 3 x matcher (threshold 48), 3 x perspective find_ransac (device RANSAC + LM refit), 3 x dense correlation
@@ -153,7 +153,7 @@ def measure_sfm3(size, steps, warmup, dev=None, pencil=0):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             acc = {}
-        res = reconstruction.reconstruct_pairs(dev, pyr, ProjectionMode.Perspective, seed=5, borrow=True)
+        res = reconstruction.reconstruct_pairs(dev, pyr, ProjectionMode.Perspective, seed=5, borrow=True, listener=listener)
         for k, v in res["timings_ms"].items():
             acc[k] = acc.get(k, 0.0) + v
     torch.cuda.synchronize()
@@ -167,7 +167,8 @@ def measure_sfm3(size, steps, warmup, dev=None, pencil=0):
     if own_dev:
         dev.close()
     stage_ms = {k: round(v / steps, 3) for k, v in acc.items()}
-    return {"pencil": "thin_svd_rows_5_6 (reference)" if pencil == 0 else "null_space (textbook)", "size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
+    return {"pencil": "thin_svd_rows_5_6 (reference)" if pencil == 0 else "null_space (textbook)",
+            "ransac_listener": "report_status + report_matches attached (reconstruction.rs:510-518)" if listener else "none", "size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
             "dense_mpixels_per_s": round(n_pairs * size * size / 1e6 / (stage_ms["dense"] / 1e3), 2),
             "whole_pipeline_mpixels_per_s": round(3 * size * size / 1e6 / (dt / steps), 2),
             "keypoints": [int(len(k[0])) for k in res["keypoints"]], "matches": matches, "ransac_inliers": inliers,
@@ -417,7 +418,7 @@ def main():
     pc.set_profiling(0, False)
 
     extras = world == 1 and sim is None and not args.no_extras
-    readback = geometry_sweep = sfm3 = None
+    readback = geometry_sweep = sfm3 = boundary_path = None
     if extras:
         # ---- t_dense INCLUDING the final readback of the forward grid into host memory
         # (GpuContext::complete_process lands in a host Grid, gpu/mod.rs:210-216).  Page-locked destinations.
@@ -465,6 +466,58 @@ def main():
                             "transfer of pair i under the search of pair i+1 (cvhip_ctx_set_async_readback)"}
         del host
 
+        # ---- The reference's real call modes.  PointCorrelations::correlate_images issues FOUR
+        # backend calls per level (correlation/mod.rs:217-245: correlate_images fwd, rev with the images exchanged,
+        # cross_check_filter fwd, rev) with HOST level images (`Grid<u8>`, gpu/mod.rs:218-274), and complete_process lands
+        # in host memory (gpu/mod.rs:210-216) - the sequence INTEGRATION.md binds.  Timed here, per pair, clock stopped when
+        # the forward grid is in host memory (pageable numpy arrays on both sides, like Rust's Vec):
+        #   four_call_host    the four calls per level on host images, complete() to host
+        #   level_call_host   cvhip_correlate_level (the optional fused call) on host images, complete() to host
+        #   four_call_device  the four calls per level on the HBM-resident pyramid, grid left in HBM (the headline's
+        #                     workload through the reference's call sequence)
+        hp1, hp2 = [p.cpu().numpy() for p in d1], [p.cpu().numpy() for p in d2]
+        hxy, hcorr = np.empty((H, W, 2), dtype=np.int32), np.empty((H, W), dtype=np.float32)
+        pcb = correlation.PointCorrelations(dev, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
+        pcb.set_fuse_level_calls(True)  # (what the binding's GpuContext::new does: INTEGRATION.md)
+
+        def pair(p1, p2, fused, to_host):
+            pcb.first_pass = True
+            for j in range(steps + 1):
+                k = steps - j
+                pcb.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=fused)
+            if to_host:
+                pcb.complete(out_xy=hxy, out_corr=hcorr)
+            else:
+                pcb.complete(out_xy=out_xy, out_corr=out_corr)
+
+        def timed_pairs(p1, p2, fused, to_host, n=5):
+            pair(p1, p2, fused, to_host)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                pair(p1, p2, fused, to_host)
+            fence()
+            return (time.perf_counter() - t1) * 1e3 / n
+
+        want_xy = out_xy.cpu().numpy()
+        ms_4h = timed_pairs(hp1, hp2, False, True)
+        same_b = bool((hxy == want_xy).all())
+        ms_lh = timed_pairs(hp1, hp2, True, True)
+        same_b = same_b and bool((hxy == want_xy).all())
+        pcb.set_borrow_inputs(True)
+        pcb.set_stats_ahead(True)
+        ms_4d = timed_pairs(d1, d2, False, False)
+        same_b = same_b and bool(torch.equal(out_xy.cpu(), torch.from_numpy(want_xy)))
+        pcb.close()
+        boundary_path = {"four_call_host_ms": round(ms_4h, 3), "four_call_host_mpixels_per_s": round(W * H / 1e6 / (ms_4h / 1e3), 1),
+                         "level_call_host_ms": round(ms_lh, 3), "four_call_device_ms": round(ms_4d, 3),
+                         "four_call_device_vs_headline": round(ms_4d / (dt * 1e3 / args.steps), 3),
+                         "results_equal_headline": same_b,
+                         "note": "per level cvhip_correlate_images x2 + cvhip_cross_check_filter x2 (correlation/mod.rs:217-245), then "
+                                 "cvhip_complete; host = pageable level images in, pageable grid out (44 MB up, 201 MB down per pair); "
+                                 "device = the headline's resident pyramid and resident grid through the same four calls"}
+        del hp1, hp2, hxy, hcorr
+
     pc.close()
     pc = None
     if extras:
@@ -508,7 +561,14 @@ def main():
         d1 = d2 = None
         torch.cuda.empty_cache()
         # ---- BASELINE config 5, per-stage times
-        sfm3 = measure_sfm3(2048 if W == 4096 else max(W // 2, 256), 5, 1, dev=dev)
+        # the library's defaults - the reference's own 7-point pencil, both RANSAC thunks attached - and, beside it, the
+        # stage times of the textbook pencil and of a call without a listener (what rounds 2-3 quoted)
+        sfm_size = 2048 if W == 4096 else max(W // 2, 256)
+        sfm3 = measure_sfm3(sfm_size, 5, 1, dev=dev)
+        alt = measure_sfm3(sfm_size, 3, 1, dev=dev, pencil=1)
+        bare = measure_sfm3(sfm_size, 3, 1, dev=dev, listener=False)
+        sfm3["other_modes"] = {"null_space_pencil_with_listener": {"ms_per_step": alt["ms_per_step"], "stage_ms": alt["stage_ms"], "ransac_inliers": alt["ransac_inliers"]},
+                               "reference_pencil_without_listener": {"ms_per_step": bare["ms_per_step"], "stage_ms": bare["stage_ms"]}}
 
     sharded_ok = None
     if world > 1:
@@ -613,7 +673,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} u8 value-noise pair, integer disparity field |d|<={max(W // 64, 1)}px, "
                                    f"affine parameter set (11x11 window, 5 stripes, thr 0.6), F = horizontal epipolar "
-                                   f"lines, {steps + 1} pyramid levels (2x2 box), fwd+rev search + 2 cross-checks per "
+                                   f"lines, {steps + 1} pyramid levels (2x2 box), fwd+rev search + 2 cross-checks (the last level: 1 - its reverse filter only feeds the grid complete() drops) per "
                                    f"level + complete() to HBM",
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"row bands x{world} + halo, no exchange between levels, one RCCL all-gather of the final grid"
@@ -658,6 +718,8 @@ def main():
             result["geometry_sweep"] = geometry_sweep
         if sfm3 is not None:
             result["sfm3"] = sfm3
+        if boundary_path is not None:
+            result["boundary_path"] = boundary_path
         if world > 1:
             result["collective"] = collective
             result["ranks_seen"] = ranks_seen

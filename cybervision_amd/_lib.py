@@ -67,6 +67,7 @@ SIGNATURES = {
     "cvhip_ctx_set_async_readback": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_search_version": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_borrow_inputs": (C.c_int, [_vp, C.c_int]),
+    "cvhip_ctx_set_fuse_level_calls": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_stats_ahead": (C.c_int, [_vp, C.c_int]),
     "cvhip_downsample_box": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
     "cvhip_resize_lanczos3": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),

@@ -215,6 +215,11 @@ class PointCorrelations:
         the last pixel of each and keeps them unchanged until the call's work has completed (include/cvhip.h)."""
         _lib.check(_lib.lib().cvhip_ctx_set_borrow_inputs(self._h, int(borrow)), "cvhip_ctx_set_borrow_inputs")
 
+    def set_fuse_level_calls(self, enable: bool):
+        """cvhip_ctx_set_fuse_level_calls: the four per-pass calls of a level arrive in the reference's order
+        (correlate_images(fused=False) issues exactly that) and are executed as one level call (include/cvhip.h)."""
+        _lib.check(_lib.lib().cvhip_ctx_set_fuse_level_calls(self._h, int(enable)), "cvhip_ctx_set_fuse_level_calls")
+
     def set_stats_ahead(self, ahead: bool):
         """cvhip_ctx_set_stats_ahead: the window statistics of borrowed level images run on a side stream, under the
         coarse levels' search (the images must be complete in memory when they are passed)."""

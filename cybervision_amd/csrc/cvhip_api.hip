@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 namespace cvhip {
 
@@ -190,18 +191,147 @@ static size_t stats_level_offset(size_t max_px, int k)
 }
 static size_t stats_pool_elems(size_t max_px) { return stats_level_offset(max_px, 16) + 64; }
 
-static int stage_images(cvhip_ctx *c, const uint8_t *img1, size_t n1, const uint8_t *img2, size_t n2, hipStream_t s)
+// The staged image of level k lives at its own offset of the per-image pool, like the statistics: a host image of level
+// k - 1 can then be uploaded (copy stream) while level k is still being searched.
+static size_t img_level_offset(size_t max_px, int k)
+{
+    size_t off = 0;
+    for (int j = 0; j < k; j++) off += ((max_px >> (2 * j)) + IMG_PAD + 255) & ~(size_t)255;
+    return off;
+}
+static size_t img_pool_bytes(size_t max_px) { return img_level_offset(max_px, 16) + IMG_PAD + 256; }
+
+// The handle's copy stream (uploads of host level images, readback of host-destination grids) and its events.
+static int copy_stream_reserve(Device &d)
+{
+    auto &rb = d.rb;
+    if (rb.stream) return CVHIP_OK;
+    CVHIP_TRY_HIP(hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+    CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.ready, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.done[i], hipEventDisableTiming));
+    return CVHIP_OK;
+}
+
+// `bytes` of the handle's page-locked upload ring, free of any transfer that may still read them; *done is the event the
+// caller records behind its transfer.  nullptr: no ring to be had (out of page-locked memory) - the caller copies straight
+// from the pageable source and synchronises.
+static uint8_t *upload_ring_take(Device &d, size_t bytes, size_t want_cap, hipEvent_t *done)
+{
+    Device::UploadRing &up = d.up;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (up.cap < bytes || (!up.base && want_cap)) {
+        for (auto &c : up.busy) {
+            (void)hipEventSynchronize(c.done);
+            up.spare.push_back(c.done);
+        }
+        up.busy.clear();
+        if (up.base) (void)hipHostFree(up.base);
+        up.base = nullptr;
+        up.cap = up.head = 0;
+        const size_t cap = std::max(std::max(bytes, want_cap), (size_t)32 << 20);
+        void *p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        up.base = static_cast<uint8_t *>(p);
+        up.cap = cap;
+    }
+    if (up.head + bytes > up.cap) up.head = 0;
+    const size_t begin = up.head, end = up.head + bytes;
+    for (size_t i = 0; i < up.busy.size();) {
+        if (up.busy[i].begin < end && begin < up.busy[i].end) {
+            (void)hipEventSynchronize(up.busy[i].done); // (normally long done: the ring holds two pairs' worth)
+            up.spare.push_back(up.busy[i].done);
+            up.busy.erase(up.busy.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
+    hipEvent_t ev = nullptr;
+    if (!up.spare.empty()) {
+        ev = up.spare.back();
+        up.spare.pop_back();
+    } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    up.busy.push_back({begin, end, ev});
+    up.head = end;
+    *done = ev;
+    return up.base + begin;
+}
+
+// (a 16.8 MB level image is ~1.7 ms of one core's memcpy: four threads take their quarter each)
+static void host_copy(uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    constexpr size_t PER_THREAD = (size_t)2 << 20;
+    const size_t parts = std::min<size_t>(4, bytes / PER_THREAD);
+    if (parts < 2) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::thread th[3];
+    const size_t chunk = ((bytes / parts) + 4095) & ~(size_t)4095;
+    for (size_t i = 1; i < parts; i++) {
+        const size_t off = i * chunk, len = std::min(chunk, bytes - std::min(bytes, off));
+        th[i - 1] = std::thread([=] { if (off < bytes) std::memcpy(dst + off, src + off, len); });
+    }
+    std::memcpy(dst, src, std::min(chunk, bytes));
+    for (size_t i = 1; i < parts; i++) th[i - 1].join();
+}
+
+// Level images of a call (transfer_in_images, gpu/mod.rs:274) -> c->cur_img[]:
+//  * a device image the caller has vouched for (cvhip_ctx_set_borrow_inputs) is used where it is;
+//  * another device image is copied into the level's area of the pool on the context's stream;
+//  * a HOST image goes through the handle's page-locked ring: copied out of the caller's buffer here (the buffer is free
+//    when this returns), transferred on the copy stream behind the last readers of the level's area, and the context's
+//    stream waits for the transfer - no host synchronisation, and the transfer of level k - 1 runs under level k's search.
+static int stage_images(cvhip_ctx *c, int k, const uint8_t *img1, size_t n1, const uint8_t *img2, size_t n2, hipStream_t s)
 {
     const uint8_t *src[2] = {img1, img2};
     const size_t n[2] = {n1, n2};
-    for (int d = 0; d < 2; d++) {
-        if (c->borrow_inputs && is_device_ptr(src[d])) {
-            c->cur_img[d] = src[d];
-        } else {
-            CVHIP_TRY(copy_in(c->img[d], src[d], n[d], s));
-            c->cur_img[d] = c->img[d];
+    Device &d = c->dev->d;
+    c->staged_from_pageable = false;
+    const size_t off = img_level_offset(c->max_px, k);
+    bool waited_readers = false;
+    for (int i = 0; i < 2; i++) {
+        if (is_device_ptr(src[i])) {
+            if (c->borrow_inputs) {
+                c->cur_img[i] = src[i];
+            } else {
+                CVHIP_TRY_HIP(hipMemcpyAsync(c->img[i] + off, src[i], n[i], hipMemcpyDeviceToDevice, s));
+                c->cur_img[i] = c->img[i] + off;
+            }
+            continue;
         }
+        c->cur_img[i] = c->img[i] + off;
+        hipEvent_t done = nullptr;
+        uint8_t *ring = nullptr;
+        if (copy_stream_reserve(d) == CVHIP_OK) ring = upload_ring_take(d, n[i], 6 * c->max_px, &done);
+        if (!ring) { // no ring: straight from the caller's pageable memory; the call synchronises before it returns
+            CVHIP_TRY_HIP(hipMemcpyAsync(c->img[i] + off, src[i], n[i], hipMemcpyHostToDevice, s));
+            c->staged_from_pageable = true;
+            continue;
+        }
+        host_copy(ring, src[i], n[i]);
+        if (!waited_readers && k < 16 && c->level_read[k]) {
+            CVHIP_TRY_HIP(hipStreamWaitEvent(d.rb.stream, c->level_read[k], 0));
+            waited_readers = true;
+        }
+        CVHIP_TRY_HIP(hipMemcpyAsync(c->img[i] + off, ring, n[i], hipMemcpyHostToDevice, d.rb.stream));
+        CVHIP_TRY_HIP(hipEventRecord(done, d.rb.stream));
+        CVHIP_TRY_HIP(hipStreamWaitEvent(s, done, 0));
     }
+    return CVHIP_OK;
+}
+
+// The level's staged images have their last readers enqueued: an upload into the same area (the next pair's) waits here.
+static int mark_level_read(cvhip_ctx *c, int k, hipStream_t s)
+{
+    if (k < 0 || k >= 16) return CVHIP_OK;
+    if (!c->level_read[k]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&c->level_read[k], hipEventDisableTiming));
+    CVHIP_TRY_HIP(hipEventRecord(c->level_read[k], s));
     return CVHIP_OK;
 }
 
@@ -494,6 +624,9 @@ static int check_level_args(const cvhip_ctx *ctx, const uint8_t *img1, uint32_t 
         return fail(CVHIP_ERR_UNSUPPORTED, "level dimension above 65535");
     if ((size_t)w1 * h1 > ctx->max_px || (size_t)w2 * h2 > ctx->max_px)
         return fail(CVHIP_ERR_INVALID, "level image larger than the context's full-resolution images");
+    // (the level's area of the image pool holds max_px / 4^k pixels: checked before anything is staged)
+    if ((size_t)w1 * h1 > (ctx->max_px >> (2 * *k)) || (size_t)w2 * h2 > (ctx->max_px >> (2 * *k)))
+        return fail(CVHIP_ERR_UNSUPPORTED, "level dims must be floor(full * scale) (reconstruction.rs:146-152)");
     return CVHIP_OK;
 }
 
@@ -522,6 +655,13 @@ void device_free(cvhip_device *dev)
             if (rb.done[i]) (void)hipEventDestroy(rb.done[i]);
         }
         if (rb.ready) (void)hipEventDestroy(rb.ready);
+        auto &up = dev->d.up; // (the copy stream has drained: no transfer reads the ring any more)
+        for (auto &c : up.busy) (void)hipEventDestroy(c.done);
+        for (hipEvent_t ev : up.spare) (void)hipEventDestroy(ev);
+        up.busy.clear();
+        up.spare.clear();
+        if (up.base) (void)hipHostFree(up.base);
+        up.base = nullptr;
         if (rb.stream) (void)hipStreamDestroy(rb.stream);
     }
     {
@@ -708,7 +848,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
         const size_t ge = grid_elems(c->dir[d].gw, c->dir[d].gh);
         for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc(&c->dir[d].cells[i], ge * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&c->dir[d].scores, ge * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&c->img[d], c->max_px + IMG_PAD);
+        if (e == hipSuccess) e = hipMalloc(&c->img[d], img_pool_bytes(c->max_px));
         if (e == hipSuccess) e = hipMalloc(&c->istats[d], stats_pool_elems(c->max_px) * sizeof(uint2));
     }
     if (!reused) {
@@ -721,7 +861,7 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     }
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
-        e = hipMemsetAsync(c->img[d], 0, c->max_px + IMG_PAD, dev->d.stream);
+        e = hipMemsetAsync(c->img[d], 0, img_pool_bytes(c->max_px), dev->d.stream);
     if (e != hipSuccess) {
         free_ctx_buffers(c);
         delete c;
@@ -736,143 +876,112 @@ void cvhip_ctx_destroy(cvhip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev->d.ordinal);
+    if (ctx->dev->d.rb.stream) (void)hipStreamSynchronize(ctx->dev->d.rb.stream); // (uploads into the image pool)
     (void)hipStreamSynchronize(ctx->dev->d.stream);
+    for (hipEvent_t &ev : ctx->level_read)
+        if (ev) (void)hipEventDestroy(ev);
     free_ctx_buffers(ctx, true); // the buffer set is parked on the device handle for the next pair
     delete ctx;
 }
 
-int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
-                           uint32_t w2, uint32_t h2, float scale, int first_pass, int dir,
-                           cvhip_progress_fn progress, void *user)
+// ---------------------------------------------------------------------------------------------------------------
+// One pyramid level = the four backend calls of PointCorrelations::correlate_images (correlation/mod.rs:217-245):
+// correlate_images forward, correlate_images reverse (images exchanged, F transposed), cross_check_filter forward,
+// cross_check_filter reverse.  The work of a level is cut into three pieces that cvhip_correlate_level runs back to
+// back and that the four per-pass calls run ONE BY ONE when the caller has promised the reference's call order
+// (cvhip_ctx_set_fuse_level_calls): level_begin (images in, window statistics), level_search (both search passes in
+// the same launches), level_cross (both cross-checks in one launch).  Without that promise the per-pass calls are
+// executed independently, each for itself, as before.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct LevelStats { // what level_begin leaves for the level's search launches
+    bool ahead = false;          // the statistics run on the side stream (cvhip_ctx_set_stats_ahead)
+    hipEvent_t done = nullptr;   // ... and this event marks them
+};
+
+// Images in (transfer_in_images, gpu/mod.rs:274) and the window statistics of both (compute_image_point_data,
+// mod.rs:632-694), in line or ahead on the side stream.
+int level_begin(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2, uint32_t w2, uint32_t h2, int k,
+                int first_pass, bool sharded, bool clear_work, LevelStats &ls)
 {
-    int k = 0;
-    CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
-    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
-    if (ctx->band_mode) {
-        // the plan is laid out over the forward direction's pyramid: dir 1 is called with the images swapped
-        const uint32_t fw = dir == 0 ? w1 : w2, fh = dir == 0 ? h1 : h2;
-        if (k > ctx->band_steps || (ctx->w1 >> k) != fw || (ctx->h1 >> k) != fh)
-            return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
-    }
-    CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
-    CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s)); // transfer_in_images, gpu/mod.rs:274
-    report(progress, user, dir, 0.02f);
-    {
-        uint32_t sr0 = 0, sr1 = std::max(h1, h2);
-        if (ctx->band_mode) {
-            sr0 = ctx->band[k].st[0];
-            sr1 = ctx->band[k].st[1];
+    CVHIP_TRY(stage_images(ctx, k, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s));
+    uint32_t sr0 = 0, sr1 = std::max(h1, h2);
+    if (ctx->band_mode) {
+        sr0 = ctx->band[k].st[0];
+        sr1 = ctx->band[k].st[1];
+    }
+    uint2 *const st0 = ctx->istats[0] + stats_level_offset(ctx->max_px, k), *const st1 = ctx->istats[1] + stats_level_offset(ctx->max_px, k);
+    bool stats_ahead = ctx->stats_ahead && ctx->time_kernels != 1 && !sharded && ctx->borrow_inputs &&
+                       is_device_ptr(img1) && is_device_ptr(img2) && k < 16;
+    if (stats_ahead && ctx->dev->d.sa.verdict == 0 && ctx->dev->d.sa.probe_recorded && first_pass) {
+        // the previous run's probe, if it has completed (never waits)
+        Device::StatsAhead &sa = ctx->dev->d.sa;
+        float lead_ms = 0.0f;
+        const hipError_t pe = hipEventElapsedTime(&lead_ms, sa.probe_side, sa.probe_main);
+        if (pe == hipSuccess) {
+            sa.verdict = lead_ms > 0.05f ? 1 : -1; // (overlapping: ~1 ms at 4096^2; in line: zero or negative)
+            sa.probe_recorded = false;
+        } else {
+            (void)hipGetLastError(); // hipErrorNotReady: ask again at the next run
         }
+    }
+    if (stats_ahead && ctx->dev->d.sa.verdict < 0) stats_ahead = false;
+    ls.ahead = stats_ahead;
+    ls.done = nullptr;
+    if (stats_ahead) {
+        // The statistics depend on the level's images only.  On a stream of their own they run while the main stream
+        // works through the coarse levels - a chain of ~40 small dependent launches that leaves the chip idle for
+        // ~0.4 ms of a 4096^2 pair - instead of 0.5 ms of full-chip work in line with it.
+        Device &d = ctx->dev->d;
+        hipStream_t side = nullptr;
+        CVHIP_TRY_HIP(aux_stream(d, 0, &side));
+        if (!d.sa.fence) CVHIP_TRY_HIP(hipEventCreateWithFlags(&d.sa.fence, hipEventDisableTiming));
+        if (!d.sa.done[k]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&d.sa.done[k], hipEventDisableTiming));
+        if (first_pass || !ctx->stats_ahead_fenced) {
+            // a new pyramid run: its side-stream work starts behind everything enqueued so far (the previous run's
+            // readers of these buffers among it), and its first level finds the work-list counts cleared
+            CVHIP_TRY_HIP(hipEventRecord(d.sa.fence, s));
+            CVHIP_TRY_HIP(hipStreamWaitEvent(side, d.sa.fence, 0));
+            CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 8 * sizeof(uint32_t), s));
+            ctx->stats_ahead_fenced = true;
+        }
+        // (only where the answer is unambiguous: a full-resolution level of a megapixel or more, several levels deep)
+        const bool probe = d.sa.verdict == 0 && !d.sa.probe_recorded && k == 0 && !first_pass && (size_t)w1 * h1 >= ((size_t)1 << 20);
+        if (probe) {
+            if (!d.sa.probe_side) CVHIP_TRY_HIP(hipEventCreate(&d.sa.probe_side));
+            if (!d.sa.probe_main) CVHIP_TRY_HIP(hipEventCreate(&d.sa.probe_main));
+            CVHIP_TRY_HIP(hipEventRecord(d.sa.probe_side, side)); // the full-resolution statistics start here ...
+            CVHIP_TRY_HIP(hipEventRecord(d.sa.probe_main, s));    // ... and the main stream gets here when level 1 is done
+            d.sa.probe_recorded = true;
+        }
+        // (48 KB of LDS ballast per workgroup: three of them per CU instead of eight.  A full-chip grid beside the
+        // coarse levels starved their small kernels - a 30 us box launch took the 370 us of the statistics kernel,
+        // stream priorities notwithstanding; at four per CU the chain still lost 0.17 ms; at two the statistics of the
+        // full-resolution level are not done when that level's turn comes: step 5.60 / 5.45 / 5.37 / 5.47 ms for
+        // 0 / 32 / 48 / 64 KB)
+        launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev, nullptr, side,
+                                 48u * 1024u);
+        CVHIP_TRY_HIP(hipEventRecord(d.sa.done[k], side));
+        ls.done = d.sa.done[k]; // (the search range does not read the statistics: the wait goes behind its launch)
+    } else {
+        ctx->stats_ahead_fenced = false;
+        // both images in one launch, which (clear_work) also clears the work-list counts of the level's two search passes
         CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-            launch_window_stats_pair(ctx->cur_img[0], w1, h1, ctx->istats[0] + stats_level_offset(ctx->max_px, k), ctx->cur_img[1], w2, h2,
-                                     ctx->istats[1] + stats_level_offset(ctx->max_px, k), sr0, sr1, ctx->min_stdev, nullptr, s);
+            launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev,
+                                     clear_work ? ctx->work : nullptr, s);
         }));
     }
-    report(progress, user, dir, 0.20f);
-    CVHIP_TRY(search_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, dir));
-    // Pageable host sources must not be reused by the caller before the copy has happened.
-    if (!is_device_ptr(img1) || !is_device_ptr(img2)) CVHIP_TRY_HIP(hipStreamSynchronize(s));
-    report(progress, user, dir, 1.0f);
     return CVHIP_OK;
 }
 
-int cvhip_cross_check_filter(cvhip_ctx *ctx, float scale, int dir)
+// Both search passes of the level (mod.rs:224-237), in the same launches, and - row-shard mode - the all-gathers.
+// (w1, h1) / (w2, h2): the FORWARD call's images.
+int level_search(cvhip_ctx *ctx, uint32_t w1, uint32_t h1, uint32_t w2, uint32_t h2, float scale, int k, int first_pass, bool sharded,
+                 const LevelStats &ls, cvhip_progress_fn progress, void *user)
 {
-    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
-    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
-    const int k = scale_to_k(scale);
-    if (k < 0) return fail(CVHIP_ERR_UNSUPPORTED, "scale must be 2^-k");
-    CVHIP_TRY(set_device(ctx->dev));
-    return cross_check_pass(ctx, k, dir);
-}
-
-int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
-                          uint32_t w2, uint32_t h2, float scale, int first_pass, cvhip_progress_fn progress,
-                          void *user)
-{
-    int k = 0;
-    CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
-    // Shard this level only if every rank gets a useful band; tiny levels are computed whole on
-    // every rank (identical results, no collective).  The rule depends on level dims only, so all
-    // ranks take the same branch.
-    const uint32_t den = ctx->shard_den, num = ctx->shard_num;
-    const bool sharded = !ctx->band_mode && den > 1 && std::min(h1, h2) / den >= 64;
-    if (sharded && !ctx->gather)
-        return fail(CVHIP_ERR_INVALID, "row-sharded context without an all-gather hook (cvhip_ctx_set_row_shard)");
-    if (ctx->band_mode && (k > ctx->band_steps || (ctx->w1 >> k) != w1 || (ctx->h1 >> k) != h1))
-        return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
-    CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
-    CVHIP_TRY(stage_images(ctx, img1, (size_t)w1 * h1, img2, (size_t)w2 * h2, s));
-    bool stats_ahead = false;
-    hipEvent_t stats_done = nullptr;
-    {
-        uint32_t sr0 = 0, sr1 = std::max(h1, h2);
-        if (ctx->band_mode) {
-            sr0 = ctx->band[k].st[0];
-            sr1 = ctx->band[k].st[1];
-        }
-        uint2 *const st0 = ctx->istats[0] + stats_level_offset(ctx->max_px, k), *const st1 = ctx->istats[1] + stats_level_offset(ctx->max_px, k);
-        stats_ahead = ctx->stats_ahead && ctx->time_kernels != 1 && !sharded && ctx->borrow_inputs &&
-                      is_device_ptr(img1) && is_device_ptr(img2) && k < 16;
-        if (stats_ahead && ctx->dev->d.sa.verdict == 0 && ctx->dev->d.sa.probe_recorded && first_pass) {
-            // the previous run's probe, if it has completed (never waits)
-            Device::StatsAhead &sa = ctx->dev->d.sa;
-            float lead_ms = 0.0f;
-            const hipError_t pe = hipEventElapsedTime(&lead_ms, sa.probe_side, sa.probe_main);
-            if (pe == hipSuccess) {
-                sa.verdict = lead_ms > 0.05f ? 1 : -1; // (overlapping: ~1 ms at 4096^2; in line: zero or negative)
-                sa.probe_recorded = false;
-            } else {
-                (void)hipGetLastError(); // hipErrorNotReady: ask again at the next run
-            }
-        }
-        if (stats_ahead && ctx->dev->d.sa.verdict < 0) stats_ahead = false;
-        if (stats_ahead) {
-            // The statistics depend on the level's images only.  On a stream of their own they run while the main stream
-            // works through the coarse levels - a chain of ~40 small dependent launches that leaves the chip idle for
-            // ~0.4 ms of a 4096^2 pair - instead of 0.5 ms of full-chip work in line with it.
-            Device &d = ctx->dev->d;
-            hipStream_t side = nullptr;
-            CVHIP_TRY_HIP(aux_stream(d, 0, &side));
-            if (!d.sa.fence) CVHIP_TRY_HIP(hipEventCreateWithFlags(&d.sa.fence, hipEventDisableTiming));
-            if (!d.sa.done[k]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&d.sa.done[k], hipEventDisableTiming));
-            if (first_pass || !ctx->stats_ahead_fenced) {
-                // a new pyramid run: its side-stream work starts behind everything enqueued so far (the previous run's
-                // readers of these buffers among it), and its first level finds the work-list counts cleared
-                CVHIP_TRY_HIP(hipEventRecord(d.sa.fence, s));
-                CVHIP_TRY_HIP(hipStreamWaitEvent(side, d.sa.fence, 0));
-                CVHIP_TRY_HIP(hipMemsetAsync(ctx->work, 0, 8 * sizeof(uint32_t), s));
-                ctx->stats_ahead_fenced = true;
-            }
-            // (only where the answer is unambiguous: a full-resolution level of a megapixel or more, several levels deep)
-            const bool probe = d.sa.verdict == 0 && !d.sa.probe_recorded && k == 0 && !first_pass && (size_t)w1 * h1 >= ((size_t)1 << 20);
-            if (probe) {
-                if (!d.sa.probe_side) CVHIP_TRY_HIP(hipEventCreate(&d.sa.probe_side));
-                if (!d.sa.probe_main) CVHIP_TRY_HIP(hipEventCreate(&d.sa.probe_main));
-                CVHIP_TRY_HIP(hipEventRecord(d.sa.probe_side, side)); // the full-resolution statistics start here ...
-                CVHIP_TRY_HIP(hipEventRecord(d.sa.probe_main, s));    // ... and the main stream gets here when level 1 is done
-                d.sa.probe_recorded = true;
-            }
-            // (48 KB of LDS ballast per workgroup: three of them per CU instead of eight.  A full-chip grid beside the
-            // coarse levels starved their small kernels - a 30 us box launch took the 370 us of the statistics kernel,
-            // stream priorities notwithstanding; at four per CU the chain still lost 0.17 ms; at two the statistics of the
-            // full-resolution level are not done when that level's turn comes: step 5.60 / 5.45 / 5.37 / 5.47 ms for
-            // 0 / 32 / 48 / 64 KB)
-            launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev, nullptr, side,
-                                     48u * 1024u);
-            CVHIP_TRY_HIP(hipEventRecord(d.sa.done[k], side));
-            stats_done = d.sa.done[k]; // (the search range does not read the statistics: the wait goes behind its launch)
-        } else {
-            ctx->stats_ahead_fenced = false;
-            // both images in one launch, which also clears the work-list counts of the level's two search passes
-            CVHIP_TRY(timed(ctx, cvhip_ctx::K_STATS, [&] {
-                launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev, ctx->work, s);
-            }));
-        }
-    }
-    report(progress, user, 0, 0.20f);
+    const uint32_t den = ctx->shard_den, num = ctx->shard_num;
     if (!sharded) {
         ctx->shard_num = 0;
         ctx->shard_den = 1;
@@ -902,11 +1011,12 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     PassPlan plans[2];
     int rc = plan_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, plans[0]);                 // mod.rs:224-230
     if (rc == CVHIP_OK) rc = plan_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, plans[1]); // mod.rs:231-237
-    if (rc == CVHIP_OK) rc = launch_passes(ctx, plans, 2, false, s, stats_done);
-    else if (stats_done) (void)hipStreamWaitEvent(s, stats_done, 0); // (the side stream's work stays ordered before whatever follows)
+    if (rc == CVHIP_OK) rc = launch_passes(ctx, plans, 2, false, s, ls.done);
+    else if (ls.done) (void)hipStreamWaitEvent(s, ls.done, 0); // (the side stream's work stays ordered before whatever follows)
     if (rc == CVHIP_OK) {
         commit_pass(ctx, plans[0]);
         commit_pass(ctx, plans[1]);
+        rc = mark_level_read(ctx, k, s);
     }
     report(progress, user, 0, 1.0f);
     if (rc == CVHIP_OK && sharded) rc = run_gather(0);
@@ -915,30 +1025,188 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     ctx->shard_den = den;
     CVHIP_TRY(rc);
     report(progress, user, 1, 1.0f);
-    // mod.rs:239-240: forward then reverse cross-check.  They commute and each depends only on the unfiltered
-    // other grid, so one launch runs both.
-    {
-        DirState &df = ctx->dir[0], &dr = ctx->dir[1];
-        if (!df.valid || !dr.valid || (int)df.k != k || (int)dr.k != k)
-            return fail(CVHIP_ERR_INVALID, "cross-check before both passes of the level ran");
-        uint32_t f0 = 0, f1 = df.lh, r0 = 0, r1 = dr.lh;
-        if (ctx->band_mode) {
-            f0 = std::min(ctx->band[k].cf[0], df.lh);
-            f1 = std::min(ctx->band[k].cf[1], df.lh);
-            r0 = std::min(ctx->band[k].cr[0], dr.lh);
-            r1 = std::min(ctx->band[k].cr[1], dr.lh);
-        } else if (k == 0) { // the reverse filter of the last level is deferred (cvhip_ctx::rev_cross_check_pending)
-            r0 = r1 = 0;
-            ctx->rev_cross_check_pending = true;
-        }
-        CVHIP_TRY(timed(ctx, cvhip_ctx::K_CROSS, [&] {
-            // (stats ahead: the next level's statistics kernel runs on another stream and cannot clear the work-list counts)
-            launch_cross_check_pair(df.cells[df.cur], dr.cells[dr.cur], df.lw, df.lh, dr.lw, dr.lh, f0, f1, r0, r1, s,
-                                    stats_ahead ? ctx->work : nullptr);
-        }));
-        CVHIP_TRY_HIP(hipGetLastError());
+    return CVHIP_OK;
+}
+
+// mod.rs:239-240: forward then reverse cross-check.  They commute and each depends only on the unfiltered other grid
+// (DESIGN.md section 5), so one launch runs both.
+int level_cross(cvhip_ctx *ctx, int k, bool stats_ahead)
+{
+    hipStream_t s = ctx->dev->d.stream;
+    DirState &df = ctx->dir[0], &dr = ctx->dir[1];
+    if (!df.valid || !dr.valid || (int)df.k != k || (int)dr.k != k)
+        return fail(CVHIP_ERR_INVALID, "cross-check before both passes of the level ran");
+    uint32_t f0 = 0, f1 = df.lh, r0 = 0, r1 = dr.lh;
+    if (ctx->band_mode) {
+        f0 = std::min(ctx->band[k].cf[0], df.lh);
+        f1 = std::min(ctx->band[k].cf[1], df.lh);
+        r0 = std::min(ctx->band[k].cr[0], dr.lh);
+        r1 = std::min(ctx->band[k].cr[1], dr.lh);
+    } else if (k == 0) { // the reverse filter of the last level is deferred (cvhip_ctx::rev_cross_check_pending)
+        r0 = r1 = 0;
+        ctx->rev_cross_check_pending = true;
     }
-    if (!is_device_ptr(img1) || !is_device_ptr(img2)) CVHIP_TRY_HIP(hipStreamSynchronize(s));
+    CVHIP_TRY(timed(ctx, cvhip_ctx::K_CROSS, [&] {
+        // (stats ahead: the next level's statistics kernel runs on another stream and cannot clear the work-list counts)
+        launch_cross_check_pair(df.cells[df.cur], dr.cells[dr.cur], df.lw, df.lh, dr.lw, dr.lh, f0, f1, r0, r1, s,
+                                stats_ahead ? ctx->work : nullptr);
+    }));
+    CVHIP_TRY_HIP(hipGetLastError());
+    return CVHIP_OK;
+}
+
+// Host images have been copied out of the caller's buffers when stage_images returns (page-locked ring), unless the ring
+// could not be had: then the pageable sources must not be reused by the caller before the copy has happened.
+int release_host_sources(cvhip_ctx *ctx, const uint8_t *img1, const uint8_t *img2)
+{
+    if (ctx->staged_from_pageable && (!is_device_ptr(img1) || !is_device_ptr(img2))) CVHIP_TRY_HIP(hipStreamSynchronize(ctx->dev->d.stream));
+    return CVHIP_OK;
+}
+} // namespace
+
+// What the fused-calls mode (cvhip_ctx_set_fuse_level_calls) has taken in but not yet executed: the forward search pass
+// waits for the reverse call of its level, the forward cross-check for the reverse one.  Every other entry point of the
+// context calls this first, so nothing ever observes the difference.
+extern "C++" int cvhip::flush_level_calls(cvhip_ctx *ctx)
+{
+    cvhip_ctx::LevelCalls &lc = ctx->calls;
+    const int stage = lc.stage;
+    lc.stage = cvhip_ctx::LevelCalls::NONE;
+    if (stage == cvhip_ctx::LevelCalls::FWD_TAKEN) {
+        // the reverse call did not come (or not for the same images): the forward pass alone, as the per-pass call runs it
+        CVHIP_TRY(set_device(ctx->dev));
+        hipStream_t s = ctx->dev->d.stream;
+        PassPlan plan;
+        int rc = plan_pass(ctx, 0, 1, lc.w1, lc.h1, lc.w2, lc.h2, lc.scale, lc.k, lc.first_pass, 0, plan);
+        if (rc == CVHIP_OK) rc = launch_passes(ctx, &plan, 1, true, s, lc.stats_done);
+        else if (lc.stats_done) (void)hipStreamWaitEvent(s, lc.stats_done, 0);
+        CVHIP_TRY(rc);
+        commit_pass(ctx, plan);
+        CVHIP_TRY(mark_level_read(ctx, lc.k, s));
+    } else if (stage == cvhip_ctx::LevelCalls::CROSS_FWD_TAKEN) {
+        CVHIP_TRY(set_device(ctx->dev));
+        CVHIP_TRY(cross_check_pass(ctx, lc.k, 0));
+    }
+    return CVHIP_OK;
+}
+
+int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
+                           uint32_t w2, uint32_t h2, float scale, int first_pass, int dir,
+                           cvhip_progress_fn progress, void *user)
+{
+    int k = 0;
+    CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
+    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
+    if (ctx->band_mode) {
+        // the plan is laid out over the forward direction's pyramid: dir 1 is called with the images swapped
+        const uint32_t fw = dir == 0 ? w1 : w2, fh = dir == 0 ? h1 : h2;
+        if (k > ctx->band_steps || (ctx->w1 >> k) != fw || (ctx->h1 >> k) != fh)
+            return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
+    }
+    CVHIP_TRY(set_device(ctx->dev));
+    hipStream_t s = ctx->dev->d.stream;
+    cvhip_ctx::LevelCalls &lc = ctx->calls;
+    const bool fuse = ctx->fuse_level_calls && ctx->shard_den <= 1;
+    if (fuse && dir == 1 && lc.stage == cvhip_ctx::LevelCalls::FWD_TAKEN && lc.k == k && lc.first_pass == first_pass && lc.img1 == img2 &&
+        lc.img2 == img1 && lc.w1 == w2 && lc.h1 == h2 && lc.w2 == w1 && lc.h2 == h1) {
+        // the reverse call of the level whose forward call was taken in: the images are staged (exchanged), their
+        // statistics computed - both search passes go out together, as in cvhip_correlate_level
+        lc.stage = cvhip_ctx::LevelCalls::NONE;
+        LevelStats ls;
+        ls.ahead = lc.stats_ahead;
+        ls.done = lc.stats_done;
+        report(progress, user, dir, 0.20f);
+        CVHIP_TRY(level_search(ctx, lc.w1, lc.h1, lc.w2, lc.h2, scale, k, first_pass, false, ls, nullptr, nullptr));
+        lc.stage = cvhip_ctx::LevelCalls::SEARCHED;
+        report(progress, user, dir, 1.0f);
+        return CVHIP_OK;
+    }
+    CVHIP_TRY(flush_level_calls(ctx));
+    LevelStats ls;
+    if (fuse && dir == 0) {
+        // the forward call of a level: images in, statistics - the search pass itself waits for the reverse call
+        CVHIP_TRY(level_begin(ctx, img1, w1, h1, img2, w2, h2, k, first_pass, false, true, ls));
+        lc.k = k;
+        lc.first_pass = first_pass;
+        lc.scale = scale;
+        lc.img1 = img1;
+        lc.img2 = img2;
+        lc.w1 = w1;
+        lc.h1 = h1;
+        lc.w2 = w2;
+        lc.h2 = h2;
+        lc.stats_ahead = ls.ahead;
+        lc.stats_done = ls.done;
+        lc.stage = cvhip_ctx::LevelCalls::FWD_TAKEN;
+        CVHIP_TRY(release_host_sources(ctx, img1, img2));
+        report(progress, user, dir, 1.0f);
+        return CVHIP_OK;
+    }
+    report(progress, user, dir, 0.02f);
+    CVHIP_TRY(level_begin(ctx, img1, w1, h1, img2, w2, h2, k, first_pass, false, false, ls));
+    report(progress, user, dir, 0.20f);
+    {
+        PassPlan plan;
+        int rc = plan_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, dir, plan);
+        if (rc == CVHIP_OK) rc = launch_passes(ctx, &plan, 1, true, s, ls.done);
+        else if (ls.done) (void)hipStreamWaitEvent(s, ls.done, 0);
+        CVHIP_TRY(rc);
+        commit_pass(ctx, plan);
+        CVHIP_TRY(mark_level_read(ctx, k, s));
+    }
+    CVHIP_TRY(release_host_sources(ctx, img1, img2));
+    report(progress, user, dir, 1.0f);
+    return CVHIP_OK;
+}
+
+int cvhip_cross_check_filter(cvhip_ctx *ctx, float scale, int dir)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
+    const int k = scale_to_k(scale);
+    if (k < 0) return fail(CVHIP_ERR_UNSUPPORTED, "scale must be 2^-k");
+    CVHIP_TRY(set_device(ctx->dev));
+    cvhip_ctx::LevelCalls &lc = ctx->calls;
+    if (ctx->fuse_level_calls && lc.k == k) {
+        if (dir == 0 && lc.stage == cvhip_ctx::LevelCalls::SEARCHED) { // waits for the reverse filter's call
+            DirState &df = ctx->dir[0], &dr = ctx->dir[1];
+            if (!df.valid || !dr.valid || (int)df.k != k || (int)dr.k != k)
+                return fail(CVHIP_ERR_INVALID, "cross_check_filter scale does not match the grids' current level");
+            lc.stage = cvhip_ctx::LevelCalls::CROSS_FWD_TAKEN;
+            return CVHIP_OK;
+        }
+        if (dir == 1 && lc.stage == cvhip_ctx::LevelCalls::CROSS_FWD_TAKEN) { // both filters of the level in one launch
+            lc.stage = cvhip_ctx::LevelCalls::NONE;
+            return level_cross(ctx, k, lc.stats_ahead);
+        }
+    }
+    CVHIP_TRY(flush_level_calls(ctx));
+    return cross_check_pass(ctx, k, dir);
+}
+
+int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, const uint8_t *img2,
+                          uint32_t w2, uint32_t h2, float scale, int first_pass, cvhip_progress_fn progress,
+                          void *user)
+{
+    int k = 0;
+    CVHIP_TRY(check_level_args(ctx, img1, w1, h1, img2, w2, h2, scale, &k));
+    // Shard this level only if every rank gets a useful band; tiny levels are computed whole on
+    // every rank (identical results, no collective).  The rule depends on level dims only, so all
+    // ranks take the same branch.
+    const uint32_t den = ctx->shard_den;
+    const bool sharded = !ctx->band_mode && den > 1 && std::min(h1, h2) / den >= 64;
+    if (sharded && !ctx->gather)
+        return fail(CVHIP_ERR_INVALID, "row-sharded context without an all-gather hook (cvhip_ctx_set_row_shard)");
+    if (ctx->band_mode && (k > ctx->band_steps || (ctx->w1 >> k) != w1 || (ctx->h1 >> k) != h1))
+        return fail(CVHIP_ERR_UNSUPPORTED, "band mode: level outside the planned pyramid");
+    CVHIP_TRY(set_device(ctx->dev));
+    CVHIP_TRY(flush_level_calls(ctx));
+    LevelStats ls;
+    CVHIP_TRY(level_begin(ctx, img1, w1, h1, img2, w2, h2, k, first_pass, sharded, true, ls));
+    report(progress, user, 0, 0.20f);
+    CVHIP_TRY(level_search(ctx, w1, h1, w2, h2, scale, k, first_pass, sharded, ls, progress, user));
+    CVHIP_TRY(level_cross(ctx, k, ls.ahead));
+    CVHIP_TRY(release_host_sources(ctx, img1, img2));
     return CVHIP_OK;
 }
 
@@ -946,11 +1214,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
 static int readback_reserve(Device &d, size_t n)
 {
     auto &rb = d.rb;
-    if (!rb.stream) {
-        CVHIP_TRY_HIP(hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
-        CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.ready, hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.done[i], hipEventDisableTiming));
-    }
+    CVHIP_TRY(copy_stream_reserve(d));
     if (n <= rb.cap_px) return CVHIP_OK;
     CVHIP_TRY_HIP(hipStreamSynchronize(rb.stream));
     for (int i = 0; i < 2; i++) {
@@ -974,6 +1238,7 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
     if (!ctx || !out_xy) return fail(CVHIP_ERR_INVALID, "null argument");
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
     CVHIP_TRY(set_device(ctx->dev));
+    CVHIP_TRY(flush_level_calls(ctx));
     if (dir == 1) CVHIP_TRY(flush_reverse_cross_check(ctx));
     hipStream_t s = ctx->dev->d.stream;
     DirState &ds = ctx->dir[dir];
@@ -1030,6 +1295,7 @@ int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr)
 int cvhip_triangulate_affine(cvhip_ctx *ctx, double *out_points3d, uint32_t *out_p2, uint64_t cap, uint64_t *out_n)
 {
     if (!ctx || !out_n) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(flush_level_calls(ctx));
     if (cap && !out_points3d) return fail(CVHIP_ERR_INVALID, "out_points3d is null");
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
@@ -1069,6 +1335,7 @@ int cvhip_triangulate_affine(cvhip_ctx *ctx, double *out_points3d, uint32_t *out
 int cvhip_ctx_set_row_shard(cvhip_ctx *ctx, uint32_t num, uint32_t den, cvhip_allgather_fn gather, void *user)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     if (den == 0 || den > 64 || num >= den) return fail(CVHIP_ERR_INVALID, "need 0 <= num < den <= 64");
     ctx->band_mode = false;
     ctx->shard_num = num;
@@ -1112,6 +1379,7 @@ static bool host_minor_offset_bound(const cvhip_ctx *c, int dir, int k, uint32_t
 int cvhip_ctx_set_row_band(cvhip_ctx *ctx, uint32_t num, uint32_t den)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     if (den == 0 || den > 64 || num >= den) return fail(CVHIP_ERR_INVALID, "need 0 <= num < den <= 64");
     ctx->band_mode = false;
     ctx->shard_num = num;
@@ -1193,6 +1461,7 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, void **scores, u
                          uint32_t *row1, uint32_t *rows_per_shard)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
     DirState &ds = ctx->dir[dir];
     if (!ds.valid) return fail(CVHIP_ERR_INVALID, "no level computed yet");
@@ -1215,6 +1484,7 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, void **scores, u
 int cvhip_ctx_set_profiling(cvhip_ctx *ctx, int time_kernels, int count_candidates)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     ctx->time_kernels = time_kernels == 2 ? 2 : (time_kernels ? 1 : 0);
     ctx->count_candidates = count_candidates ? 1 : 0;
     return CVHIP_OK;
@@ -1223,6 +1493,7 @@ int cvhip_ctx_set_profiling(cvhip_ctx *ctx, int time_kernels, int count_candidat
 int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms, uint64_t *candidates, int reset)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     CVHIP_TRY(set_device(ctx->dev));
     hipStream_t s = ctx->dev->d.stream;
     CVHIP_TRY_HIP(hipStreamSynchronize(s));
@@ -1246,6 +1517,7 @@ int cvhip_ctx_get_profile(cvhip_ctx *ctx, uint32_t *launches, double *search_ms,
 int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[7], uint32_t launches[7], int reset)
 {
     if (!ctx || !ms || !launches) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(flush_level_calls(ctx));
     CVHIP_TRY(set_device(ctx->dev));
     CVHIP_TRY_HIP(hipStreamSynchronize(ctx->dev->d.stream));
     CVHIP_TRY(resolve_events(ctx));
@@ -1263,6 +1535,7 @@ int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[7], uint32_t launches[7
 int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset)
 {
     if (!ctx || !out) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(flush_level_calls(ctx));
     CVHIP_TRY(set_device(ctx->dev));
     CVHIP_TRY_HIP(hipStreamSynchronize(ctx->dev->d.stream));
     unsigned long long v[4] = {0, 0, 0, 0};
@@ -1275,6 +1548,7 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset)
 int cvhip_ctx_set_stats_ahead(cvhip_ctx *ctx, int ahead)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     ctx->stats_ahead = ahead != 0;
     return CVHIP_OK;
 }
@@ -1282,7 +1556,16 @@ int cvhip_ctx_set_stats_ahead(cvhip_ctx *ctx, int ahead)
 int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     ctx->borrow_inputs = borrow != 0;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_fuse_level_calls(cvhip_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
+    ctx->fuse_level_calls = enable != 0;
     return CVHIP_OK;
 }
 
@@ -1296,6 +1579,7 @@ int cvhip_ctx_set_async_readback(cvhip_ctx *ctx, int enable)
 int cvhip_ctx_set_exact_scores(cvhip_ctx *ctx, int all_passes)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     ctx->exact_scores = all_passes != 0;
     return CVHIP_OK;
 }
@@ -1303,6 +1587,7 @@ int cvhip_ctx_set_exact_scores(cvhip_ctx *ctx, int all_passes)
 int cvhip_ctx_set_range_mode(cvhip_ctx *ctx, int mode)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     if (mode < 0 || mode > 3) return fail(CVHIP_ERR_INVALID, "range mode must be 0..3");
     ctx->range_mode = mode;
     return CVHIP_OK;
@@ -1311,6 +1596,7 @@ int cvhip_ctx_set_range_mode(cvhip_ctx *ctx, int mode)
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    CVHIP_TRY(flush_level_calls(ctx));
     // 4 = version 3 with the box kernel launched for every geometry (tests: exercises its per-workgroup decline)
     if (version < 1 || version > 4) return fail(CVHIP_ERR_INVALID, "search version must be 1, 2 or 3");
     ctx->force_box = version == 4;

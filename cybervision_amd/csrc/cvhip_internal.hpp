@@ -217,6 +217,19 @@ struct Device {
         bool pending[2] = {false, false};
         int next = 0;
     } rb;
+    // Page-locked ring for HOST level images (cvhip_correlate_images / _level with host pointers): the caller's buffer is
+    // copied into the ring on the calling thread(s), the H2D transfer runs on the copy stream (rb.stream) under whatever
+    // the main stream is doing, and the call returns without synchronising - the caller's buffer is free on return.
+    struct UploadRing {
+        uint8_t *base = nullptr;
+        size_t cap = 0, head = 0;
+        struct Chunk {
+            size_t begin, end;
+            hipEvent_t done;
+        };
+        std::vector<Chunk> busy;       // transfers that may still be reading their part of the ring (oldest first)
+        std::vector<hipEvent_t> spare; // events to reuse
+    } up;
     // Side streams of the handle, shared by whoever needs one (the RANSAC generators: both; the statistics-ahead mode:
     // the first) and created on first use.  Shared on purpose: a process gets four hardware queues, and a fifth stream
     // is mapped onto a queue that is already in use - its "concurrent" kernels then wait for that stream's (with a
@@ -255,6 +268,10 @@ struct Device {
     int comm_refs = 0;
     bool destroy_pending = false;
 };
+} // namespace cvhip
+struct cvhip_ctx;
+namespace cvhip {
+int flush_level_calls(cvhip_ctx *ctx); // cvhip_api.hip: run what cvhip_ctx_set_fuse_level_calls has deferred
 inline hipError_t aux_stream(Device &d, int i, hipStream_t *out)
 {
     hipError_t e = hipSuccess;
@@ -377,6 +394,25 @@ struct cvhip_ctx {
     // level follows scale 1 and complete() returns the forward grid (mod.rs:208-215).  It is therefore deferred and
     // only runs if somebody does ask for the reverse grid (cvhip_complete_dir(.., 1, ..), cvhip_ctx_level_grid(.., 1, ..)).
     bool rev_cross_check_pending = false;
+    // cvhip_ctx_set_fuse_level_calls: the caller issues the four backend calls of a level in
+    // PointCorrelations::correlate_images' order (mod.rs:217-245) - forward, reverse with the SAME two images exchanged,
+    // cross-check forward, cross-check reverse - and the library executes them as cvhip_correlate_level would: the
+    // forward call takes the images in (statistics of both), the reverse call launches both search passes together, the
+    // second cross-check call launches both filters.  `calls` is what has been taken in but not executed yet
+    // (cvhip::flush_level_calls runs it whenever another entry point comes first).
+    bool fuse_level_calls = false;
+    struct LevelCalls {
+        enum { NONE = 0, FWD_TAKEN, SEARCHED, CROSS_FWD_TAKEN };
+        int stage = NONE;
+        int k = -1, first_pass = 0;
+        float scale = 0.0f;
+        const uint8_t *img1 = nullptr, *img2 = nullptr; // the forward call's images (identity only: never dereferenced later)
+        uint32_t w1 = 0, h1 = 0, w2 = 0, h2 = 0;
+        bool stats_ahead = false;
+        hipEvent_t stats_done = nullptr;
+    } calls;
+    bool staged_from_pageable = false; // the last stage_images copied straight from the caller's pageable memory (no ring)
+    hipEvent_t level_read[16] = {};    // per level: the last kernels that read the staged images have been enqueued before it
     bool async_readback = false; // cvhip_ctx_set_async_readback
     bool exact_scores = false; // cvhip_ctx_set_exact_scores: every pass writes the reference's scores (tests)
     int search_version = 3;

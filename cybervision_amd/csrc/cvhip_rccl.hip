@@ -189,6 +189,7 @@ int cvhip_rccl_gather(cvhip_rccl *comm, void *buf, uint64_t shard_bytes, uint32_
 int cvhip_ctx_set_row_shard_rccl(cvhip_ctx *ctx, cvhip_rccl *comm)
 {
     if (!ctx || !comm) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(cvhip::flush_level_calls(ctx));
     if (ctx->dev != comm->dev) return fail(CVHIP_ERR_INVALID, "context and communicator belong to different device handles");
     CVHIP_TRY(cvhip_ctx_set_row_shard(ctx, comm->rank, comm->world, rccl_hook, comm));
     ctx->gather_on_stream = true;
@@ -198,6 +199,7 @@ int cvhip_ctx_set_row_shard_rccl(cvhip_ctx *ctx, cvhip_rccl *comm)
 int cvhip_ctx_gather_bands_rccl(cvhip_ctx *ctx, cvhip_rccl *comm, int root)
 {
     if (!ctx || !comm) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(cvhip::flush_level_calls(ctx));
     if (ctx->dev != comm->dev) return fail(CVHIP_ERR_INVALID, "context and communicator belong to different device handles");
     if (ctx->shard_den != comm->world || ctx->shard_num != comm->rank)
         return fail(CVHIP_ERR_INVALID, "the context's shard is not the communicator's rank");

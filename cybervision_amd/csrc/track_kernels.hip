@@ -144,6 +144,7 @@ extern "C" int cvhip_extend_tracks(cvhip_ctx *ctx, const int32_t *track_p1, uint
                                    uint64_t *out_n_new)
 {
     if (!ctx || !out_n_new) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(cvhip::flush_level_calls(ctx));
     if (n_tracks && (!track_p1 || !out_track_p2)) return fail(CVHIP_ERR_INVALID, "track arrays are null");
     if (cap && (!out_new_p1 || !out_new_p2)) return fail(CVHIP_ERR_INVALID, "new-track arrays are null");
     CVHIP_TRY_HIP(hipSetDevice(ctx->dev->d.ordinal));

@@ -54,10 +54,12 @@ class ImageReconstruction:
         return m
 
     # reconstruction.rs:502-526
-    def find_fundamental_matrix(self, img1_dimensions, img2_dimensions, point_matches, seed: int = 0):
+    def find_fundamental_matrix(self, img1_dimensions, img2_dimensions, point_matches, seed: int = 0, progress_listener=None):
+        """progress_listener: the reference ALWAYS passes one (`Some(&pb)`, reconstruction.rs:510-518): an object with
+        report_status(pos) / report_matches(count), both thunks of cvhip_find_ransac."""
         max_dimension = float(max(img1_dimensions[0], img1_dimensions[1], img2_dimensions[0], img2_dimensions[1]))
         fm = fundamentalmatrix.FundamentalMatrix(self.projection_mode, max_dimension)
-        return self._timed("ransac", lambda: fm.find_ransac(self.device, point_matches, seed=seed))
+        return self._timed("ransac", lambda: fm.find_ransac(self.device, point_matches, seed=seed, progress_listener=progress_listener))
 
     # reconstruction.rs:528-603 (up to complete(); triangulation is the next stage)
     def correlate_dense(self, pyr1, pyr2, f, out_xy=None, out_corr=None, borrow=False):
@@ -112,8 +114,23 @@ def padded_pyramid(pyr):
     return out, True
 
 
+class ProgressBar:
+    """Stand-in for the reference's indicatif bar (reconstruction.rs:840-863): both RANSAC thunks, nothing drawn."""
+
+    def __init__(self):
+        self.pos, self.matches, self.calls = 0.0, 0, 0
+
+    def report_status(self, pos):
+        self.pos = pos
+        self.calls += 1
+
+    def report_matches(self, count):
+        self.matches = count
+        self.calls += 1
+
+
 def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = ProjectionMode.Perspective, seed: int = 0,
-                      dense: bool = True, borrow: bool = False):
+                      dense: bool = True, borrow: bool = False, listener: bool = False):
     """The two pair loops of `reconstruct` (reconstruction.rs:261-277 sparse, :680-730 dense) over n images:
     for every i < j the sparse stage (ORB on both, matcher, RANSAC); then, for every pair that produced an F, the
     dense correlation.  The reference re-extracts an image's keypoints for every pair it takes part in; the result
@@ -130,7 +147,8 @@ def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = Projec
             matches = rec.match_keypoints(keypoints[i], keypoints[j])
             entry = {"matches": matches, "f": None, "inliers": None, "error": None}
             try:
-                f, inliers, _ = rec.find_fundamental_matrix(di, dj, matches, seed=seed + 1000 * i + j)
+                f, inliers, _ = rec.find_fundamental_matrix(di, dj, matches, seed=seed + 1000 * i + j,
+                                                            progress_listener=ProgressBar() if listener else None)
                 entry["f"], entry["inliers"] = f, inliers
             except Exception as exc:  # "Failed to match images" (reconstruction.rs:268-274): the pair is skipped
                 entry["error"] = str(exc)

@@ -222,6 +222,18 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, void **scores, u
  * image stays unchanged until the work of the call has completed on the device's stream.  Host images are
  * still copied.  Off by default. */
 int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow);
+/* The reference issues FOUR backend calls per pyramid level (PointCorrelations::correlate_images, correlation/mod.rs:
+ * 217-245): correlate_images forward, correlate_images reverse with the SAME two images exchanged, cross_check_filter
+ * forward, cross_check_filter reverse.  By enabling this the caller promises that order - the binding of
+ * GpuContext::new does - and the library executes the four calls as cvhip_correlate_level would: the
+ * forward call takes the images in (both images' window statistics, once per level), the reverse call - recognised by
+ * the exchanged image pointers, dimensions, scale and first_pass - launches both search passes together, the second
+ * cross-check call launches both filters.  Results are those of the independent calls, bit for bit; a call sequence
+ * that departs from the order is executed call by call as without the promise (whatever was taken in runs first), and
+ * every other entry point of the context first runs what is pending.  What the promise adds to the contract: between a
+ * level's forward and reverse call the two images must not change (the reverse call does not read them again), and an
+ * error of the forward pass is reported by the call that executes it.  Off by default. */
+int cvhip_ctx_set_fuse_level_calls(cvhip_ctx *ctx, int enable);
 /* Window statistics of a level (compute_image_point_data, mod.rs:632-694) on a stream of the library's own, ahead of
  * the level's turn: they depend on the level's images only, and the coarse levels' search is a chain of small
  * dependent launches that leaves the chip idle for ~0.4 ms of a 4096^2 pair - room for the 0.5 ms of full-chip work

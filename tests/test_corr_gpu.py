@@ -180,6 +180,99 @@ def test_per_pass_calls_equal_fused_level_call(gpu_device):
     assert_same_grid(run_gpu(gpu_device, c, fused=False), run_gpu(gpu_device, c, fused=True), "per-pass vs fused")
 
 
+@pytest.mark.parametrize("name", ["tilt3_200x150", "persp_240x180", "ragged_dims"])
+def test_fused_level_calls_equal_independent_calls(gpu_device, oracle, name):
+    """cvhip_ctx_set_fuse_level_calls: the reference's four calls per level, in the reference's order, executed as one
+    level call (forward call: images in + statistics; reverse call: both search passes; second cross-check call: both
+    filters) give the grids of the independent calls and of the oracle - host images through the upload ring, device
+    images copied and borrowed, both directions' grids, several pairs on one context's parked buffers."""
+    import torch
+
+    c = cases.make_case(name)
+    want = run_oracle(oracle, c, both=True)
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    pads = [[torch.zeros(l.size + 64, dtype=torch.uint8, device="cuda") for l in p] for p in (p1, p2)]
+    dev_p = []
+    for p, bufs in zip((p1, p2), pads):
+        lv = []
+        for l, b in zip(p, bufs):
+            b[:l.size].copy_(torch.from_numpy(l.reshape(-1)))
+            lv.append(b[:l.size].view(l.shape[0], l.shape[1]))
+        dev_p.append(lv)
+    torch.cuda.synchronize()
+    for mode in ("host", "device", "borrowed", "host again"):
+        pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"], correlation.ProjectionMode(c["projection"]))
+        pc.set_exact_scores(True)
+        pc.set_fuse_level_calls(True)
+        a, b = (p1, p2) if mode.startswith("host") else dev_p
+        if mode == "borrowed":
+            pc.set_borrow_inputs(True)
+            pc.set_stats_ahead(True)
+        try:
+            for i in range(c["steps"] + 1):
+                k = c["steps"] - i
+                pc.correlate_images(a[k], b[k], 1.0 / float(1 << k), fused=False)
+            got = (pc.complete(correlation.CorrelationDirection.Forward), pc.complete(correlation.CorrelationDirection.Reverse))
+        finally:
+            pc.close()
+        assert_same_grid(got[0], want[0], f"{name} fused calls ({mode}) forward")
+        assert_same_grid(got[1], want[1], f"{name} fused calls ({mode}) reverse")
+
+
+def test_fused_level_calls_out_of_order(gpu_device, oracle):
+    """A caller that has promised the reference's call order and departs from it still gets every call executed: grids
+    read between the calls (complete() after each), a forward call whose reverse call never comes, a reverse call with
+    OTHER images than the forward call's, cross-checks in the other order."""
+    c = cases.make_case("sem320x200")
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    F, D = correlation.CorrelationDirection.Forward, correlation.CorrelationDirection.Reverse
+    pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"])
+    pc.set_exact_scores(True)
+    pc.set_fuse_level_calls(True)
+    oc = oracle.Corr((w1, h1), (w2, h2), c["F"], 0, 8)
+    try:
+        for i in range(c["steps"] + 1):
+            k = c["steps"] - i
+            s = 1.0 / float(1 << k)
+            variant = i % 3
+            pc.correlate_images_step(p1[k], p2[k], s, F)
+            oc.step(p1[k], p2[k], s, 0)
+            if variant == 0:   # the grid is read before the reverse call: the pending forward pass runs alone
+                assert_same_grid(pc.complete(F), oc.get(0), f"level {k} fwd search (read early)")
+            if variant == 1:   # the reverse call passes a COPY of the images: not recognised as the level's reverse call
+                pc.correlate_images_step(p2[k].copy(), p1[k].copy(), s, D)
+            else:
+                pc.correlate_images_step(p2[k], p1[k], s, D)
+            oc.step(p2[k], p1[k], s, 1)
+            assert_same_grid(pc.complete(D), oc.get(1), f"level {k} rev search")
+            if variant == 2:   # reverse filter first
+                pc.cross_check_filter(s, D)
+                oc.cross_check(s, 1)
+                pc.cross_check_filter(s, F)
+                oc.cross_check(s, 0)
+            else:
+                pc.cross_check_filter(s, F)
+                oc.cross_check(s, 0)
+                if variant == 0:
+                    assert_same_grid(pc.complete(F), oc.get(0), f"level {k} fwd cross-check (read early)")
+                pc.cross_check_filter(s, D)
+                oc.cross_check(s, 1)
+            assert_same_grid(pc.complete(F), oc.get(0), f"level {k} fwd")
+            assert_same_grid(pc.complete(D), oc.get(1), f"level {k} rev")
+            pc.first_pass = False
+            oc.end_level()
+        # a forward call that is never followed by anything but the context's destruction
+        pc.first_pass = True
+        pc.correlate_images_step(p1[c["steps"]], p2[c["steps"]], 1.0 / float(1 << c["steps"]), F)
+    finally:
+        pc.close()
+        oc.close()
+
+
 def test_each_level_matches_oracle(gpu_device, oracle):
     """Stage-by-stage: after every search pass and every cross-check the device grids equal
     the oracle's (catches compensating errors that a final-grid comparison could hide)."""
