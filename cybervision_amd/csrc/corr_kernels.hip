@@ -1605,6 +1605,496 @@ __global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void s
 #include "box_body.inc"
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// search4_mfma_kernel: the filter's numerator as a small dense product on the matrix pipe (int8 MFMA) - for rectified
+// affine pairs (exactly axis-parallel row-major lines, five stripes), where search3_box_kernel's lean instantiation ran.
+//   S12(pixel, position) = sum over the 11 x 11 window of a * b     with a' = a - 128, b' = b - 128 as int8:
+//   sum a' b' = S12 - 128 s1 - 128 s2 + 121 * 128^2   ->   N = 121 S12 - s1 s2 = 121 acc + P + (-s2) (s1 - 15488),
+//   P = 15488 s1 - 121^2 * 128^2 - exact integers throughout, so band test, contender bookkeeping, DELTA and the exact
+// re-evaluation are search3_box_kernel's, unchanged: the kernels compute the same N.
+// v_mfma_i32_16x16x64_i8: rows (M) = 16 consecutive target POSITIONS of one stripe, columns (N) = 16 PIXELS - a tile of
+// 8 x 2 (two image rows share all but one of their 16 target rows, and an 8-wide tile wastes less of the diagonal band:
+// pixel nx searches positions x + [lo, lo + W), so 8 pixels span W + 7 positions = two 16-position tiles for W <= 25,
+// 56 % of the computed pairs candidates, against 37 % for 16 x 1), K = 4 target rows x 16 bytes per instruction.  Lane
+// (m | n = l & 15, kb = l >> 4) supplies 16 bytes of target row rho = 4 i + kb at position m for the position operand and
+// the same row of pixel n's window - window row j = rho - stripe - ny, eleven bytes and five zeros, all zeros where j is
+// not 0..10 - for the pixel operand; both through the same byte map, so the product is exact whatever the instruction's
+// internal k order.  The position operand of a tile (rows rho = 0..15: four fragments) serves all five stripes; the pixel
+// operands depend on 4 i - stripe only (fifteen distinct fragments, registers for the whole pixel tile).  18 MFMAs per
+// position tile and 1280 (pixel, position, stripe) pairs.  Accumulator lane l holds pixel l & 15 and positions
+// 4 (l >> 4) .. + 3: one pixel per lane, so its constants (P, s1 - 15488, the acceptance limit) are per-lane scalars.
+// LDS: target strip and pixel strip biased by 128 in FOUR byte-shifted copies (a 16-byte fragment at any byte offset o
+// is four dwords of copy o & 3: an unaligned ds_read_b128 costs 7x an aligned one on gfx950), candidate statistics
+// {-s2, sd2}, and the pixels' walk state (running maximum, limit, contender list): a pixel's candidates arrive in four
+// lanes, which update the state one lane group after the other inside the rarely taken hit branch.
+// Setup and the exact phase run one pixel per thread (64 x 4 tile), as in the box kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int S4_TW = 64, S4_TH = 4;
+constexpr int S4_TROWS = 18, S4_TPITCH = 172; // target strip: 4 pixel rows + 4 stripe steps + 10 window rows; 43 dwords per row
+constexpr int S4_PROWS = 14, S4_PPITCH = 100; // pixel strip: 4 pixel rows + 10 window rows; 64 + 10 columns (+ alignment, + the fragment's tail)
+constexpr int S4_ISROWS = 8, S4_ISP = 160;    // candidate statistics: pixel row + stripe, position
+constexpr int S4_WMAX = 60;                   // widest displacement box of a workgroup (strip and statistics rows hold it)
+constexpr int S4_T_OFF = 0, S4_TCOPY = S4_TROWS * S4_TPITCH;
+constexpr int S4_P_OFF = S4_T_OFF + 4 * S4_TCOPY, S4_PCOPY = S4_PROWS * S4_PPITCH;
+constexpr int S4_IS_OFF = (S4_P_OFF + 4 * S4_PCOPY + 15) & ~15;
+constexpr int S4_ST_OFF = S4_IS_OFF + S4_ISROWS * S4_ISP * 8;
+struct S4PixelState { // per pixel of the workgroup's tile (struct of arrays in LDS)
+    float runmax[256], k1[256];
+    uint32_t count[256];
+    unsigned long long clist[256];
+    int s1[256], lox[256], r0[256];
+    uint32_t wx[256];
+};
+constexpr int S4_LDS_BYTES = S4_ST_OFF + (int)sizeof(S4PixelState);
+constexpr int S4_QCAP = 12; // events a pixel's queue holds per tile (beyond: the pixel's whole corridor is re-evaluated exactly)
+struct S4Merge {
+    float runmax[64], g[4][64];
+    uint32_t count[64];
+    unsigned long long clist[64];
+    uint32_t evn[16];
+    uint2 ev[16 * S4_QCAP];
+};
+typedef int s4_i32x4 __attribute__((ext_vector_type(4)));
+
+// `nrows` image rows from `row0`, `nd` dwords from byte column `col0` (a multiple of 4) -> four byte-shifted copies,
+// biased by 128: dword D of copy c = image bytes col0 + 4 D + c .. + 3 (zero outside the image: those positions and
+// pixels are never candidates)
+__device__ __forceinline__ void s4_stage_copies(uint8_t *__restrict__ dst, int copy_bytes, int pitch, const uint8_t *__restrict__ img, int w, int h,
+                                                int row0, int col0, int nrows, int nd)
+{
+    for (int u = (int)threadIdx.x; u < nrows * nd; u += 256) {
+        const int r = u / nd, D = u - r * nd;
+        const uint32_t d0 = load_dword_checked(img, w, h, row0 + r, col0 + 4 * D) ^ 0x80808080u;
+        const uint32_t d1 = load_dword_checked(img, w, h, row0 + r, col0 + 4 * D + 4) ^ 0x80808080u;
+        uint32_t *o = reinterpret_cast<uint32_t *>(dst + r * pitch) + D;
+        o[0] = d0;
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(o) + copy_bytes) = __builtin_amdgcn_alignbyte(d1, d0, 1);
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(o) + 2 * copy_bytes) = __builtin_amdgcn_alignbyte(d1, d0, 2);
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(o) + 3 * copy_bytes) = __builtin_amdgcn_alignbyte(d1, d0, 3);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256, 3) void search4_mfma_kernel(SearchJob ja, SearchJob jb)
+{
+    const SearchJob &j = this_job();
+    const CorrParams &p = j.p;
+    const uint8_t *__restrict__ const img1 = j.img1, *__restrict__ const img2 = j.img2;
+    const uint2 *__restrict__ const stats1 = j.stats1, *__restrict__ const istats2 = j.stats2;
+    unsigned long long *__restrict__ const contenders = j.contenders, *__restrict__ const counters = j.counters;
+    uint32_t *__restrict__ const out = j.out;
+    float *__restrict__ const out_score = j.out_score;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[S4_LDS_BYTES];
+    __shared__ int bb[8]; // min dx, max dx, min loy, max loy, largest candidate count of a pixel, 1 = some pixel is no rectangle
+    S4PixelState &st = *reinterpret_cast<S4PixelState *>(lds + S4_ST_OFF);
+    __shared__ S4Merge mg_lds[4]; // one per wave: the four lanes' contender lists of a pixel meet here when its tile is done
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const TileId tid = xcd_tile();
+    const int U0 = (int)tid.x * S4_TW;
+    const uint32_t V0 = p.row0 + tid.y * S4_TH;
+    const uint32_t x = (uint32_t)U0 + lane, y = V0 + w;
+    const int xi = (int)x;
+    const bool is_out = x < p.w1 && y < p.row1;
+    if (threadIdx.x == 0) {
+        bb[0] = 0x7FFFFFFF;
+        bb[1] = -0x7FFFFFFF;
+        bb[2] = 0x7FFFFFFF;
+        bb[3] = -0x7FFFFFFF;
+        bb[4] = 0;
+        bb[5] = 0;
+    }
+    // ---- per-pixel setup (one pixel per thread): search3_box_kernel's, for its lean instantiation ---------------
+    PixelSetup ps;
+    ps.st1 = make_float2(0.0f, 1.0f);
+    ps.e.cx = ps.e.cy = ps.e.ax = ps.e.ay = 0.0;
+    ps.e.ox = ps.e.oy = 0;
+    ps.r0 = ps.r1 = 0;
+    const bool active = is_out && pixel_setup(p, x, y, stats1, j.range, ps);
+    const Line &e = ps.e;
+    const uint32_t r0 = ps.r0, r1 = ps.r1;
+    const int cs = p.corridor_size;
+    bool simple = true;
+    int lox = 0, loy = 0;
+    uint32_t wx = 0;
+    if (active) {
+        // the candidate set must be the rectangle [lox, lox + wx) x [loy, loy + 5): candidates advance along x (x2 == i
+        // exactly), the five stripes are consecutive rows that do not depend on i (minor coefficient +-0)
+        const bool major_x = e.ox == 0;
+        uint32_t m0 = 0;
+        bool consecutive = true;
+        for (int off = -cs; off <= cs; off++) {
+            const uint32_t mf = f64_to_u32_sat(floor((e.cy * (double)r0 + e.ay) + (double)(off * e.oy)));
+            if (off == -cs) m0 = mf;
+            consecutive = consecutive && mf == m0 + (uint32_t)(off + cs);
+        }
+        const uint32_t ilo = max(r0, (uint32_t)KERNEL_SIZE), ihi = min(r1, sat_sub_u32(p.w2, KERNEL_SIZE));
+        const uint32_t nmaj = ihi > ilo ? ihi - ilo : 0u;
+        simple = major_x && cs == 2 && e.cy == 0.0 && e.cx == 1.0 && e.ax == 0.0 && consecutive && (r1 - r0) <= CW_MAX_LEN && m0 < 0x40000000u &&
+                 ilo < 0x40000000u;
+        lox = (int)ilo - xi;
+        wx = nmaj;
+        loy = (int)m0 - (int)y;
+    }
+    const bool has = active && simple && wx > 0u;
+    const int mnx = wave_min_i32(has ? lox : 0x7FFFFFFF), mxx = wave_max_i32(has ? lox + (int)wx - 1 : -0x7FFFFFFF);
+    const int mny = wave_min_i32(has ? loy : 0x7FFFFFFF), mxy = wave_max_i32(has ? loy : -0x7FFFFFFF);
+    const int need = wave_max_i32(has ? (int)min(wx * 5u, 0x3FFFFFFFu) : 0);
+    const bool wave_odd = __any(active && !simple);
+    __syncthreads(); // bb initialised
+    if (lane == 0) {
+        if (mxx >= mnx) {
+            atomicMin(&bb[0], mnx);
+            atomicMax(&bb[1], mxx);
+            atomicMin(&bb[2], mny);
+            atomicMax(&bb[3], mxy);
+            atomicMax(&bb[4], need);
+        }
+        if (wave_odd) atomicOr(&bb[5], 1);
+    }
+    __syncthreads();
+    const size_t pix = (size_t)y * p.w1 + x;
+    const bool any_has = bb[1] >= bb[0];
+    const int dx0 = bb[0], W = bb[1] - bb[0] + 1, LOY = bb[2];
+    // one stripe origin for the whole workgroup, a box the strips hold, and a walk not much larger than the largest
+    // pixel's own candidate set (disparity discontinuities)
+    const bool eligible = !bb[5] && (!any_has || (bb[2] == bb[3] && W <= S4_WMAX && (long long)(W + 7) * 5 <= 3ll * bb[4] + 80));
+    if (!eligible || !any_has) {
+        if (is_out) {
+            const bool fb = active && !eligible;
+            if (!eligible) contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
+            if (!fb) out[pix] = CELL_NONE;
+        }
+        if (!eligible && threadIdx.x == 0) worklist_push(j.declined, (uint32_t)U0 | (tid.y << 16) | 0x80000000u);
+        return;
+    }
+    // ---- staging ---------------------------------------------------------------------------------------------
+    const int TC0 = (U0 + dx0 - KERNEL_SIZE) & ~3;     // image column of byte 0 of the target strip
+    const int TR0 = (int)V0 + LOY - KERNEL_SIZE;      // image row of its row 0
+    const int PC0 = (U0 - KERNEL_SIZE) & ~3, PR0 = (int)V0 - KERNEL_SIZE;
+    {
+        const int tnd = min((U0 + dx0 - KERNEL_SIZE - TC0 + S4_TW + W + 38 + 3) >> 2, S4_TPITCH / 4 - 1); // bytes the fragments can touch
+        s4_stage_copies(lds + S4_T_OFF, S4_TCOPY, S4_TPITCH, img2, (int)p.w2, (int)p.h2, TR0, TC0, S4_TROWS, tnd);
+        s4_stage_copies(lds + S4_P_OFF, S4_PCOPY, S4_PPITCH, img1, (int)p.w1, (int)p.h1, PR0, PC0, S4_PROWS, S4_PPITCH / 4 - 1);
+        // candidate statistics {-s2, sd2}: row = pixel row + stripe, entry = position - (U0 + dx0); centres outside the
+        // image or skipped by the reference (mod.rs:430-441) get sd2 = +inf: their limit can never be reached
+        const int isp = min(S4_TW + W + 32, S4_ISP);
+        const int gu0 = U0 + dx0, gv0 = (int)V0 + LOY;
+        for (int u = (int)threadIdx.x; u < isp * S4_ISROWS; u += 256) {
+            const int r = u / isp, c = u - r * isp;
+            const int gy = gv0 + r, gx = gu0 + c;
+            uint2 v = make_uint2(0u, 0x7F800000u);
+            if (gy >= 0 && gy < (int)p.h2 && gx >= 0 && gx < (int)p.w2) {
+                const uint2 tt = istats2[(size_t)gy * p.w2 + (size_t)gx];
+                if (tt.x & 0x80000000u) v = make_uint2(0u - (tt.x & 0x7FFFFFFFu), tt.y);
+            }
+            *reinterpret_cast<uint2 *>(lds + S4_IS_OFF + (size_t)(r * S4_ISP + c) * 8u) = v;
+        }
+    }
+    const uint32_t s1 = has ? (stats1[pix].x & 0x7FFFFFFFu) : 0u;
+    const float k1 = ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT); // 121*121*sd1
+    const float thr_lo = p.threshold - S2_DELTA;
+    {
+        const uint32_t pi = threadIdx.x; // = w * 64 + lane
+        st.runmax[pi] = -__builtin_inff();
+        st.k1[pi] = k1;
+        st.count[pi] = 0u;
+        st.clist[pi] = 0ull;
+        st.s1[pi] = (int)s1;
+        st.lox[pi] = lox;
+        st.r0[pi] = (int)r0;
+        st.wx[pi] = has ? wx : 0u;
+    }
+    __syncthreads();
+
+    // ---- the walk: wave w takes pixel tiles w, w + 4, w + 8, w + 12 of the sixteen 8 x 2 tiles ------------------
+    uint32_t evaluated = 0;
+    {
+        const uint32_t n = lane & 15u, q = lane >> 4, nx = n & 7u, ny = n >> 3;
+        for (uint32_t t = w; t < 16u; t += 4u) {
+            const uint32_t tx = t & 7u, th = t >> 3;
+            const uint32_t pi = (2u * th + ny) * 64u + 8u * tx + nx;
+            const uint32_t pwx = st.wx[pi];
+            const int plox = st.lox[pi];
+            const int dmin = wave_min_i32(pwx ? plox : 0x7FFFFFFF), dmax = wave_max_i32(pwx ? plox + (int)pwx - 1 : -0x7FFFFFFF);
+            if (dmax < dmin) continue; // (wave-uniform) nothing to search in this tile
+            const int ntiles = (dmax - dmin + 1 + 7 + 15) >> 4;
+            const int x0t = U0 + 8 * (int)tx;
+            const int ps1 = st.s1[pi], P = 15488 * ps1 - 239878144, Qn = ps1 - 15488;
+            const float kk1 = st.k1[pi];
+            // acceptance band in the integer domain, as in the box kernel; lanes without candidates never pass
+            float limk = pwx ? thr_lo * kk1 * (1.0f - 9.5367431640625e-7f) : __builtin_inff();
+            S4Merge &mm = mg_lds[w];
+            if (lane < 16u) mm.evn[lane] = 0u; // (the previous tile's readers are behind the wave barrier at its end)
+            // pixel operands: fragment k <-> 4 i - stripe = k - 3: window row j = k - 3 + kb - ny of pixel n, i.e. strip row
+            // 2 th + kb + k - 3 (ny cancels), eleven bytes and five zeros; zero where j is not 0..10
+            s4_i32x4 G[15];
+            {
+                const int op = x0t + (int)nx - KERNEL_SIZE - PC0; // byte offset of the pixel's window in its strip rows
+                const uint8_t *const base = lds + S4_P_OFF + (op & 3) * S4_PCOPY + (op >> 2) * 4;
+#pragma unroll
+                for (int k = 0; k < 15; k++) {
+                    const int jrow = k - 3 + (int)q - (int)ny, prow = 2 * (int)th + (int)q + k - 3;
+                    const bool ok = jrow >= 0 && jrow <= 10;
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(base + (ok ? prow : 0) * S4_PPITCH);
+                    G[k][0] = ok ? (int)src[0] : 0;
+                    G[k][1] = ok ? (int)src[1] : 0;
+                    G[k][2] = ok ? (int)(src[2] & 0x00FFFFFFu) : 0;
+                    G[k][3] = 0;
+                }
+            }
+            // position fragments: byte offset of position (pt, m) in its strip rows, statistics entry of (pt, 4 q)
+            const int P0 = x0t + dmin; // position of (pt = 0, m = 0)
+            const int ob = P0 + (int)n - KERNEL_SIZE - TC0;
+            const uint8_t *posb = lds + S4_T_OFF + (ob & 3) * S4_TCOPY + (ob >> 2) * 4 + (2 * (int)th + (int)q) * S4_TPITCH;
+            const uint8_t *isb = lds + S4_IS_OFF + (size_t)((2 * (int)th + (int)ny) * S4_ISP + (P0 - (U0 + dx0)) + 4 * (int)q) * 8u;
+            const int dbase = dmin + 4 * (int)q - (int)nx; // displacement of this lane's first position in tile 0
+            // position tiles from the middle outwards (the ranges are centred on the previous level's prediction)
+            for (int ti = 0; ti < ntiles; ti++) {
+                const int mid = ntiles >> 1, pt = (ti & 1) ? mid - ((ti + 1) >> 1) : mid + (ti >> 1);
+                if (pt < 0 || pt >= ntiles) continue; // (ntiles even: the order 1, 2, 0, 3 ... visits index -1 / ntiles once)
+                s4_i32x4 A[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(posb + 16 * pt + 4 * i * S4_TPITCH);
+                    A[i][0] = (int)src[0];
+                    A[i][1] = (int)src[1];
+                    A[i][2] = (int)src[2];
+                    A[i][3] = (int)src[3];
+                }
+                s4_i32x4 acc[5];
+#pragma unroll
+                for (int s = 0; s < 5; s++) acc[s] = s4_i32x4{0, 0, 0, 0};
+                // stripe s, instruction i: pixel fragment k = 4 i - s + 3
+                acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], G[3], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], G[2], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], G[1], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], G[0], acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], G[3], acc[4], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], G[7], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], G[6], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], G[5], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], G[4], acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], G[7], acc[4], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], G[11], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], G[10], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], G[9], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], G[8], acc[3], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], G[11], acc[4], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], G[14], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], G[13], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], G[12], acc[3], 0, 0, 0);
+                const int d0 = dbase + 16 * pt; // displacement of acc[.][0]
+                // stripes from the middle outwards: every record raises the limit
+#pragma unroll
+                for (int si = 0; si < 5; si++) {
+                    const int s = si == 0 ? 2 : (si == 1 ? 1 : (si == 2 ? 3 : (si == 3 ? 0 : 4)));
+                    const uint2 *isp = reinterpret_cast<const uint2 *>(isb + (size_t)(s * S4_ISP + 16 * pt) * 8u);
+                    int num[4];
+                    float sd[4], mg[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint2 is2 = isp[r];
+                        num[r] = __mul24(acc[s][r], KERNEL_POINT_COUNT) + P + __mul24((int)is2.x, Qn);
+                        sd[r] = __uint_as_float(is2.y);
+                        mg[r] = __builtin_fmaf(-limk, sd[r], (float)num[r]);
+                    }
+                    if (COUNT) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if ((uint32_t)(d0 + r - plox) < pwx && sd[r] < __builtin_inff()) evaluated++;
+                    }
+                    const float margin = fmaxf(fmaxf(mg[0], mg[1]), fmaxf(mg[2], mg[3]));
+                    if (__any(margin >= 0.0f)) {
+                        // Passing candidates are EVENTS: (score, code) appended to the pixel's queue in LDS (sixteen pixels
+                        // x four lanes x twenty values per position tile: some lane has one at most steps, so what a lane
+                        // does here has to be short - the contender bookkeeping waits until the tile is done).  The limit
+                        // rises at once: a candidate with score g puts the maximum at g or above.
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (mg[r] >= 0.0f) {
+                                const int d = d0 + r;
+                                if ((uint32_t)(d - plox) < pwx && sd[r] < __builtin_inff() && (float)num[r] >= limk * sd[r]) {
+                                    const float c1 = 1.0f / kk1; // as in the box kernel
+                                    const float g = (float)num[r] * (c1 * __builtin_amdgcn_rcpf(sd[r]));
+                                    const uint32_t code = ((uint32_t)s << 11) | (uint32_t)(x0t + (int)nx + d - st.r0[pi]);
+                                    const uint32_t at = atomicAdd(&mm.evn[n], 1u);
+                                    if (at < (uint32_t)S4_QCAP) mm.ev[n * S4_QCAP + at] = make_uint2(__float_as_uint(g), code);
+                                    limk = fmaxf(limk, fmaxf(g - 2.0f * S2_DELTA, thr_lo) * kk1 * (1.0f - 9.5367431640625e-7f));
+                                }
+                            }
+                        }
+                        // the pixel's limit: the largest of its four lanes' (lanes l, l ^ 16, l ^ 32, l ^ 48)
+                        {
+                            const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(limk), __float_as_uint(limk), false, false);
+                            limk = fmaxf(__uint_as_float(h[0]), __uint_as_float(h[1]));
+                            const auto g16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(limk), __float_as_uint(limk), false, false);
+                            limk = fmaxf(__uint_as_float(g16[0]), __uint_as_float(g16[1]));
+                        }
+                    }
+                }
+            }
+            // ---- the tile is done: the pixels' events go through the box kernel's record() - lane (n, q) takes events
+            // q, q + 4, ... of pixel n onto a list of its own (scores kept), then the four lists of a pixel are merged.
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float runmax = -__builtin_inff(), gs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            uint32_t count = 0;
+            unsigned long long clist = 0ull;
+            {
+                const uint32_t nev = mm.evn[n];
+                if (nev > (uint32_t)S4_QCAP) { // more events than the queue holds: the whole corridor, exactly
+                    count = (uint32_t)S2_K + 1u;
+                    runmax = __builtin_inff();
+                }
+                for (uint32_t i = q; i < min(nev, (uint32_t)S4_QCAP); i += 4u) {
+                    const uint2 evv = mm.ev[n * S4_QCAP + i];
+                    const float g = __uint_as_float(evv.x);
+                    const float lim = fmaxf(runmax - 2.0f * S2_DELTA, thr_lo);
+                    if (g >= lim) {
+                        if (g > runmax + 2.0f * S2_DELTA) { // everything recorded so far is out of the band
+                            count = 0;
+                            clist = 0ull;
+                        }
+                        runmax = fmaxf(runmax, g);
+                        if (count < (uint32_t)S2_K) {
+                            clist |= (unsigned long long)evv.y << (15u * count);
+                            if (count == 0u) gs[0] = g;
+                            else if (count == 1u) gs[1] = g;
+                            else if (count == 2u) gs[2] = g;
+                            else gs[3] = g;
+                        }
+                        count = min(count + 1u, (uint32_t)S2_K + 1u);
+                    }
+                }
+            }
+            // ---- the tile is done: merge the four lanes' lists of every pixel (through LDS, the wave's own slots) -------
+            // Everything within 2 delta of the pixel's maximum was within 2 delta of its lane's running maximum when it was
+            // met, so it is on that lane's list unless a reset dropped it - and a reset only drops what is more than
+            // 2 delta below a score that is itself not above the maximum.  A lane whose list overflowed inside the band
+            // sends the pixel to the whole-corridor evaluation, as an overflowing pixel list does.
+            {
+                mm.runmax[lane] = runmax;
+                mm.count[lane] = count;
+                mm.clist[lane] = clist;
+#pragma unroll
+                for (int c = 0; c < 4; c++) mm.g[c][lane] = gs[c];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (q == 0u) {
+                    float gmax = -__builtin_inff();
+#pragma unroll
+                    for (uint32_t qq = 0; qq < 4u; qq++) gmax = fmaxf(gmax, mm.runmax[n + 16u * qq]);
+                    const float band = fmaxf(gmax - 2.0f * S2_DELTA, thr_lo);
+                    uint32_t cnt = 0;
+                    unsigned long long cl = 0ull;
+#pragma unroll
+                    for (uint32_t qq = 0; qq < 4u; qq++) {
+                        const uint32_t lc = mm.count[n + 16u * qq];
+                        const unsigned long long lcl = mm.clist[n + 16u * qq];
+                        if (lc > (uint32_t)S2_K && mm.runmax[n + 16u * qq] >= band) cnt = (uint32_t)S2_K + 1u; // overflowed inside the band
+#pragma unroll
+                        for (uint32_t c = 0; c < (uint32_t)S2_K; c++) {
+                            if (c < min(lc, (uint32_t)S2_K) && mm.g[c][n + 16u * qq] >= band) {
+                                if (cnt < (uint32_t)S2_K) cl |= ((lcl >> (15u * c)) & 0x7FFFull) << (15u * cnt);
+                                cnt = min(cnt + 1u, (uint32_t)S2_K + 1u);
+                            }
+                        }
+                    }
+                    st.runmax[pi] = gmax;
+                    st.count[pi] = cnt;
+                    st.clist[pi] = cl;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- exact re-evaluation of the contenders (one pixel per thread): search3_box_kernel's ----------------------
+    unsigned long long word = 0ull;
+    uint2 cell = make_uint2(CELL_NONE, 0x7FC00000u);
+    uint32_t multi = 0, whole = 0, exact_evals = 0;
+    if (has) {
+        const uint32_t count = st.count[threadIdx.x];
+        const unsigned long long clist = st.clist[threadIdx.x];
+        const float runmax = st.runmax[threadIdx.x];
+        if (count > (uint32_t)S2_K) {
+            word = CW_WHOLE << 60;
+            whole = 1;
+        } else if (count > 0u) {
+            multi = count > 1 ? 1u : 0u;
+            bool have = false;
+            float bcorr = 0.0f;
+            uint32_t bxy = 0, bcode = 0;
+            const float avg1 = ps.st1.x, sdev1 = ps.st1.y;
+            const uint8_t *base1 = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (x - KERNEL_SIZE);
+            uint32_t ecount = count;
+            if (!p.need_scores && count == 1u && runmax >= p.threshold + S2_DELTA) {
+                const uint32_t code = (uint32_t)clist & 0x7FFFu;
+                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                cell = make_uint2(c.x | (c.y << 16), __float_as_uint(runmax));
+                ecount = 0u;
+            }
+            for (uint32_t jj = 0; jj < ecount; jj++) {
+                const uint32_t code = (uint32_t)(clist >> (15u * jj)) & 0x7FFFu;
+                const CandXY c = candidate_xy(e, r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+                const uint2 is2 = istats2[(size_t)c.y * p.w2 + c.x];
+                const float avg2 = (float)(is2.x & 0x7FFFFFFFu) / (float)KERNEL_POINT_COUNT; // == compute_point_avg
+                const float sdev2 = __uint_as_float(is2.y);
+                const uint8_t *base2 = img2 + (size_t)(c.y - KERNEL_SIZE) * p.w2 + (c.x - KERNEL_SIZE);
+                float corr = 0.0f;
+#pragma unroll 1
+                for (int rb = 0; rb < 12; rb += 4) {
+                    Row12 av[4], bv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int rr = min(rb + r, KERNEL_WIDTH - 1);
+                        av[r] = load_row12(base1 + (size_t)rr * p.w1);
+                        bv[r] = load_row12(base2 + (size_t)rr * p.w2);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (rb + r < KERNEL_WIDTH) corr = row_corr_acc(corr, av[r], bv[r], avg1, avg2);
+                }
+                corr /= sdev1 * sdev2 * (float)KERNEL_POINT_COUNT; // mod.rs:454
+                exact_evals++;
+                if (corr >= p.threshold && (!have || corr > bcorr || (corr == bcorr && code < bcode))) { // mod.rs:456-464
+                    have = true;
+                    bcorr = corr;
+                    bcode = code;
+                    bxy = c.x | (c.y << 16);
+                }
+            }
+            if (have) cell = make_uint2(bxy, __float_as_uint(bcorr));
+        }
+    }
+    if (is_out && !whole) store_cell(p, out, out_score, pix, cell);
+    if (counters) {
+        uint32_t v0 = evaluated, v1 = exact_evals, v2 = multi, v3 = whole;
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            v0 += __shfl_down(v0, sft, 64);
+            v1 += __shfl_down(v1, sft, 64);
+            v2 += __shfl_down(v2, sft, 64);
+            v3 += __shfl_down(v3, sft, 64);
+        }
+        if (lane == 0) {
+            if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
+            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
+            if (v2) atomicAdd(&counters[2], (unsigned long long)v2);
+            if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
+        }
+    }
+    {
+        const int any_whole = __syncthreads_or(whole ? 1 : 0);
+        if (any_whole && is_out) contenders[pix] = word;
+        if (threadIdx.x == 0 && any_whole) worklist_push(j.whole, (uint32_t)U0 | (tid.y << 16) | 0x80000000u);
+    }
+}
+
 // ---- kernel B: exact re-evaluation of the contenders (mod.rs:442-464), in corridor order --------------
 __device__ __forceinline__ void search2_exact_tile(const CorrParams &p, const uint8_t *__restrict__ img1,
                                                    const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
@@ -1828,8 +2318,24 @@ void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipS
         hipLaunchKernelGGL(search3_fallback_kernel<false>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
 }
 
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, hipStream_t s)
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s)
 {
+    // rectified affine pairs under search version 5: the filter on the matrix pipe (search4_mfma_kernel); a pass that counts
+    // candidates (profiling) takes the box kernel - the matrix-pipe walk does not know, value by value, which pixel ends up
+    // re-evaluating its whole corridor
+    if (mfma && !stepped_lines && !transposed && !jobs[0].counters) {
+        uint32_t gx = 0, gy = 0;
+        for (int i = 0; i < n; i++) {
+            const CorrParams &p = jobs[i].p;
+            if (!job_active(jobs[i])) continue;
+            gx = std::max(gx, (p.w1 + S4_TW - 1) / S4_TW);
+            gy = std::max(gy, (p.row1 - p.row0 + S4_TH - 1) / S4_TH);
+        }
+        if (!gx || !gy) return;
+        const dim3 grid(gx, gy, (unsigned)n);
+        hipLaunchKernelGGL(search4_mfma_kernel<false>, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]);
+        return;
+    }
     // lanes along x, 4 rows per workgroup - or, transposed, lanes along y and 4 columns per workgroup
     uint32_t gx = 0, gy = 0;
     for (int i = 0; i < n; i++) {

@@ -117,7 +117,7 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
                    unsigned long long *cand_counter, hipStream_t s);
 void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s);
 void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s);
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, hipStream_t s);
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
@@ -415,7 +415,7 @@ struct cvhip_ctx {
     hipEvent_t level_read[16] = {};    // per level: the last kernels that read the staged images have been enqueued before it
     bool async_readback = false; // cvhip_ctx_set_async_readback
     bool exact_scores = false; // cvhip_ctx_set_exact_scores: every pass writes the reference's scores (tests)
-    int search_version = 3;
+    int search_version = 3; // (5: version 3 with the rectified box launches on the matrix pipe, search4_mfma_kernel - measured slower)
     int range_mode = 0; // search_range_kernel: 0 = integer box sums + chain where needed, 1 = chain only, 2 / 3 = test hooks
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
     // per-direction scratch of a search pass (the two passes of a level are independent: one launch, blockIdx.z picks one)

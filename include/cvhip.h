@@ -270,9 +270,12 @@ int cvhip_ctx_get_kernel_times(cvhip_ctx *ctx, double ms[7], uint32_t launches[7
 int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
 /* Select the search kernel: 1 = every candidate through the exact serial f32 chain, 2 = exact-integer
  * filter per candidate + exact re-evaluation of the contenders, 3 (default) = the same filter evaluated
- * as displacement-plane box sums for whole row segments where the pair is rectified (axis-parallel
- * epipolar lines), with 2 for every other geometry and as the per-workgroup fallback; 4 = 3 with the
- * box kernel launched for every geometry (testing).  All give identical results. */
+ * as displacement-plane box sums for whole row segments where the epipolar lines keep one major axis, with 2 for
+ * every other geometry and as the per-workgroup fallback; 4 = 3 with the box kernel launched for every geometry
+ * (testing); 5 = 3 with the rectified affine launches (exactly axis-parallel row-major lines, five stripes) as int8
+ * matrix products on the matrix pipe (search4_mfma_kernel: the formulation the north star names; bit-exact, and
+ * measured SLOWER than the box sums on MI355X - DESIGN.md section 4.7 - so it is not the default).  All give
+ * identical results. */
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
 /* Which passes write the reference's SCORES.  Match positions are the reference's in every pass, always.  Scores are
  * only observable for the forward grid of the last (full-resolution) level: the reference overwrites every cell a

@@ -180,6 +180,21 @@ def test_per_pass_calls_equal_fused_level_call(gpu_device):
     assert_same_grid(run_gpu(gpu_device, c, fused=False), run_gpu(gpu_device, c, fused=True), "per-pass vs fused")
 
 
+@pytest.mark.parametrize("name", ["h256", "sem320x200", "ragged_dims"])
+def test_matrix_pipe_filter_matches_oracle(gpu_device, oracle, name):
+    """Search version 5: the rectified affine launches as int8 matrix products (search4_mfma_kernel: sixteen positions x
+    sixteen pixels x four target rows per v_mfma_i32_16x16x64_i8, the window sums biased by 128 and corrected exactly) -
+    the same integers as the box filter, so both directions' grids are the oracle's bit for bit; and on a larger pair with
+    disparity discontinuities (workgroups that decline, pixels with more events than their queue holds)."""
+    c = cases.make_case(name)
+    assert_same_grid(run_gpu(gpu_device, c, version=5, both=True)[0], run_oracle(oracle, c, both=True)[0], f"{name} v5 forward")
+    assert_same_grid(run_gpu(gpu_device, c, version=5, both=True)[1], run_oracle(oracle, c, both=True)[1], f"{name} v5 reverse")
+    if name == "h256":
+        a, b, _ = synth.make_pair(1024, 768, seed=77)
+        big = {"img1": a, "img2": b, "F": synth.F_HORIZONTAL, "projection": 0, "steps": synth.optimal_scale_steps(1024, 768)}
+        assert_same_grid(run_gpu(gpu_device, big, version=5), run_gpu(gpu_device, big, version=3), "1024x768 v5 vs v3")
+
+
 @pytest.mark.parametrize("name", ["tilt3_200x150", "persp_240x180", "ragged_dims"])
 def test_fused_level_calls_equal_independent_calls(gpu_device, oracle, name):
     """cvhip_ctx_set_fuse_level_calls: the reference's four calls per level, in the reference's order, executed as one
