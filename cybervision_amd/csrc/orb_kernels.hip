@@ -352,10 +352,11 @@ __device__ __forceinline__ bool blur_valid(uint32_t w, uint32_t h, uint32_t x, u
 // ---------------------------------------------------------------------------------------------
 // patch moments (orb.rs:316-339): one wave per ranked keypoint.  Integer sums are exact, so the
 // wave-parallel reduction equals the reference's serial loop.  out = (m00, m10, m01, valid).
+constexpr uint32_t ORB_BAD_INDEX = 0x80000000u; // in the describe step's open-count word: a sorted corner index was out of range
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void moments_body(const double *__restrict__ blur, uint32_t w, uint32_t h,
                                                       const uint32_t *__restrict__ kp_xy,
-                                                      const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                      const uint32_t *__restrict__ sorted_idx, uint32_t count, uint32_t n_kp,
                                                       unsigned long long *__restrict__ out, double *__restrict__ sincos)
 {
     const uint32_t r = blockIdx.x;
@@ -363,7 +364,9 @@ __device__ __forceinline__ void moments_body(const double *__restrict__ blur, ui
     const uint32_t src = sorted_idx[r];
     const uint32_t lane = threadIdx.x;
     unsigned long long m00 = 0, m10 = 0, m01 = 0;
-    bool ok = src != 0xFFFFFFFFu;
+    // (an index beyond the corner list - a sort that went wrong, see scripts/micro/rocprim_partial_bits_sort.hip - must not
+    // become an address: the keypoint is dropped here and brief_body reports it)
+    bool ok = src != 0xFFFFFFFFu && src < n_kp;
     uint32_t x = 0, y = 0;
     if (ok) {
         x = kp_xy[2 * (size_t)src];
@@ -445,7 +448,7 @@ __device__ __forceinline__ unsigned long long sat_add_signed(unsigned long long 
 
 __device__ __forceinline__ void brief_body(const double *__restrict__ blur, uint32_t w, uint32_t h,
                                                     const uint32_t *__restrict__ kp_xy,
-                                                    const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                    const uint32_t *__restrict__ sorted_idx, uint32_t count, uint32_t n_kp,
                                                     const double *__restrict__ sincos,
                                                     const signed char *__restrict__ pattern,
                                                     uint32_t *__restrict__ desc, uint32_t *__restrict__ flags, double guard,
@@ -460,7 +463,9 @@ __device__ __forceinline__ void brief_body(const double *__restrict__ blur, uint
     const uint32_t lane = threadIdx.x;
     const uint32_t src = sorted_idx[r];
     const double angle_sin = sincos[3 * (size_t)r + 0], angle_cos = sincos[3 * (size_t)r + 1];
-    bool ok = src != 0xFFFFFFFFu && sincos[3 * (size_t)r + 2] != 0.0;
+    const bool in_list = src == 0xFFFFFFFFu || src < n_kp;
+    if (!in_list && lane == 0 && open_count) atomicOr(open_count, ORB_BAD_INDEX); // the host turns this into CVHIP_ERR_DEVICE
+    bool ok = src != 0xFFFFFFFFu && in_list && sincos[3 * (size_t)r + 2] != 0.0;
     uint32_t cx = 0, cy = 0;
     if (ok) {
         cx = kp_xy[2 * (size_t)src];
@@ -604,20 +609,20 @@ __global__ __launch_bounds__(256) void blur_v_kernel(const double *__restrict__ 
 }
 __global__ __launch_bounds__(64) void moments_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
                                                       const uint32_t *__restrict__ kp_xy,
-                                                      const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                      const uint32_t *__restrict__ sorted_idx, uint32_t count, uint32_t n_kp,
                                                       unsigned long long *__restrict__ out, double *__restrict__ sincos)
 {
-    moments_body(blur, w, h, kp_xy, sorted_idx, count, out, sincos);
+    moments_body(blur, w, h, kp_xy, sorted_idx, count, n_kp, out, sincos);
 }
 __global__ __launch_bounds__(64) void brief_kernel(const double *__restrict__ blur, uint32_t w, uint32_t h,
                                                     const uint32_t *__restrict__ kp_xy,
-                                                    const uint32_t *__restrict__ sorted_idx, uint32_t count,
+                                                    const uint32_t *__restrict__ sorted_idx, uint32_t count, uint32_t n_kp,
                                                     const double *__restrict__ sincos,
                                                     const signed char *__restrict__ pattern,
                                                     uint32_t *__restrict__ desc, uint32_t *__restrict__ flags, double guard,
                                                     uint32_t *__restrict__ open_count)
 {
-    brief_body(blur, w, h, kp_xy, sorted_idx, count, sincos, pattern, desc, flags, guard, open_count);
+    brief_body(blur, w, h, kp_xy, sorted_idx, count, n_kp, sincos, pattern, desc, flags, guard, open_count);
 }
 __global__ __launch_bounds__(1024) void final_compact_kernel(const uint32_t *__restrict__ flags,
                                                               const uint32_t *__restrict__ kp_xy,
@@ -727,13 +732,13 @@ __global__ __launch_bounds__(64) void moments_jobs(const OrbJobDev *jobs)
 {
     const OrbJobDev &j = jobs[blockIdx.z];
     if (blockIdx.x >= j.count) return;
-    moments_body(j.blur, j.w, j.h, j.kp, j.idx_sorted, j.count, j.mom, j.sc);
+    moments_body(j.blur, j.w, j.h, j.kp, j.idx_sorted, j.count, j.n_fast, j.mom, j.sc);
 }
 __global__ __launch_bounds__(64) void brief_jobs(const OrbJobDev *jobs, const signed char *__restrict__ pattern, double guard)
 {
     const OrbJobDev &j = jobs[blockIdx.z];
     if (blockIdx.x >= j.count) return;
-    brief_body(j.blur, j.w, j.h, j.kp, j.idx_sorted, j.count, j.sc, pattern, j.desc, j.flags, guard, j.pack + 1);
+    brief_body(j.blur, j.w, j.h, j.kp, j.idx_sorted, j.count, j.n_fast, j.sc, pattern, j.desc, j.flags, guard, j.pack + 1);
 }
 __global__ __launch_bounds__(1024) void final_compact_jobs(const OrbJobDev *jobs)
 {
@@ -1225,7 +1230,7 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             uint32_t *d_out_n = j.d_pack, *d_out_xy = j.xy_dev ? j.out_xy : j.d_pack + 64,
                      *d_out_desc = j.desc_dev ? j.out_desc : j.d_pack + 64 + (size_t)j.out_cap * 2;
             CVHIP_TRY_HIP(hipMemsetAsync(j.d_pack, 0, 8, s)); // {n_out, open count}
-            hipLaunchKernelGGL(brief_kernel, dim3(j.count), dim3(64), 0, s, j.d_blur, j.w, j.h, j.d_kp, j.d_idx_sorted, j.count, j.d_sc,
+            hipLaunchKernelGGL(brief_kernel, dim3(j.count), dim3(64), 0, s, j.d_blur, j.w, j.h, j.d_kp, j.d_idx_sorted, j.count, j.n_fast, j.d_sc,
                                (const signed char *)dev->d.orb_pattern, j.d_desc, j.d_flags, g, j.d_pack + 1);
             hipLaunchKernelGGL(final_compact_kernel, dim3(1), dim3(1024), 0, s, j.d_flags, j.d_kp, j.d_idx_sorted, j.d_desc, j.count,
                                j.out_cap, d_out_xy, d_out_desc, d_out_n);
@@ -1383,7 +1388,7 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             CVHIP_TRY_HIP(mem.alloc(&j.d_pack, j.pack_bytes / sizeof(uint32_t)));
             j.xy_dev = dev_ptr(j.out_xy);
             j.desc_dev = dev_ptr(j.out_desc);
-            hipLaunchKernelGGL(moments_kernel, dim3(j.count), dim3(64), 0, s, j.d_blur, j.w, j.h, j.d_kp, j.d_idx_sorted, j.count, j.d_mom,
+            hipLaunchKernelGGL(moments_kernel, dim3(j.count), dim3(64), 0, s, j.d_blur, j.w, j.h, j.d_kp, j.d_idx_sorted, j.count, j.n_fast, j.d_mom,
                                j.d_sc);
             if (i == 0) report(0.35f);
             if (guard > 0.0) {
@@ -1401,6 +1406,9 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
         // ---- the images with a keypoint inside the guard band (rare), or all of them with the guard off: orientation
         // on the host with libm, exactly as the reference (orb.rs:337-341, 365-366), and their descriptors again
         std::vector<OrbJob *> redo;
+        for (OrbJob &j : jobs)
+            if (j.n_fast && guard > 0.0 && (reinterpret_cast<const uint32_t *>(stage + j.pack_off)[1] & ORB_BAD_INDEX))
+                return fail(CVHIP_ERR_DEVICE, "orb_extract: a sorted corner index is outside the corner list (device sort failed)");
         for (OrbJob &j : jobs)
             if (j.n_fast && (guard <= 0.0 || reinterpret_cast<const uint32_t *>(stage + j.pack_off)[1] != 0u)) redo.push_back(&j);
         if (!redo.empty()) {
