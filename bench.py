@@ -218,7 +218,7 @@ def main():
                     help="dense4096 (default): the headline metric; sfm3: BASELINE config 5, a secondary line")
     ap.add_argument("--pencil", type=int, default=0, choices=[0, 1], help="--config sfm3: 7-point pencil (0 = the reference's thin-SVD rows, 1 = null space)")
     ap.add_argument("--no-extras", action="store_true", help="skip readback / geometry_sweep / sfm3 in the headline line")
-    ap.add_argument("--sweep-tilts", default="3,10,30,60,90", help="tilts (degrees) of geometry_sweep")
+    ap.add_argument("--sweep-tilts", default="3,10,30,45,60,90", help="tilts (degrees) of geometry_sweep")
     args = ap.parse_args()
     if args.config == "sfm3":
         return bench_sfm3(args)
