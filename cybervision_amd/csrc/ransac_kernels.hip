@@ -392,6 +392,113 @@ __host__ __device__ CVHIP_LM_INLINE int levenberg_marquardt7(double (&q)[7], con
     return event ? event : (ok ? 1 : 0);
 }
 
+// The same loop for validate_f's seven observations with the Jacobian never stored: row k's seven entries are folded into
+// g = J'r and the 28 distinct entries of J'J as they are made, k ascending - the order of blas `dot` for seven terms (0 + t0
+// + t1 + ...), and J'J's (i, j) and (j, i) are the same sum of the same products - so every value is levenberg_marquardt<7>'s,
+// bit for bit (the per-sample tests compare the two).  What it saves: J'J is rebuilt only when J changed - a rejected step
+// leaves it as it was, and in the thin-SVD pencil's regime two thirds of the roots only ever have rejected steps - and the
+// 49 Jacobian entries do not live across the trips.  -> 1 = Ok, 0 = Err, LM_EVENT_BUDGET, LM_EVENT_ACCEPTED (stop_on_accept).
+__host__ __device__ CVHIP_LM_INLINE int levenberg_marquardt7_lean(double (&q)[7], const Obs *obs, int budget, bool stop_on_accept)
+{
+    double M[9], g[7], r[7], jj[28];
+    const auto evaluate = [&](const double (&at)[7], double (&into)[7]) {
+        matrix_of(at, M);
+#pragma unroll
+        for (int i = 0; i < 7; i++) into[i] = residual_of(M, obs[i]);
+    };
+    const auto linearise = [&](const double (&at)[7], const double (&res)[7]) { // J'r and J'J at `at`
+        matrix_of(at, M);
+#pragma unroll
+        for (int j = 0; j < 7; j++) g[j] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 28; m++) jj[m] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            double row[7];
+            gradient_of(M, obs[k], row);
+            int m = 0;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                g[i] += row[i] * res[k];
+#pragma unroll
+                for (int j = i; j < 7; j++) jj[m++] += row[i] * row[j];
+            }
+        }
+    };
+    const auto largest = [](const double (&v)[7]) {
+        double m = v[0];
+#pragma unroll
+        for (int j = 1; j < 7; j++)
+            if (m < v[j]) m = v[j];
+        return m;
+    };
+    const auto norm7 = [](const double (&v)[7]) { return sqrt(long_dot(v, 1, v, 1, 7)); };
+
+    evaluate(q, r);
+    linearise(q, r);
+    if (fabs(largest(g)) <= 1e-12) return 1;
+    double mu = 0.0;
+    {
+        int m = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const double djj = jj[m];
+            if (j == 0 || djj >= mu) mu = djj;
+            m += 7 - j;
+        }
+    }
+    mu *= 1e-3;
+    double nu = 2.0;
+    for (int iteration = 0; iteration < 1000; iteration++) {
+        if (iteration >= budget) return LM_EVENT_BUDGET;
+        double A[49], step[7];
+        {
+            int m = 0;
+#pragma unroll
+            for (int i = 0; i < 7; i++)
+#pragma unroll
+                for (int j = i; j < 7; j++) {
+                    A[i * 7 + j] = jj[m];
+                    A[j * 7 + i] = jj[m++];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) A[i * 7 + i] += mu;
+#pragma unroll
+        for (int j = 0; j < 7; j++) step[j] = g[j];
+        if (!solve7(A, step)) return 0;
+        if (norm7(step) <= 1e-12 * (norm7(q) + 1e-12)) return 1;
+        double trial[7], damped[7], r_new[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) trial[j] = q[j] + step[j];
+        evaluate(trial, r_new);
+        const double before = long_dot(r, 1, r, 1, 7);
+        const double after = long_dot(r_new, 1, r_new, 1, 7);
+#pragma unroll
+        for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + g[j];
+        const double rho = (before - after) / long_dot(step, 1, damped, 1, 7);
+        if (rho > 0.0) {
+            if (stop_on_accept) return LM_EVENT_ACCEPTED;
+            const bool converged = sqrt(before) - sqrt(after) < 0.0 * sqrt(before);
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                r[j] = r_new[j];
+                q[j] = trial[j];
+            }
+            linearise(q, r);
+            if (converged || fabs(largest(g)) <= 1e-12) return 1;
+            const double w = 2.0 * rho - 1.0, shrink = 1.0 - w * w * w;
+            mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
+            nu = 2.0;
+        } else {
+            mu *= nu;
+            nu *= 2.0;
+        }
+        if (sqrt(long_dot(r, 1, r, 1, 7)) <= 1e-12) return 1;
+    }
+    return 0; // "Levenberg-Marquardt failed to converge"
+}
+
 // optimize_perspective_f (:391-426): F (normalised by F[2][2]) -> out, false = None
 __host__ __device__ inline bool optimize_perspective_f(const double (&F)[9], const Obs *obs, uint32_t n, double *r,
                                                        double *r_new, double *J, double (&out)[9])
@@ -2079,7 +2186,7 @@ __global__ __launch_bounds__(64) void ransac_lm_start_kernel(const PerspPencil *
     double q[7];
 #pragma unroll
     for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
-    const int status = lm::levenberg_marquardt7(q, obs, 1000, true);
+    const int status = lm::levenberg_marquardt7_lean(q, obs, 1000, true);
     if (status == lm::LM_EVENT_ACCEPTED) {
         next[1u + atomicAdd(&next[0], 1u)] = g; // (F[g] still holds the start parameters)
         return;
@@ -2112,7 +2219,7 @@ __global__ __launch_bounds__(64) void ransac_lm_run_kernel(const PerspPencil *__
     double q[7];
 #pragma unroll
     for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
-    const int status = lm::levenberg_marquardt7(q, obs, budget);
+    const int status = lm::levenberg_marquardt7_lean(q, obs, budget, false);
     const double nan = __builtin_nan("");
     if (status == lm::LM_EVENT_BUDGET) {
         if (!late_list) {
@@ -2597,7 +2704,9 @@ hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double
                              double *d_F_out, hipStream_t s);
 // Hypotheses are generated GEN_BATCH rounds at a time (the generator kernels are bound by the latency of their serial f64
 // work on too few threads for the chip - 50 000 samples are 782 waves - so two rounds in one launch take what one
-// takes), into one of GEN_DEPTH buffers: the batch being scored and the two that may be generated ahead of it.
+// takes), into one of GEN_DEPTH buffers: the batch being scored and the two that may be generated ahead of it.  (Five - a buffer
+// per batch of the reference's twenty rounds - changed nothing for the thin-SVD pencil: 52.2 ms either way; what holds a
+// generator stream back there is the scoring chain's counting kernel when the two share a hardware pipe.)
 constexpr uint32_t GEN_BATCH = 4, GEN_DEPTH = 3;
 // The call's stragglers (thin-SVD pencil; batched scoring only): roots whose Levenberg-Marquardt loop outlasts the thread
 // kernels' budget - a handful per 100 000, but each keeps ONE wave busy for up to 1000 trips (~5 ms), and run inside their
@@ -2680,7 +2789,8 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // round ends (the latter are single-workgroup kernels: 20 - 70 us of an otherwise idle chip each).
     const bool score_batches = !may_exit_early;
     constexpr uint32_t GEN_STREAMS = 2;
-    static_assert(GEN_DEPTH <= sizeof(Device::RansacQueues::ready) / sizeof(hipEvent_t), "Device holds two side streams and RansacQueues' events");
+    static_assert(GEN_DEPTH + 2 <= sizeof(Device::RansacQueues::ready) / sizeof(hipEvent_t), // (ready[6], ready[7]: the stragglers' events)
+                  "Device holds two side streams and RansacQueues' events");
     Device::RansacQueues &rq = dev->d.rq; // (kept on the handle: created once)
     hipStream_t g[GEN_STREAMS] = {};
     for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = aux_stream(dev->d, (int)k, &g[k]);
