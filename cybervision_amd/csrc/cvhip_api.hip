@@ -315,6 +315,10 @@ static int stage_images(cvhip_ctx *c, int k, const uint8_t *img1, size_t n1, con
             continue;
         }
         host_copy(ring, src[i], n[i]);
+        if (!c->pool_waited) { // (the pool's clearing at context creation is work of the context's stream)
+            if (c->pool_ready) CVHIP_TRY_HIP(hipStreamWaitEvent(d.rb.stream, c->pool_ready, 0));
+            c->pool_waited = true;
+        }
         if (!waited_readers && k < 16 && c->level_read[k]) {
             CVHIP_TRY_HIP(hipStreamWaitEvent(d.rb.stream, c->level_read[k], 0));
             waited_readers = true;
@@ -864,7 +868,11 @@ int cvhip_ctx_create(cvhip_device *dev, uint32_t w1, uint32_t h1, uint32_t w2, u
     if (e == hipSuccess) e = hipMemsetAsync(c->d_cand, 0, 4 * sizeof(unsigned long long), dev->d.stream);
     for (int d = 0; d < 2 && e == hipSuccess; d++)
         e = hipMemsetAsync(c->img[d], 0, img_pool_bytes(c->max_px), dev->d.stream);
+    // (host level images are uploaded on the handle's COPY stream: it must not overtake the clearing above)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pool_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(c->pool_ready, dev->d.stream);
     if (e != hipSuccess) {
+        if (c->pool_ready) (void)hipEventDestroy(c->pool_ready);
         free_ctx_buffers(c);
         delete c;
         return fail(e == hipErrorOutOfMemory ? CVHIP_ERR_NOMEM : CVHIP_ERR_DEVICE,
@@ -882,6 +890,7 @@ void cvhip_ctx_destroy(cvhip_ctx *ctx)
     (void)hipStreamSynchronize(ctx->dev->d.stream);
     for (hipEvent_t &ev : ctx->level_read)
         if (ev) (void)hipEventDestroy(ev);
+    if (ctx->pool_ready) (void)hipEventDestroy(ctx->pool_ready);
     free_ctx_buffers(ctx, true); // the buffer set is parked on the device handle for the next pair
     delete ctx;
 }

@@ -413,6 +413,8 @@ struct cvhip_ctx {
     } calls;
     bool staged_from_pageable = false; // the last stage_images copied straight from the caller's pageable memory (no ring)
     hipEvent_t level_read[16] = {};    // per level: the last kernels that read the staged images have been enqueued before it
+    hipEvent_t pool_ready = nullptr;   // the image pool has been cleared (context creation, on the context's stream): the copy
+    bool pool_waited = false;          // stream waits for it before its first upload into the pool
     bool async_readback = false; // cvhip_ctx_set_async_readback
     bool exact_scores = false; // cvhip_ctx_set_exact_scores: every pass writes the reference's scores (tests)
     int search_version = 3; // (5: version 3 with the rectified box launches on the matrix pipe, search4_mfma_kernel - measured slower)

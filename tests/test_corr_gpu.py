@@ -236,6 +236,30 @@ def test_fused_level_calls_equal_independent_calls(gpu_device, oracle, name):
         assert_same_grid(got[1], want[1], f"{name} fused calls ({mode}) reverse")
 
 
+def test_host_images_into_fresh_contexts(gpu_device, oracle):
+    """Host level images are uploaded on the handle's copy stream into a pool that the context's creation clears on the
+    CONTEXT's stream: the first upload must wait for that clearing (a race that a randomised sweep caught in 13 of 250
+    cases - whole grids wrong - and no fixed-size test did: contexts of dimensions seen before reuse parked buffers whose
+    clearing is long done).  Fresh dimensions every time, host images, level call and four fused calls."""
+    rng = np.random.default_rng(7)
+    for it in range(14):
+        w, h = int(rng.integers(96, 260)), int(rng.integers(96, 200))
+        a, b, _ = synth.make_pair(w, h, seed=100 + it)
+        c = {"img1": a, "img2": b, "F": synth.F_HORIZONTAL, "projection": 0, "steps": synth.optimal_scale_steps(w, h)}
+        want = run_oracle(oracle, c)
+        p1, p2 = cases.pyramids(c)
+        pc = correlation.PointCorrelations(gpu_device, (w, h), (w, h), c["F"])
+        try:
+            if it & 1:
+                pc.set_fuse_level_calls(True)
+            for i in range(c["steps"] + 1):
+                k = c["steps"] - i
+                pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=not (it & 1))
+            assert_same_grid(pc.complete(), want, f"fresh context {w}x{h}")
+        finally:
+            pc.close()
+
+
 def test_fused_level_calls_out_of_order(gpu_device, oracle):
     """A caller that has promised the reference's call order and departs from it still gets every call executed: grids
     read between the calls (complete() after each), a forward call whose reverse call never comes, a reverse call with

@@ -47,13 +47,19 @@ for it in range(N):
     steps = synth.optimal_scale_steps(a.shape[1], a.shape[0])
     p1, p2 = synth.box_pyramid(a, steps), synth.box_pyramid(b, steps)
     want = cvref.correlate_dense(p1, p2, F, proj)
-    for version in (3, 4):
+    # (5: the rectified affine launches on the matrix pipe; everything else of a version-5 run is version 3's)
+    for version in (3, 4, 5):
         pc = correlation.PointCorrelations(dev, (a.shape[1], a.shape[0]), (b.shape[1], b.shape[0]), F,
                                            correlation.ProjectionMode(proj))
         pc.set_search_version(version)
+        # every other case goes through the reference's four calls per level, executed as one level
+        # (cvhip_ctx_set_fuse_level_calls; host images: the upload ring)
+        four_calls = bool((it + version) & 1)
+        if four_calls:
+            pc.set_fuse_level_calls(True)
         for i in range(steps + 1):
             k = steps - i
-            pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+            pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=not four_calls)
         got = pc.complete()
         pc.close()
         ok = (got[0] == want[0]).all()
@@ -61,7 +67,7 @@ for it in range(N):
         ok = ok and (got[1].view(np.uint32)[v] == want[1].view(np.uint32)[v]).all()
         if not ok:
             bad += 1
-            print(f"MISMATCH it={it} version={version} {w}x{h} b={b.shape} tilt={tilt} consistent={consistent} seed={seed} "
+            print(f"MISMATCH it={it} version={version} four_calls={four_calls} {w}x{h} b={b.shape} tilt={tilt} consistent={consistent} seed={seed} "
                   f"proj={proj} diff_cells={(got[0] != want[0]).any(axis=-1).sum()}")
     if it % 10 == 9:
         print(f"{it + 1} cases, {bad} mismatches", flush=True)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised check of the perspective RANSAC's two scoring schedules: with a listener that wants the count after every
-round the rounds are scored one by one, in order; without one, batches of rounds are scored as one round each and in the
-order their generators finish.  Both must give the same matrix and the same inlier mask for every match
-set, seed and run.   usage: fuzz_ransac.py [cases] [seed]"""
+"""Randomised check of the perspective RANSAC's schedules: batches of rounds scored as their generators
+finish (the host polls), in order behind their events (cvhip_ransac_set_in_order), with and without the reference's
+listener - the same matrix and the same inlier mask for every match set, seed and run, for both 7-point pencils (even cases:
+the reference's thin-SVD rows, odd cases: the null space).   usage: fuzz_ransac.py [cases] [seed]"""
 import sys
 from pathlib import Path
 
@@ -39,22 +39,25 @@ for it in range(N):
     m, truth, _, _ = cases.perspective_matches(n=n, outlier_frac=frac, seed=int(rng.integers(1, 10000)), size=size)
     seed = int(rng.integers(0, 1 << 30))
     fmx = fundamentalmatrix.FundamentalMatrix(fundamentalmatrix.ProjectionMode.Perspective, float(size))
+    fundamentalmatrix.set_pencil(dev, it & 1)
     try:
         F0, _, mask0 = fmx.find_ransac(dev, m, seed=seed, progress_listener=Listener())
     except Exception as ex:  # no model: both schedules must agree on that too
         F0, mask0 = None, str(ex)
     for rep in range(2):
+        fundamentalmatrix.set_in_order(dev, rep == 1)
         try:
             F1, _, mask1 = fmx.find_ransac(dev, m, seed=seed)
         except Exception as ex:
             F1, mask1 = None, str(ex)
+        fundamentalmatrix.set_in_order(dev, False)
         same = (F0 is None and F1 is None and mask0 == mask1) or (
             F0 is not None and F1 is not None and np.array_equal(F0, F1) and np.array_equal(mask0, mask1))
         if not same:
             bad += 1
             print(f"MISMATCH case {it} rep {rep}: n={n} outliers={frac:.2f} size={size} seed={seed}")
     inl = int(np.asarray(mask0).sum()) if F0 is not None else -1
-    print(f"case {it}: n={n} outliers={frac:.2f} size={size} inliers={inl} of {int(truth.sum())} true", flush=True)
+    print(f"case {it}: pencil={it & 1} n={n} outliers={frac:.2f} size={size} inliers={inl} of {int(truth.sum())} true", flush=True)
 dev.close()
 print(f"done: {N} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
