@@ -273,12 +273,18 @@ static void host_copy(uint8_t *dst, const uint8_t *src, size_t bytes)
     }
     std::thread th[3];
     const size_t chunk = ((bytes / parts) + 4095) & ~(size_t)4095;
-    for (size_t i = 1; i < parts; i++) {
-        const size_t off = i * chunk, len = std::min(chunk, bytes - std::min(bytes, off));
-        th[i - 1] = std::thread([=] { if (off < bytes) std::memcpy(dst + off, src + off, len); });
+    size_t started = 1;
+    for (; started < parts; started++) {
+        const size_t off = started * chunk, len = std::min(chunk, bytes - std::min(bytes, off));
+        try {
+            th[started - 1] = std::thread([=] { if (off < bytes) std::memcpy(dst + off, src + off, len); });
+        } catch (...) { // no thread to be had: this one copies the rest itself (nothing may be thrown across the C ABI)
+            break;
+        }
     }
     std::memcpy(dst, src, std::min(chunk, bytes));
-    for (size_t i = 1; i < parts; i++) th[i - 1].join();
+    if (started < parts && started * chunk < bytes) std::memcpy(dst + started * chunk, src + started * chunk, bytes - started * chunk);
+    for (size_t i = 1; i < started; i++) th[i - 1].join();
 }
 
 // Level images of a call (transfer_in_images, gpu/mod.rs:274) -> c->cur_img[]:
