@@ -46,6 +46,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DOT4_PEAK_TMACS = 256 * 4 * 64 * 4 / 4 * 2.4e9 / 1e12   # = 157.3 T multiply-adds/s, the filter kernel's roof
 
 
+RESULT_BANDS = 6                 # cvhip_ctx_set_result_bands in the host-destination modes (scripts/result_bands_probe.py)
 SEARCH_KERNEL = "search3_box_kernel"   # the kernel class "search" times (search version 3, the default)
 
 
@@ -447,6 +448,20 @@ def main():
         dev.synchronize()
         rb_sync_ms = (time.perf_counter() - t1) * 1e3 / rb_steps
         same_host = bool(torch.equal(host[(rb_steps - 1) & 1][0], out_xy.cpu()))
+        # (c) per pair as (a), the last level in result bands (cvhip_ctx_set_result_bands): band b on its way to the host
+        #     while the bands behind it are searched
+        pc.set_result_bands(RESULT_BANDS)
+        step_host(0)
+        step_host(1)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(rb_steps):
+            step_host(i)
+        dev.synchronize()
+        rb_band_ms = (time.perf_counter() - t1) * 1e3 / rb_steps
+        live_bands = pc.result_bands()
+        same_host = same_host and bool(torch.equal(host[(rb_steps - 1) & 1][0], out_xy.cpu()))
+        pc.set_result_bands(1)
         pc.set_async_readback(True)
         step_host(0)
         dev.synchronize()
@@ -459,11 +474,14 @@ def main():
         same_host = same_host and bool(torch.equal(host[(rb_steps - 1) & 1][0], out_xy.cpu()))
         mpx_ = W * H / 1e6
         readback = {"t_dense_with_readback_ms": round(rb_sync_ms, 4), "mpixels_per_s_with_readback": round(mpx_ / (rb_sync_ms / 1e3), 1),
+                    "t_dense_with_readback_banded_ms": round(rb_band_ms, 4), "result_bands": live_bands,
+                    "mpixels_per_s_with_readback_banded": round(mpx_ / (rb_band_ms / 1e3), 1),
                     "t_dense_with_readback_pipelined_ms": round(rb_pipe_ms, 4),
                     "mpixels_per_s_with_readback_pipelined": round(mpx_ / (rb_pipe_ms / 1e3), 1),
                     "bytes_to_host_per_pair": W * H * 12, "steps": rb_steps, "host_grid_equals_device_grid": same_host,
-                    "note": "complete() into page-locked host memory (12 B/px: int32 x, y + f32 score); pipelined = the "
-                            "transfer of pair i under the search of pair i+1 (cvhip_ctx_set_async_readback)"}
+                    "note": "complete() into page-locked host memory (12 B/px: int32 x, y + f32 score); banded = the last level in "
+                            "row bands, each copied out under the search of the bands behind it (cvhip_ctx_set_result_bands); "
+                            "pipelined = the transfer of pair i under the search of pair i+1 (cvhip_ctx_set_async_readback)"}
         del host
 
         # ---- The reference's real call modes.  PointCorrelations::correlate_images issues FOUR
@@ -480,12 +498,16 @@ def main():
         pcb = correlation.PointCorrelations(dev, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
         pcb.set_fuse_level_calls(True)  # (what the binding's GpuContext::new does: INTEGRATION.md)
 
+        hcells = np.empty((H, W), dtype=np.uint32)
+
         def pair(p1, p2, fused, to_host):
             pcb.first_pass = True
             for j in range(steps + 1):
                 k = steps - j
                 pcb.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=fused)
-            if to_host:
+            if to_host == "packed":
+                pcb.complete_packed(out_cells=hcells, out_corr=hcorr)
+            elif to_host:
                 pcb.complete(out_xy=hxy, out_corr=hcorr)
             else:
                 pcb.complete(out_xy=out_xy, out_corr=out_corr)
@@ -500,23 +522,32 @@ def main():
             return (time.perf_counter() - t1) * 1e3 / n
 
         want_xy = out_xy.cpu().numpy()
-        ms_4h = timed_pairs(hp1, hp2, False, True)
+        ms_4h_flat = timed_pairs(hp1, hp2, False, True)   # (round 3's figure: the whole grid copied out behind the last level)
         same_b = bool((hxy == want_xy).all())
+        pcb.set_result_bands(RESULT_BANDS)  # (the binding's setting: the grid always goes to the host there)
+        ms_4h = timed_pairs(hp1, hp2, False, True)
+        same_b = same_b and bool((hxy == want_xy).all()) and pcb.result_bands() == RESULT_BANDS
+        ms_4hp = timed_pairs(hp1, hp2, False, "packed")
+        same_b = same_b and bool((correlation.PointCorrelations.unpack_cells(hcells) == want_xy).all())
         ms_lh = timed_pairs(hp1, hp2, True, True)
         same_b = same_b and bool((hxy == want_xy).all())
+        pcb.set_result_bands(1)
         pcb.set_borrow_inputs(True)
         pcb.set_stats_ahead(True)
         ms_4d = timed_pairs(d1, d2, False, False)
         same_b = same_b and bool(torch.equal(out_xy.cpu(), torch.from_numpy(want_xy)))
         pcb.close()
         boundary_path = {"four_call_host_ms": round(ms_4h, 3), "four_call_host_mpixels_per_s": round(W * H / 1e6 / (ms_4h / 1e3), 1),
+                         "four_call_host_packed_cells_ms": round(ms_4hp, 3), "four_call_host_one_band_ms": round(ms_4h_flat, 3),
+                         "result_bands": RESULT_BANDS,
                          "level_call_host_ms": round(ms_lh, 3), "four_call_device_ms": round(ms_4d, 3),
                          "four_call_device_vs_headline": round(ms_4d / (dt * 1e3 / args.steps), 3),
                          "results_equal_headline": same_b,
                          "note": "per level cvhip_correlate_images x2 + cvhip_cross_check_filter x2 (correlation/mod.rs:217-245), then "
-                                 "cvhip_complete; host = pageable level images in, pageable grid out (44 MB up, 201 MB down per pair); "
+                                 "cvhip_complete; host = pageable level images in, pageable grid out (44 MB up, 201 MB down per pair; packed cells: "
+                                 "cvhip_complete_packed, 134 MB down), the last level in result bands (one_band: without); "
                                  "device = the headline's resident pyramid and resident grid through the same four calls"}
-        del hp1, hp2, hxy, hcorr
+        del hp1, hp2, hxy, hcorr, hcells
 
     pc.close()
     pc = None

@@ -44,6 +44,7 @@ SIGNATURES = {
                                         _vp]),
     "cvhip_complete": (C.c_int, [_vp, _vp, _vp]),
     "cvhip_complete_dir": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "cvhip_complete_packed": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "cvhip_triangulate_affine": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cvhip_extend_tracks": (C.c_int, [_vp, _vp, C.c_uint64, _u32, _vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cvhip_ctx_set_row_shard": (C.c_int, [_vp, _u32, _u32, ALLGATHER_FN, _vp]),
@@ -65,6 +66,8 @@ SIGNATURES = {
     "cvhip_ctx_set_range_mode": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_exact_scores": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_async_readback": (C.c_int, [_vp, C.c_int]),
+    "cvhip_ctx_set_result_bands": (C.c_int, [_vp, C.c_uint32]),
+    "cvhip_ctx_get_result_bands": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "cvhip_ctx_set_search_version": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_borrow_inputs": (C.c_int, [_vp, C.c_int]),
     "cvhip_ctx_set_fuse_level_calls": (C.c_int, [_vp, C.c_int]),

@@ -153,6 +153,30 @@ class PointCorrelations:
             self.correlated_points = (out_xy, out_corr)
         return out_xy, out_corr
 
+    def complete_packed(self, direction: CorrelationDirection = CorrelationDirection.Forward, out_cells=None, out_corr=None):
+        """cvhip_complete_packed: (cells[h, w] uint32 = y2 << 16 | x2 with 0xFFFFFFFF = None, corr[h, w] f32) - 8 bytes per
+        cell over PCIe instead of 12; unpack_cells gives complete()'s xy."""
+        w, h = (self.w1, self.h1) if direction == CorrelationDirection.Forward else (self.w2, self.h2)
+        if out_cells is None:
+            out_cells = np.empty((h, w), dtype=np.uint32)
+            out_corr = np.empty((h, w), dtype=np.float32)
+        pxy = C.c_void_p(out_cells.data_ptr() if hasattr(out_cells, "data_ptr") else out_cells.ctypes.data)
+        pc = None
+        if out_corr is not None:
+            pc = C.c_void_p(out_corr.data_ptr() if hasattr(out_corr, "data_ptr") else out_corr.ctypes.data)
+        _lib.check(_lib.lib().cvhip_complete_packed(self._h, int(direction), pxy, pc), "cvhip_complete_packed")
+        return out_cells, out_corr
+
+    @staticmethod
+    def unpack_cells(cells):
+        """[h, w] uint32 packed cells -> [h, w, 2] int32 (x, y), (-1, -1) = None."""
+        cells = np.asarray(cells)
+        xy = np.empty(cells.shape + (2,), dtype=np.int32)
+        none = cells == 0xFFFFFFFF
+        xy[..., 0] = np.where(none, -1, (cells & 0xFFFF).astype(np.int32))
+        xy[..., 1] = np.where(none, -1, (cells >> 16).astype(np.int32))
+        return xy
+
     def triangulate_affine(self):
         """AffineTriangulation::triangulate (triangulation.rs:268-330) straight from the device grid:
         -> (points3d[n, 3] float64 = (x, y, |p1 - p2|), p2[n, 2] uint32), one row per Some cell in scan order."""
@@ -232,6 +256,17 @@ class PointCorrelations:
         """complete() into page-locked HOST arrays returns once the copies are enqueued; they are complete after
         device.synchronize() (include/cvhip.h)."""
         _lib.check(_lib.lib().cvhip_ctx_set_async_readback(self._h, int(enable)), "cvhip_ctx_set_async_readback")
+
+    def set_result_bands(self, bands: int):
+        """cvhip_ctx_set_result_bands: the last level in row bands, each copied out to a HOST destination under the search
+        of the bands behind it (same result; include/cvhip.h)."""
+        _lib.check(_lib.lib().cvhip_ctx_set_result_bands(self._h, bands), "cvhip_ctx_set_result_bands")
+
+    def result_bands(self) -> int:
+        """How many bands the grid now held went out in (1 = not banded)."""
+        n = C.c_uint32(0)
+        _lib.check(_lib.lib().cvhip_ctx_get_result_bands(self._h, C.byref(n)), "cvhip_ctx_get_result_bands")
+        return int(n.value)
 
     def set_exact_scores(self, all_passes: bool):
         """Scores of EVERY pass are the reference's bits (default: only the observable ones - the forward pass at

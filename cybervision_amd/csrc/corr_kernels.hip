@@ -2495,14 +2495,15 @@ void launch_cross_check_pair(uint32_t *fwd, uint32_t *rev, uint32_t fw, uint32_t
 // once at complete(): full-res cell (x << k, y << k) = level cell (x, y) with the match scaled
 // back by round(x2 / scale) = x2 << k.  All other full-res cells are None.
 // ---------------------------------------------------------------------------------------------
+template <bool PACKED>
 __global__ __launch_bounds__(256) void expand_grid_kernel(const uint32_t *__restrict__ cells, const float *__restrict__ scores,
                                                            uint32_t lw, uint32_t lh,
-                                                           uint32_t k, uint32_t gw, uint32_t gh,
+                                                           uint32_t k, uint32_t gw, uint32_t gy0, uint32_t gy1,
                                                            int32_t *__restrict__ out_xy, float *__restrict__ out_corr)
 {
     const uint32_t gx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t gy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (gx >= gw || gy >= gh) return;
+    const uint32_t gy = gy0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (gx >= gw || gy >= gy1) return;
     int32_t ox = -1, oy = -1;
     float oc = __builtin_nanf("");
     const uint32_t mask = (1u << k) - 1u;
@@ -2518,15 +2519,24 @@ __global__ __launch_bounds__(256) void expand_grid_kernel(const uint32_t *__rest
         }
     }
     const size_t o = (size_t)gy * gw + gx;
-    reinterpret_cast<int2 *>(out_xy)[o] = make_int2(ox, oy);
+    if (PACKED) // one word per cell: y << 16 | x, all ones = None (the coordinates are below 65536: check_level_args)
+        reinterpret_cast<uint32_t *>(out_xy)[o] = ox < 0 ? CELL_NONE : ((uint32_t)oy << 16 | (uint32_t)ox);
+    else
+        reinterpret_cast<int2 *>(out_xy)[o] = make_int2(ox, oy);
     if (out_corr) out_corr[o] = oc;
 }
 
+// rows [gy0, min(gy1, gh)) of the full-resolution grid
 void launch_expand_grid(const uint32_t *cells, const float *scores, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
-                        int32_t *out_xy, float *out_corr, hipStream_t s)
+                        int32_t *out_xy, float *out_corr, hipStream_t s, uint32_t gy0, uint32_t gy1, bool packed)
 {
-    dim3 grid((gw + 63) / 64, (gh + 3) / 4);
-    hipLaunchKernelGGL(expand_grid_kernel, grid, dim3(256), 0, s, cells, scores, lw, lh, k, gw, gh, out_xy, out_corr);
+    gy1 = std::min(gy1, gh);
+    if (gy1 <= gy0) return;
+    dim3 grid((gw + 63) / 64, (gy1 - gy0 + 3) / 4);
+    if (packed)
+        hipLaunchKernelGGL(expand_grid_kernel<true>, grid, dim3(256), 0, s, cells, scores, lw, lh, k, gw, gy0, gy1, out_xy, out_corr);
+    else
+        hipLaunchKernelGGL(expand_grid_kernel<false>, grid, dim3(256), 0, s, cells, scores, lw, lh, k, gw, gy0, gy1, out_xy, out_corr);
 }
 
 // ---------------------------------------------------------------------------------------------

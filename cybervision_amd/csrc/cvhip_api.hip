@@ -358,7 +358,7 @@ struct PassPlan {
 };
 
 static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2, float scale,
-                     int k, int first_pass, int dir, PassPlan &plan)
+                     int k, int first_pass, int dir, PassPlan &plan, const uint32_t *rows = nullptr)
 {
     DirState &ds = c->dir[dir];
     if (lw1 != (ds.gw >> k) || lh1 != (ds.gh >> k))
@@ -422,6 +422,10 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
         p.row1 = std::min(r[1], lh1);
     } else {
         shard_rows(c, lh1, &p.row0, &p.row1);
+    }
+    if (rows) { // (the last level in result bands: level_search)
+        p.row0 = std::min(rows[0], lh1);
+        p.row1 = std::min(rows[1], lh1);
     }
     plan.dir = dir;
     plan.lw = lw1;
@@ -568,6 +572,7 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
 static void commit_pass(cvhip_ctx *c, const PassPlan &plan)
 {
     DirState &ds = c->dir[plan.dir];
+    c->live_bands = 0; // (level_search sets it again behind its own commits)
     ds.cur = plan.next;
     ds.valid = true;
     ds.scores_valid = plan.job.p.need_scores != 0 || plan.kind == PassPlan::EXACT_V1; // (the plain kernel scores every pixel)
@@ -588,6 +593,7 @@ static int search_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, u
 
 static int cross_check_pass(cvhip_ctx *c, int k, int dir)
 {
+    if (dir == 0) c->live_bands = 0; // (the forward grid changes on the context's stream)
     DirState &own = c->dir[dir];
     DirState &other = c->dir[1 - dir];
     if (!own.valid || !other.valid) return fail(CVHIP_ERR_INVALID, "cross_check_filter before both passes ran");
@@ -897,6 +903,8 @@ void cvhip_ctx_destroy(cvhip_ctx *ctx)
     for (hipEvent_t &ev : ctx->level_read)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->pool_ready) (void)hipEventDestroy(ctx->pool_ready);
+    for (hipEvent_t &ev : ctx->band_done)
+        if (ev) (void)hipEventDestroy(ev);
     free_ctx_buffers(ctx, true); // the buffer set is parked on the device handle for the next pair
     delete ctx;
 }
@@ -910,6 +918,7 @@ void cvhip_ctx_destroy(cvhip_ctx *ctx)
 // the same launches), level_cross (both cross-checks in one launch).  Without that promise the per-pass calls are
 // executed independently, each for itself, as before.
 // ---------------------------------------------------------------------------------------------------------------
+static bool host_minor_offset_bound(const cvhip_ctx *c, int dir, int k, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2, double *bound);
 namespace {
 struct LevelStats { // what level_begin leaves for the level's search launches
     bool ahead = false;          // the statistics run on the side stream (cvhip_ctx_set_stats_ahead)
@@ -994,7 +1003,7 @@ int level_begin(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, c
 
 // Both search passes of the level (mod.rs:224-237), in the same launches, and - row-shard mode - the all-gathers.
 // (w1, h1) / (w2, h2): the FORWARD call's images.
-int level_search(cvhip_ctx *ctx, uint32_t w1, uint32_t h1, uint32_t w2, uint32_t h2, float scale, int k, int first_pass, bool sharded,
+int level_search(cvhip_ctx *ctx, bool with_filters, uint32_t w1, uint32_t h1, uint32_t w2, uint32_t h2, float scale, int k, int first_pass, bool sharded,
                  const LevelStats &ls, cvhip_progress_fn progress, void *user)
 {
     hipStream_t s = ctx->dev->d.stream;
@@ -1025,6 +1034,63 @@ int level_search(cvhip_ctx *ctx, uint32_t w1, uint32_t h1, uint32_t w2, uint32_t
         if (fence_hook) CVHIP_TRY_HIP(hipDeviceSynchronize());
         return CVHIP_OK;
     };
+    ctx->live_bands = 0;
+    ctx->bands_crossed = false;
+    // The last level in result bands (cvhip_ctx_set_result_bands): the two search passes of rows [r_b, r_b+1), then the
+    // forward filter of rows [r_b - E, r_b+1 - E) - a filtered cell reads the unfiltered reverse cells within D + 4 rows of
+    // its own (mod.rs:588-624), all of them searched by then - and an event; the last filter runs to the grid's end.  Only
+    // where the geometry is row-local (the bound D of independent-band mode) and the bands are tall enough; the reverse
+    // filter of the last level is deferred anyway (rev_cross_check_pending).
+    uint32_t nb = 1, reach = 0;
+    if (with_filters && k == 0 && !first_pass && ctx->result_bands > 1 && !sharded && !ctx->band_mode && !ctx->time_kernels &&
+        !ctx->count_candidates && h1 == h2) {
+        double df = 0.0, dr = 0.0;
+        if (host_minor_offset_bound(ctx, 0, 0, w1, h1, w2, h2, &df) && host_minor_offset_bound(ctx, 1, 0, w2, h2, w1, h1, &dr)) {
+            reach = ((uint32_t)std::max(df, dr) + CROSS_CHECK_SEARCH_AREA + 4 + 3) / 4 * 4;
+            nb = std::min<uint32_t>(ctx->result_bands, 16u);
+            while (nb > 1 && (h1 / nb) / 4 * 4 < 2 * reach + 64) nb--;
+        }
+    }
+    if (nb > 1) {
+        uint32_t rows[17];
+        for (uint32_t b = 0; b <= nb; b++) {
+            rows[b] = b == nb ? h1 : (uint32_t)((uint64_t)h1 * b / nb) / 4u * 4u;
+            ctx->band_rows[b] = (b == 0 || b == nb) ? rows[b] : rows[b] - reach; // (the filter's and the copy's bands)
+        }
+        int rc = CVHIP_OK;
+        // (every band is planned against the grids' state before the level; committed once the first band is out)
+        PassPlan plans[16][2];
+        for (uint32_t b = 0; b < nb && rc == CVHIP_OK; b++) {
+            rc = plan_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, plans[b][0], &rows[b]);
+            if (rc == CVHIP_OK) rc = plan_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, plans[b][1], &rows[b]);
+        }
+        for (uint32_t b = 0; b < nb && rc == CVHIP_OK; b++) {
+            // (work-list counts: band 0 finds them cleared like any level, the filter clears them for the band behind it)
+            rc = launch_passes(ctx, plans[b], 2, false, s, b == 0 ? ls.done : nullptr);
+            if (rc != CVHIP_OK) break;
+            if (b == 0) {
+                commit_pass(ctx, plans[0][0]);
+                commit_pass(ctx, plans[0][1]);
+            }
+            DirState &df_ = ctx->dir[0], &dr_ = ctx->dir[1];
+            rc = timed(ctx, cvhip_ctx::K_CROSS, [&] {
+                launch_cross_check_pair(df_.cells[df_.cur], dr_.cells[dr_.cur], df_.lw, df_.lh, dr_.lw, dr_.lh, ctx->band_rows[b],
+                                        ctx->band_rows[b + 1], 0u, 0u, s, (b + 1 < nb || ls.ahead) ? ctx->work : nullptr);
+            });
+            if (rc == CVHIP_OK && !ctx->band_done[b] && hipEventCreateWithFlags(&ctx->band_done[b], hipEventDisableTiming) != hipSuccess)
+                rc = fail(CVHIP_ERR_DEVICE, "hipEventCreate (result band)");
+            if (rc == CVHIP_OK && hipEventRecord(ctx->band_done[b], s) != hipSuccess) rc = fail(CVHIP_ERR_DEVICE, "hipEventRecord (result band)");
+        }
+        if (rc != CVHIP_OK && ls.done) (void)hipStreamWaitEvent(s, ls.done, 0);
+        if (rc == CVHIP_OK) rc = mark_level_read(ctx, k, s);
+        CVHIP_TRY(rc);
+        ctx->rev_cross_check_pending = true;
+        ctx->live_bands = nb;
+        ctx->bands_crossed = true;
+        report(progress, user, 0, 1.0f);
+        report(progress, user, 1, 1.0f);
+        return CVHIP_OK;
+    }
     PassPlan plans[2];
     int rc = plan_pass(ctx, 0, 1, w1, h1, w2, h2, scale, k, first_pass, 0, plans[0]);                 // mod.rs:224-230
     if (rc == CVHIP_OK) rc = plan_pass(ctx, 1, 0, w2, h2, w1, h1, scale, k, first_pass, 1, plans[1]); // mod.rs:231-237
@@ -1049,6 +1115,10 @@ int level_search(cvhip_ctx *ctx, uint32_t w1, uint32_t h1, uint32_t w2, uint32_t
 // (DESIGN.md section 5), so one launch runs both.
 int level_cross(cvhip_ctx *ctx, int k, bool stats_ahead)
 {
+    if (ctx->bands_crossed && k == 0) { // the last level's filters went out with its result bands (level_search)
+        ctx->bands_crossed = false;
+        return CVHIP_OK;
+    }
     hipStream_t s = ctx->dev->d.stream;
     DirState &df = ctx->dir[0], &dr = ctx->dir[1];
     if (!df.valid || !dr.valid || (int)df.k != k || (int)dr.k != k)
@@ -1103,6 +1173,13 @@ extern "C++" int cvhip::flush_level_calls(cvhip_ctx *ctx)
     } else if (stage == cvhip_ctx::LevelCalls::CROSS_FWD_TAKEN) {
         CVHIP_TRY(set_device(ctx->dev));
         CVHIP_TRY(cross_check_pass(ctx, lc.k, 0));
+    } else if (stage == cvhip_ctx::LevelCalls::HELD || stage == cvhip_ctx::LevelCalls::HELD_CROSS_FWD) {
+        CVHIP_TRY(set_device(ctx->dev));
+        LevelStats ls;
+        ls.ahead = lc.stats_ahead;
+        ls.done = lc.stats_done;
+        CVHIP_TRY(level_search(ctx, false, lc.w1, lc.h1, lc.w2, lc.h2, lc.scale, lc.k, lc.first_pass, false, ls, nullptr, nullptr));
+        if (stage == cvhip_ctx::LevelCalls::HELD_CROSS_FWD) CVHIP_TRY(cross_check_pass(ctx, lc.k, 0));
     }
     return CVHIP_OK;
 }
@@ -1128,12 +1205,19 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
         lc.img2 == img1 && lc.w1 == w2 && lc.h1 == h2 && lc.w2 == w1 && lc.h2 == h1) {
         // the reverse call of the level whose forward call was taken in: the images are staged (exchanged), their
         // statistics computed - both search passes go out together, as in cvhip_correlate_level
+        if (k == 0 && !first_pass && ctx->result_bands > 1) {
+            // result bands: the last level's launches interleave search and filter, so they wait for the two filter calls
+            // (any other call first: flush_level_calls runs what was asked for so far, unbanded)
+            lc.stage = cvhip_ctx::LevelCalls::HELD;
+            report(progress, user, dir, 1.0f);
+            return CVHIP_OK;
+        }
         lc.stage = cvhip_ctx::LevelCalls::NONE;
         LevelStats ls;
         ls.ahead = lc.stats_ahead;
         ls.done = lc.stats_done;
         report(progress, user, dir, 0.20f);
-        CVHIP_TRY(level_search(ctx, lc.w1, lc.h1, lc.w2, lc.h2, scale, k, first_pass, false, ls, nullptr, nullptr));
+        CVHIP_TRY(level_search(ctx, false, lc.w1, lc.h1, lc.w2, lc.h2, scale, k, first_pass, false, ls, nullptr, nullptr));
         lc.stage = cvhip_ctx::LevelCalls::SEARCHED;
         report(progress, user, dir, 1.0f);
         return CVHIP_OK;
@@ -1196,6 +1280,18 @@ int cvhip_cross_check_filter(cvhip_ctx *ctx, float scale, int dir)
             lc.stage = cvhip_ctx::LevelCalls::NONE;
             return level_cross(ctx, k, lc.stats_ahead);
         }
+        if (dir == 0 && lc.stage == cvhip_ctx::LevelCalls::HELD) {
+            lc.stage = cvhip_ctx::LevelCalls::HELD_CROSS_FWD;
+            return CVHIP_OK;
+        }
+        if (dir == 1 && lc.stage == cvhip_ctx::LevelCalls::HELD_CROSS_FWD) { // the whole last level, in result bands
+            lc.stage = cvhip_ctx::LevelCalls::NONE;
+            LevelStats ls;
+            ls.ahead = lc.stats_ahead;
+            ls.done = lc.stats_done;
+            CVHIP_TRY(level_search(ctx, true, lc.w1, lc.h1, lc.w2, lc.h2, lc.scale, k, lc.first_pass, false, ls, nullptr, nullptr));
+            return level_cross(ctx, k, lc.stats_ahead);
+        }
     }
     CVHIP_TRY(flush_level_calls(ctx));
     return cross_check_pass(ctx, k, dir);
@@ -1221,7 +1317,7 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
     LevelStats ls;
     CVHIP_TRY(level_begin(ctx, img1, w1, h1, img2, w2, h2, k, first_pass, sharded, true, ls));
     report(progress, user, 0, 0.20f);
-    CVHIP_TRY(level_search(ctx, w1, h1, w2, h2, scale, k, first_pass, sharded, ls, progress, user));
+    CVHIP_TRY(level_search(ctx, true, w1, h1, w2, h2, scale, k, first_pass, sharded, ls, progress, user));
     CVHIP_TRY(level_cross(ctx, k, ls.ahead));
     CVHIP_TRY(release_host_sources(ctx, img1, img2));
     return CVHIP_OK;
@@ -1250,8 +1346,10 @@ static int readback_reserve(Device &d, size_t n)
     return CVHIP_OK;
 }
 
-int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr)
+// cvhip_complete_dir (words = 2: x, y as int32) and cvhip_complete_packed (words = 1: y << 16 | x)
+static int complete_grid(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr, const uint32_t words)
 {
+    const bool packed = words == 1;
     if (!ctx || !out_xy) return fail(CVHIP_ERR_INVALID, "null argument");
     if (dir != 0 && dir != 1) return fail(CVHIP_ERR_INVALID, "dir must be 0 or 1");
     CVHIP_TRY(set_device(ctx->dev));
@@ -1277,21 +1375,43 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
         if (!xy_dev) d_xy = rb.xy[set];
         if (out_corr && !corr_dev) d_corr = rb.corr[set];
     }
+    if (to_host && dir == 0 && ctx->live_bands > 1 && ds.valid && ds.k == 0 && ds.gh == ds.lh) {
+        // The last level went out in result bands (level_search): each band is expanded and copied out on the copy stream
+        // as soon as its forward filter is through, under the search of the bands behind it.
+        for (uint32_t b = 0; b < ctx->live_bands; b++) {
+            const uint32_t r0 = ctx->band_rows[b], r1 = ctx->band_rows[b + 1];
+            const size_t o = (size_t)r0 * ds.gw, m = (size_t)(r1 - r0) * ds.gw;
+            CVHIP_TRY_HIP(hipStreamWaitEvent(rb.stream, ctx->band_done[b], 0));
+            launch_expand_grid(ds.cells[ds.cur], ds.scores_valid ? ds.scores : nullptr, ds.lw, ds.lh, 0, ds.gw, ds.gh, d_xy, d_corr,
+                               rb.stream, r0, r1, packed);
+            if (!xy_dev)
+                CVHIP_TRY_HIP(hipMemcpyAsync(out_xy + words * o, d_xy + words * o, m * words * sizeof(int32_t), hipMemcpyDeviceToHost, rb.stream));
+            if (out_corr && !corr_dev)
+                CVHIP_TRY_HIP(hipMemcpyAsync(out_corr + o, d_corr + o, m * sizeof(float), hipMemcpyDeviceToHost, rb.stream));
+        }
+        CVHIP_TRY_HIP(hipGetLastError());
+        CVHIP_TRY_HIP(hipEventRecord(rb.done[set], rb.stream));
+        rb.pending[set] = true;
+        // (a device destination beside a host one was written on the copy stream: the context's stream follows it)
+        if (xy_dev || (out_corr && corr_dev)) CVHIP_TRY_HIP(hipStreamWaitEvent(s, rb.done[set], 0));
+        if (!ctx->async_readback) CVHIP_TRY_HIP(hipStreamSynchronize(rb.stream));
+        return CVHIP_OK;
+    }
     if (ds.valid) {
         (void)timed(ctx, cvhip_ctx::K_EXPAND,
                     [&] {
                         launch_expand_grid(ds.cells[ds.cur], ds.scores_valid ? ds.scores : nullptr, ds.lw, ds.lh, ds.k, ds.gw, ds.gh, d_xy,
-                                           d_corr, s);
+                                           d_corr, s, 0, 0xFFFFFFFFu, packed);
                     });
     } else { // nothing computed: all None, like a fresh Grid (mod.rs:183-184)
-        launch_fill_u32(reinterpret_cast<uint32_t *>(d_xy), 0xFFFFFFFFu, n * 2, s);
+        launch_fill_u32(reinterpret_cast<uint32_t *>(d_xy), 0xFFFFFFFFu, n * words, s);
         if (d_corr) launch_fill_u32(reinterpret_cast<uint32_t *>(d_corr), 0x7FC00000u, n, s);
     }
     CVHIP_TRY_HIP(hipGetLastError());
     if (to_host) {
         CVHIP_TRY_HIP(hipEventRecord(rb.ready, s));
         CVHIP_TRY_HIP(hipStreamWaitEvent(rb.stream, rb.ready, 0));
-        if (!xy_dev) CVHIP_TRY_HIP(hipMemcpyAsync(out_xy, d_xy, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, rb.stream));
+        if (!xy_dev) CVHIP_TRY_HIP(hipMemcpyAsync(out_xy, d_xy, n * words * sizeof(int32_t), hipMemcpyDeviceToHost, rb.stream));
         if (out_corr && !corr_dev)
             CVHIP_TRY_HIP(hipMemcpyAsync(out_corr, d_corr, n * sizeof(float), hipMemcpyDeviceToHost, rb.stream));
         CVHIP_TRY_HIP(hipEventRecord(rb.done[set], rb.stream));
@@ -1302,6 +1422,16 @@ int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr
         if (!ctx->async_readback) CVHIP_TRY_HIP(hipStreamSynchronize(rb.stream));
     }
     return CVHIP_OK;
+}
+
+int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr)
+{
+    return complete_grid(ctx, dir, out_xy, out_corr, 2);
+}
+
+int cvhip_complete_packed(cvhip_ctx *ctx, int dir, uint32_t *out_cells, float *out_corr)
+{
+    return complete_grid(ctx, dir, reinterpret_cast<int32_t *>(out_cells), out_corr, 1);
 }
 
 int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr)
@@ -1583,6 +1713,23 @@ int cvhip_ctx_set_fuse_level_calls(cvhip_ctx *ctx, int enable)
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
     CVHIP_TRY(flush_level_calls(ctx));
     ctx->fuse_level_calls = enable != 0;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_set_result_bands(cvhip_ctx *ctx, uint32_t bands)
+{
+    if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
+    if (bands == 0 || bands > 16) return fail(CVHIP_ERR_INVALID, "result bands: 1 .. 16");
+    CVHIP_TRY(flush_level_calls(ctx));
+    ctx->result_bands = bands;
+    return CVHIP_OK;
+}
+
+int cvhip_ctx_get_result_bands(cvhip_ctx *ctx, uint32_t *live)
+{
+    if (!ctx || !live) return fail(CVHIP_ERR_INVALID, "null argument");
+    CVHIP_TRY(flush_level_calls(ctx));
+    *live = ctx->live_bands > 1 ? ctx->live_bands : 1u;
     return CVHIP_OK;
 }
 

@@ -125,7 +125,7 @@ void launch_cross_check_pair(uint32_t *fwd, uint32_t *rev, uint32_t fw, uint32_t
                              uint32_t f_row1, uint32_t r_row0, uint32_t r_row1, hipStream_t s, uint32_t *zero_words = nullptr);
 // scores == nullptr: the level's scores were not computed (CorrParams::need_scores): NaN everywhere
 void launch_expand_grid(const uint32_t *cells, const float *scores, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
-                        int32_t *out_xy, float *out_corr, hipStream_t s);
+                        int32_t *out_xy, float *out_corr, hipStream_t s, uint32_t gy0 = 0, uint32_t gy1 = 0xFFFFFFFFu, bool packed = false);
 void launch_fill_u32(uint32_t *p, uint32_t v, size_t n, hipStream_t s);
 // tracks of the affine dense consumer; block_counts must hold ceil(gw*gh/256) u32, total is one u32
 void launch_triangulate_affine(const uint32_t *cells, uint32_t lw, uint32_t lh, uint32_t k, uint32_t gw, uint32_t gh,
@@ -402,7 +402,7 @@ struct cvhip_ctx {
     // (cvhip::flush_level_calls runs it whenever another entry point comes first).
     bool fuse_level_calls = false;
     struct LevelCalls {
-        enum { NONE = 0, FWD_TAKEN, SEARCHED, CROSS_FWD_TAKEN };
+        enum { NONE = 0, FWD_TAKEN, SEARCHED, CROSS_FWD_TAKEN, HELD, HELD_CROSS_FWD }; // HELD*: result bands (below)
         int stage = NONE;
         int k = -1, first_pass = 0;
         float scale = 0.0f;
@@ -411,6 +411,14 @@ struct cvhip_ctx {
         bool stats_ahead = false;
         hipEvent_t stats_done = nullptr;
     } calls;
+    // cvhip_ctx_set_result_bands: the last level (scale 1) is searched and filtered in row bands, band b's forward filter
+    // right behind the search of band b + 1, each with an event - complete() into HOST memory then expands and copies out band
+    // b while the later bands are still being searched, instead of 201 MB of PCIe time behind the whole level.
+    uint32_t result_bands = 1;             // bands asked for (1 = off)
+    uint32_t live_bands = 0;               // bands of the current last-level result (0: not banded)
+    uint32_t band_rows[17] = {};           // forward-grid rows [band_rows[b], band_rows[b + 1])
+    hipEvent_t band_done[16] = {};         // band b of the forward grid is final
+    bool bands_crossed = false;            // the last level's cross-checks went out with its bands: level_cross has nothing to do
     bool staged_from_pageable = false; // the last stage_images copied straight from the caller's pageable memory (no ring)
     hipEvent_t level_read[16] = {};    // per level: the last kernels that read the staged images have been enqueued before it
     hipEvent_t pool_ready = nullptr;   // the image pool has been cleared (context creation, on the context's stream): the copy

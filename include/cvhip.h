@@ -107,6 +107,17 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
                           uint32_t w2, uint32_t h2, float scale, int first_pass, cvhip_progress_fn progress,
                           void *user);
 
+/* Result bands for host destinations.  With bands > 1 the last level (scale 1) of a pair whose geometry is row-local
+ * (the same test as cvhip_plan_bands: affine models, near-horizontal epipolar lines) is searched and cross-checked in
+ * `bands` row bands, and cvhip_complete_dir(dir 0) into HOST memory expands and copies band b out on the copy stream
+ * while the bands behind it are still being searched - the 201 MB grid of a 4096^2 pair then costs ~1.5 ms beyond the
+ * search instead of ~4.5.  The result is the one of bands == 1, bit for bit (tests/test_corr_gpu.py).  In the fused
+ * four-call mode the last level's launches wait for its two cross_check_filter calls.  Default 1; at most 16.
+ * Replaces nothing in the reference (its complete() maps one buffer after the last submission, gpu/mod.rs:321-349). */
+int cvhip_ctx_set_result_bands(cvhip_ctx *ctx, uint32_t bands);
+/* How many bands the grid now held went out in (1: not banded - the geometry, the size or the call order ruled it out). */
+int cvhip_ctx_get_result_bands(cvhip_ctx *ctx, uint32_t *live);
+
 /* GpuContext::complete_process (gpu/mod.rs:210-216; called mod.rs:208-215): write the forward
  * full-resolution grid.  out_xy: 2*w1*h1 int32, out_corr: w1*h1 float (may be NULL).
  * Host destinations are complete on return (synchronises); DEVICE destinations are written in
@@ -123,6 +134,12 @@ int cvhip_complete(cvhip_ctx *ctx, int32_t *out_xy, float *out_corr);
 int cvhip_ctx_set_async_readback(cvhip_ctx *ctx, int enable);
 /* Same for either direction (dir 1 = correlated_points_reverse, mod.rs:65); test hook. */
 int cvhip_complete_dir(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_corr);
+/* The same grid in 8 instead of 12 bytes per cell, for host destinations behind PCIe: out_cells[y * w + x] =
+ * y2 << 16 | x2 of the match (level dimensions are at most 65535), 0xFFFFFFFF = None; out_corr as above (may be NULL).
+ * The binding unpacks in the loop in which it builds its Grid<Option<Match>> anyway (gpu/mod.rs:321-349 reads its own
+ * [i32; 2] + f32 buffers cell by cell).  Everything else - result bands, asynchronous readback, device destinations - as
+ * cvhip_complete_dir. */
+int cvhip_complete_packed(cvhip_ctx *ctx, int dir, uint32_t *out_cells, float *out_corr);
 
 /* All-gather hook for row sharding: called by cvhip_correlate_level after each sharded search
  * pass, on the calling thread.  `cells` is the device pointer of the level grid's match plane (4 bytes per level pixel)

@@ -260,10 +260,12 @@ def test_host_images_into_fresh_contexts(gpu_device, oracle):
             pc.close()
 
 
-def test_fused_level_calls_out_of_order(gpu_device, oracle):
+@pytest.mark.parametrize("bands", [1, 2])
+def test_fused_level_calls_out_of_order(gpu_device, oracle, bands):
     """A caller that has promised the reference's call order and departs from it still gets every call executed: grids
     read between the calls (complete() after each), a forward call whose reverse call never comes, a reverse call with
-    OTHER images than the forward call's, cross-checks in the other order."""
+    OTHER images than the forward call's, cross-checks in the other order.  With result bands the last level's launches
+    are held back until its second filter call: every departure runs what was asked for so far."""
     c = cases.make_case("sem320x200")
     p1, p2 = cases.pyramids(c)
     h1, w1 = c["img1"].shape
@@ -272,12 +274,13 @@ def test_fused_level_calls_out_of_order(gpu_device, oracle):
     pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"])
     pc.set_exact_scores(True)
     pc.set_fuse_level_calls(True)
+    pc.set_result_bands(bands)
     oc = oracle.Corr((w1, h1), (w2, h2), c["F"], 0, 8)
     try:
         for i in range(c["steps"] + 1):
             k = c["steps"] - i
             s = 1.0 / float(1 << k)
-            variant = i % 3
+            variant = (i + bands - 1) % 3
             pc.correlate_images_step(p1[k], p2[k], s, F)
             oc.step(p1[k], p2[k], s, 0)
             if variant == 0:   # the grid is read before the reverse call: the pending forward pass runs alone
@@ -312,6 +315,87 @@ def test_fused_level_calls_out_of_order(gpu_device, oracle):
         oc.close()
 
 
+@pytest.mark.parametrize("name,bands,expect", [("sem320x200", 2, 2), ("sem320x200", 16, 2), ("h256", 2, 2), ("ragged_dims", 3, None),
+                                               ("tilt3_200x150", 2, None), ("persp_240x180", 4, 1)])
+def test_result_bands_give_the_same_grid(gpu_device, oracle, name, bands, expect):
+    """cvhip_ctx_set_result_bands: the last level searched and filtered in row bands, each expanded and copied out to the
+    HOST destination on the copy stream under the search of the bands behind it - the grid (and the reverse grid) of the
+    unbanded level, i.e. the oracle's, bit for bit; through the level call and through the reference's four calls (host
+    images); into device destinations (no banded copy); on a context used for a second pair.  Geometries that are not
+    row-local (perspective pairs, tilted lines beyond the bound) and bands too low for the filter's reach fall back to
+    fewer bands or none, which cvhip_ctx_get_result_bands reports."""
+    import torch
+
+    c = cases.make_case(name)
+    want = run_oracle(oracle, c, both=True)
+    p1, p2 = cases.pyramids(c)
+    h1, w1 = c["img1"].shape
+    h2, w2 = c["img2"].shape
+    F, D = correlation.CorrelationDirection.Forward, correlation.CorrelationDirection.Reverse
+    for mode in ("level call", "four calls", "device destination", "level call, pinned"):
+        pc = correlation.PointCorrelations(gpu_device, (w1, h1), (w2, h2), c["F"], correlation.ProjectionMode(c["projection"]))
+        pc.set_exact_scores(True)
+        pc.set_result_bands(bands)
+        if mode == "four calls":
+            pc.set_fuse_level_calls(True)
+        try:
+            for rep in range(2):
+                pc.first_pass = True
+                for i in range(c["steps"] + 1):
+                    k = c["steps"] - i
+                    pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=mode != "four calls")
+                live = pc.result_bands()
+                if expect is not None:
+                    assert live == expect, (mode, live)
+                if mode == "device destination":
+                    xy = torch.empty((h1, w1, 2), dtype=torch.int32, device="cuda")
+                    co = torch.empty((h1, w1), dtype=torch.float32, device="cuda")
+                    pc.complete(F, xy, co)
+                    torch.cuda.synchronize()
+                    got = (xy.cpu().numpy(), co.cpu().numpy())
+                elif mode.endswith("pinned"):
+                    xy = torch.empty((h1, w1, 2), dtype=torch.int32).pin_memory()
+                    co = torch.empty((h1, w1), dtype=torch.float32).pin_memory()
+                    xy.fill_(7)
+                    pc.complete(F, xy, co)
+                    got = (xy.numpy().copy(), co.numpy().copy())
+                else:
+                    got = pc.complete(F)
+                assert_same_grid(got, want[0], f"{name} {bands} bands ({mode}, pair {rep}) forward")
+                assert_same_grid(pc.complete(D), want[1], f"{name} {bands} bands ({mode}, pair {rep}) reverse")
+                assert_same_grid(pc.complete(F), want[0], f"{name} {bands} bands ({mode}, pair {rep}) forward again")
+                # the 8-byte cells of cvhip_complete_packed: the same grid
+                cells, co = pc.complete_packed(F)
+                assert_same_grid((pc.unpack_cells(cells), co), want[0], f"{name} {bands} bands ({mode}, pair {rep}) packed")
+        finally:
+            pc.close()
+
+
+def test_result_bands_large_pair(gpu_device):
+    """Four and eight result bands on a 1536 x 1280 pair with disparity discontinuities against the unbanded level (both on
+    the device: the oracle would take minutes), host destinations."""
+    a, b, _ = synth.make_pair(1536, 1280, seed=91)
+    c = {"img1": a, "img2": b, "F": synth.F_HORIZONTAL, "projection": 0, "steps": synth.optimal_scale_steps(1536, 1280)}
+    want = run_gpu(gpu_device, c, both=True)
+    p1, p2 = cases.pyramids(c)
+    for bands in (4, 8):
+        pc = correlation.PointCorrelations(gpu_device, (1536, 1280), (1536, 1280), c["F"])
+        pc.set_exact_scores(True)
+        pc.set_result_bands(bands)
+        pc.set_fuse_level_calls(bands == 8)
+        try:
+            for i in range(c["steps"] + 1):
+                k = c["steps"] - i
+                pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=bands == 4)
+            assert pc.result_bands() == bands
+            cells, co = pc.complete_packed()
+            assert_same_grid((pc.unpack_cells(cells), co), want[0], f"{bands} bands forward, packed")
+            assert_same_grid(pc.complete(), want[0], f"{bands} bands forward")
+            assert_same_grid(pc.complete(correlation.CorrelationDirection.Reverse), want[1], f"{bands} bands reverse")
+        finally:
+            pc.close()
+
+
 def test_each_level_matches_oracle(gpu_device, oracle):
     """Stage-by-stage: after every search pass and every cross-check the device grids equal
     the oracle's (catches compensating errors that a final-grid comparison could hide)."""
@@ -336,6 +420,8 @@ def test_each_level_matches_oracle(gpu_device, oracle):
             pc.cross_check_filter(s, F)
             oc.cross_check(s, 0)
             assert_same_grid(pc.complete(F), oc.get(0), f"level {k} fwd cross-check")
+            cells, co = pc.complete_packed(F)  # (coarser levels: the coordinates scaled back, as complete()'s)
+            assert_same_grid((pc.unpack_cells(cells), co), oc.get(0), f"level {k} fwd cross-check, packed cells")
             pc.cross_check_filter(s, D)
             oc.cross_check(s, 1)
             assert_same_grid(pc.complete(D), oc.get(1), f"level {k} rev cross-check")

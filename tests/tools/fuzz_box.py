@@ -57,17 +57,24 @@ for it in range(N):
         four_calls = bool((it + version) & 1)
         if four_calls:
             pc.set_fuse_level_calls(True)
+        # result bands (cvhip_ctx_set_result_bands; taken where the geometry and the height allow) and packed cells
+        bands = int(rng.integers(1, 5))
+        pc.set_result_bands(bands)
         for i in range(steps + 1):
             k = steps - i
             pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=not four_calls)
-        got = pc.complete()
+        if (it + version) & 2:
+            cells, corr = pc.complete_packed()
+            got = (pc.unpack_cells(cells), corr)
+        else:
+            got = pc.complete()
         pc.close()
         ok = (got[0] == want[0]).all()
         v = want[0][..., 0] >= 0
         ok = ok and (got[1].view(np.uint32)[v] == want[1].view(np.uint32)[v]).all()
         if not ok:
             bad += 1
-            print(f"MISMATCH it={it} version={version} four_calls={four_calls} {w}x{h} b={b.shape} tilt={tilt} consistent={consistent} seed={seed} "
+            print(f"MISMATCH it={it} version={version} four_calls={four_calls} bands={bands} {w}x{h} b={b.shape} tilt={tilt} consistent={consistent} seed={seed} "
                   f"proj={proj} diff_cells={(got[0] != want[0]).any(axis=-1).sum()}")
     if it % 10 == 9:
         print(f"{it + 1} cases, {bad} mismatches", flush=True)
