@@ -101,6 +101,9 @@ class PointCorrelations { // correlation/mod.rs:63-245, GPU branch
                                img2_dimensions.second, projection_mode == ProjectionMode::Perspective ? 1 : 0,
                                fundamental_matrix.data(), &ctx_),
               "cvhip_ctx_create");
+        // complete() always lands in host memory: the last level goes out in row bands, each crossing PCIe under the
+        // search of the next (same grid)
+        check(cvhip_ctx_set_result_bands(ctx_, 6), "cvhip_ctx_set_result_bands");
     }
     ~PointCorrelations() { cvhip_ctx_destroy(ctx_); }
     PointCorrelations(const PointCorrelations &) = delete;
@@ -122,13 +125,12 @@ class PointCorrelations { // correlation/mod.rs:63-245, GPU branch
     void complete()
     {
         const size_t w = dims1_.first, h = dims1_.second;
-        std::vector<int32_t> xy(2 * w * h);
+        std::vector<uint32_t> cells(w * h); // y2 << 16 | x2, all ones = None: 8 bytes per cell over PCIe with the score
         std::vector<float> corr(w * h);
-        check(cvhip_complete(ctx_, xy.data(), corr.data()), "cvhip_complete");
+        check(cvhip_complete_packed(ctx_, 0, cells.data(), corr.data()), "cvhip_complete_packed");
         correlated_points = Grid<std::optional<Match>>(w, h, std::nullopt);
         for (size_t i = 0; i < w * h; i++)
-            if (xy[2 * i] >= 0)
-                correlated_points.data()[i] = Match{{(uint32_t)xy[2 * i], (uint32_t)xy[2 * i + 1]}, corr[i]};
+            if (cells[i] != 0xFFFFFFFFu) correlated_points.data()[i] = Match{{cells[i] & 0xFFFFu, cells[i] >> 16}, corr[i]};
     }
 
     static size_t optimal_scale_steps(std::pair<uint32_t, uint32_t> dimensions) // mod.rs:542-550
