@@ -66,7 +66,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     def compile_one(src: str) -> Path:
         obj = OBJ / (src + ".o")
         if force or _stale(obj, [CSRC / src] + hdrs):
-            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
+            # (CVHIP_EXTRA_FLAGS: e.g. -DCVHIP_ABLATIONS for scripts/box_ablation*.sh - build with --force, and again without)
+            cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), *os.environ.get("CVHIP_EXTRA_FLAGS", "").split(), "-c", str(CSRC / src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

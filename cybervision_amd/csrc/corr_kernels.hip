@@ -2318,7 +2318,8 @@ void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipS
         hipLaunchKernelGGL(search3_fallback_kernel<false>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
 }
 
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s)
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s,
+                        hipStream_t side, hipEvent_t fork, hipEvent_t join)
 {
     // rectified affine pairs under search version 5: the filter on the matrix pipe (search4_mfma_kernel); a pass that counts
     // candidates (profiling) takes the box kernel - the matrix-pipe walk does not know, value by value, which pixel ends up
@@ -2346,15 +2347,27 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
     }
     if (!gx || !gy) return;
     const dim3 grid(gx, gy, (unsigned)n);
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]); };
+    size_t lean_pad = 0;
+#ifdef CVHIP_ABLATIONS
+    // (occupancy experiments: CVHIP_LEAN_LDS_PAD bytes of unused dynamic LDS per workgroup of the lean instantiations)
+    if (const char *e = getenv("CVHIP_LEAN_LDS_PAD")) lean_pad = (size_t)atoi(e);
+#endif
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), lean_pad, s, jobs[0], jobs[n - 1]); };
     auto launch_each = [&](auto kernel) { // the stepped instantiations: one launch per job (see search3_box_single_kernel)
+        const bool forked = side && fork && join && n == 2 && job_active(jobs[0]) && job_active(jobs[1]) &&
+                            hipEventRecord(fork, s) == hipSuccess && hipStreamWaitEvent(side, fork, 0) == hipSuccess;
         for (int i = 0; i < n; i++)
             if (job_active(jobs[i]))
                 hipLaunchKernelGGL(kernel, dim3(gx, gy, 1), dim3(256),
-                                   search3_step_lds_bytes(jobs[i].p.box_pd, jobs[i].p.box_sh, jobs[i].p.box_wide != 0), s, jobs[i].p,
+                                   search3_step_lds_bytes(jobs[i].p.box_pd, jobs[i].p.box_sh, jobs[i].p.box_wide != 0),
+                                   forked && i == 1 ? side : s, jobs[i].p,
                                    jobs[i].img1, jobs[i].img2, jobs[i].stats1, jobs[i].stats1, jobs[i].stats2,
                                    (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out, jobs[i].out_score, jobs[i].counters,
                                    jobs[i].declined, jobs[i].whole);
+        if (forked) { // (an error here surfaces at the caller's hipGetLastError / the next synchronisation)
+            (void)hipEventRecord(join, side);
+            (void)hipStreamWaitEvent(s, join, 0);
+        }
     };
     const bool wide = jobs[0].p.box_wide != 0;
     const int variant = (jobs[0].counters ? 4 : 0) | (stepped_lines ? 2 : 0) | (transposed ? 1 : 0);

@@ -554,7 +554,18 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
             if (zero_counts)
                 for (int q = 0; q < m; q++) CVHIP_TRY_HIP(hipMemsetAsync(jobs[q].declined.count, 0, 4 * sizeof(uint32_t), s));
             if (pl.kind == PassPlan::BOX) {
-                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] { launch_search3_box(jobs, m, pl.stepped, pl.transposed, pl.mfma, s); }, s));
+                // The stepped instantiations go out as one launch per direction: on large levels the second one runs on a side
+                // stream of the handle, filling the first one's tail (small levels: the fork / join costs more than it saves).
+                hipStream_t side = nullptr;
+                Device &d = c->dev->d;
+                if (pl.stepped && m == 2 && !c->time_kernels && (size_t)p.w1 * (p.row1 - p.row0) >= d.box_fork_min_px && s == d.stream) {
+                    for (hipEvent_t &ev : d.box_ev)
+                        if (!ev) CVHIP_TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    CVHIP_TRY_HIP(aux_stream(d, 1, &side));
+                }
+                CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
+                    launch_search3_box(jobs, m, pl.stepped, pl.transposed, pl.mfma, s, side, d.box_ev[0], d.box_ev[1]);
+                }, s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s); }, s));
             } else {
                 // candidate filter over every tile; the (rare) tiles with whole-corridor pixels queue themselves for
@@ -692,6 +703,11 @@ void device_free(cvhip_device *dev)
         if (rq.started) (void)hipEventDestroy(rq.started);
     }
     for (hipEvent_t &ev : dev->d.orb_ev)
+        if (ev) {
+            (void)hipEventDestroy(ev);
+            ev = nullptr;
+        }
+    for (hipEvent_t &ev : dev->d.box_ev)
         if (ev) {
             (void)hipEventDestroy(ev);
             ev = nullptr;

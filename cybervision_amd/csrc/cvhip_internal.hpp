@@ -117,7 +117,10 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
                    unsigned long long *cand_counter, hipStream_t s);
 void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s);
 void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s);
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s);
+// (side / fork / join: the stepped instantiations launch one kernel per direction - with a side stream the second one goes
+// there, between the two events, so that the first launch's tail is filled)
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s,
+                        hipStream_t side = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
@@ -236,6 +239,9 @@ struct Device {
     // stream of its own for the statistics, config 5's RANSAC stage ran 22 -> 27 ms in a process that had used both)
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t orb_ev[3] = {nullptr, nullptr, nullptr}; // cvhip_orb_extract_batch's fork / join events
+    hipEvent_t box_ev[2] = {nullptr, nullptr};          // the stepped box launches' fork / join (launch_passes)
+    // (levels from 1024^2: 4096^2 pair at 3 / 30 / 90 degrees 7.73 / 7.78 / 7.47 -> 7.67 / 7.74 / 7.37 ms; below, the two events cost more)
+    size_t box_fork_min_px = 500000;
     struct OrbLanes { // ... and what it learned about running three image chains at once on this handle (orb_kernels.hip)
         size_t shape = 0;
         double best_ms = 0.0;
