@@ -912,6 +912,42 @@ def test_config3_4096_matches_oracle_digest(gpu_device):
         assert hashlib.sha256(np.ascontiguousarray(score_bits).tobytes()).hexdigest() == want[name]["score_sha256"], name
 
 
+@pytest.mark.parametrize("fixture", ["corr_tilt10_4096_digest.json", "corr_tilt45_4096_digest.json", "corr_tilt60_4096_digest.json",
+                                     "corr_perspective_2048_digest.json"])
+def test_full_size_geometries_match_oracle_digest(gpu_device, fixture):
+    """The stepped (10, 45 degrees), the transposed stepped (60 degrees) and the perspective instantiations of the box
+    filter at FULL size against the oracle, by digest like config 3 above: forward and reverse match planes, score planes,
+    match counts and the candidate count - generated by tests/tools/gen_digest_4096.py <size> <case> from
+    oracle/cvref_corr.c (4096^2: a minute on 8 cores).  The regenerated input pair is checked first."""
+    import hashlib
+    import json
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).parent / "tools"))
+    import gen_digest_4096
+
+    want = json.loads((Path(__file__).parent / "golden" / fixture).read_text())
+    size = want["size"]
+    a, b, F, projection, _ = gen_digest_4096.case_inputs(want["case"], size)
+    assert gen_digest_4096.inputs_digest(a, b) == want["inputs_sha256"], "the synthetic pair is not the one the digest was made from"
+    c = dict(img1=a, img2=b, F=F, projection=projection, steps=synth.optimal_scale_steps(size, size))
+    cnt = {}
+    fwd, rev = run_gpu(gpu_device, c, both=True, counters=cnt)
+    assert cnt["candidates"] == want["candidates"]
+    for name, (xy, corr) in (("forward", fwd), ("reverse", rev)):
+        valid = xy[..., 0] >= 0
+        assert int(valid.sum()) == want[name]["matches"], name
+        assert hashlib.sha256(np.ascontiguousarray(xy, dtype=np.int32).tobytes()).hexdigest() == want[name]["xy_sha256"], name
+        score_bits = np.where(valid, corr.view(np.uint32), np.uint32(0))
+        assert hashlib.sha256(np.ascontiguousarray(score_bits).tobytes()).hexdigest() == want[name]["score_sha256"], name
+    # the default mode (no counters: the launches the bench times; scores of the observable pass only) gives the same forward grid
+    got = run_gpu(gpu_device, c)
+    assert (got[0] == fwd[0]).all()
+    valid = fwd[0][..., 0] >= 0
+    assert (got[1].view(np.uint32)[valid] == fwd[1].view(np.uint32)[valid]).all()
+
+
 @pytest.mark.parametrize("name", ["tilt3_200x150", "h256", "flat"])
 def test_triangulate_affine_matches_oracle(gpu_device, oracle, name):
     """Dense consumer (triangulation.rs:268-330) straight from the device grid: same tracks, same order,
