@@ -1518,8 +1518,9 @@ template <bool STEP, bool WIDE = true> struct S3Plan {
 // dynamic LDS of a stepped launch: LINES lines of pd dwords, then sh statistics rows of ISP cells
 static inline uint32_t search3_step_lds_bytes(uint32_t pd, uint32_t sh, bool wide)
 {
-    return wide ? (uint32_t)S3Plan<true, true>::LINES * pd * 4u + sh * (uint32_t)S3Plan<true, true>::ISP * 8u
-                : (uint32_t)S3Plan<true, false>::LINES * pd * 4u + sh * (uint32_t)S3Plan<true, false>::ISP * 8u;
+    const uint32_t plan = wide ? (uint32_t)S3Plan<true, true>::LINES * pd * 4u + sh * (uint32_t)S3Plan<true, true>::ISP * 8u
+                               : (uint32_t)S3Plan<true, false>::LINES * pd * 4u + sh * (uint32_t)S3Plan<true, false>::ISP * 8u;
+    return plan > 4u * 128u * 12u ? plan : 4u * 128u * 12u; // (at least the four waves' contender queues: box_body.inc)
 }
 
 __device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t v)

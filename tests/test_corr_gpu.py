@@ -128,6 +128,11 @@ def adversarial_case(kind):
         base = rng.integers(0, 256, size=(8, 4), dtype=np.uint8)
         a = np.tile(base, (h // 8, w // 4))
         b = a.copy()
+    elif kind == "periodic16":  # two or three exact ties per pixel: within the contender list, shared out over idle lanes
+        h, w = 192, 320
+        base = rng.integers(0, 256, size=(16, 8), dtype=np.uint8)
+        a = np.tile(base, (h // 16, w // 8))
+        b = a.copy()
     elif kind == "low_contrast":
         a = (100 + rng.integers(0, 4, size=(h, w))).astype(np.uint8)   # stdev ~ 1.1
         b = np.roll(a, 3, axis=1)
@@ -143,7 +148,7 @@ def adversarial_case(kind):
                 steps=steps)
 
 
-@pytest.mark.parametrize("kind", ["periodic", "low_contrast", "noisy"])
+@pytest.mark.parametrize("kind", ["periodic", "periodic16", "low_contrast", "noisy"])
 def test_filter_decision_rule_on_adversarial_inputs(gpu_device, oracle, kind):
     c = adversarial_case(kind)
     cnt = {}
@@ -153,6 +158,13 @@ def test_filter_decision_rule_on_adversarial_inputs(gpu_device, oracle, kind):
     assert_same_grid(got[1], want[1], f"{kind} reverse")
     if kind == "periodic":  # ties must actually have been exercised
         assert cnt["multi_contender_pixels"] + cnt["whole_corridor_pixels"] > 1000, cnt
+    if kind == "periodic16":  # ... and as lists of contenders, not only as whole-corridor pixels
+        assert cnt["multi_contender_pixels"] > 1000, cnt
+    # the launches without counters (another instantiation of the same kernels), and the stepped ones forced
+    for version in (3, 4):
+        again = run_gpu(gpu_device, c, both=True, version=version)
+        assert_same_grid(again[0], want[0], f"{kind} forward, version {version}, no counters")
+        assert_same_grid(again[1], want[1], f"{kind} reverse, version {version}, no counters")
 
 
 def test_filter_statistics(gpu_device):
