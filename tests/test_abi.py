@@ -36,6 +36,18 @@ def test_binding_table_matches_header():
     assert _lib.lib().cvhip_abi_version() == 2
 
 
+def test_integration_guide_names_only_declared_symbols():
+    """Every cvhip_* entry point INTEGRATION.md binds or mentions is declared in include/cvhip.h (a renamed or removed
+    function must not survive in the guide's Rust snippets)."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    named = set(re.findall(r"\b(cvhip_[a-z0-9_]+)\s*\(", text)) | set(re.findall(r"fn\s+(cvhip_[a-z0-9_]+)", text))
+    named |= set(re.findall(r"`(cvhip_[a-z0-9_]+)`", text))
+    declared = set(_declared_symbols())
+    prefixes = {n for n in named if n.endswith("_")}   # ("cvhip_rccl_*"-style family names)
+    unknown = sorted(n for n in named - declared - prefixes if not any(d.startswith(n) for d in declared if n.endswith("_")))
+    assert not unknown, unknown
+
+
 def test_no_product_dependency_on_oracle():
     """The product must never import, include, link or load the CPU oracle."""
     pkg = ROOT / "cybervision_amd"
