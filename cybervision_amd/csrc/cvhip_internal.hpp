@@ -233,11 +233,12 @@ struct Device {
         std::vector<Chunk> busy;       // transfers that may still be reading their part of the ring (oldest first)
         std::vector<hipEvent_t> spare; // events to reuse
     } up;
-    // Side streams of the handle, shared by whoever needs one (the RANSAC generators: both; the statistics-ahead mode:
-    // the first) and created on first use.  Shared on purpose: a process gets four hardware queues, and a fifth stream
-    // is mapped onto a queue that is already in use - its "concurrent" kernels then wait for that stream's (with a
-    // stream of its own for the statistics, config 5's RANSAC stage ran 22 -> 27 ms in a process that had used both)
-    hipStream_t aux[2] = {nullptr, nullptr};
+    // Side streams of the handle, shared by whoever needs one (the RANSAC generators: all four; the statistics-ahead mode:
+    // the first; the stepped box launches' second direction: the second) and created on first use.  Shared on purpose
+    // rather than one per purpose: streams beyond the process' hardware queues are mapped onto queues already in use (in
+    // round 3, with a stream of its own for the statistics, config 5's RANSAC stage ran 22 -> 27 ms in a process that had
+    // used both; in round 4 four generator streams beat two with GPU_MAX_HW_QUEUES at its default of 4 as with 8)
+    hipStream_t aux[4] = {};
     hipEvent_t orb_ev[3] = {nullptr, nullptr, nullptr}; // cvhip_orb_extract_batch's fork / join events
     hipEvent_t box_ev[2] = {nullptr, nullptr};          // the stepped box launches' fork / join (launch_passes)
     // (levels from 1024^2: 4096^2 pair at 3 / 30 / 90 degrees 7.73 / 7.78 / 7.47 -> 7.67 / 7.74 / 7.37 ms; below, the two events cost more)

@@ -2704,10 +2704,22 @@ hipError_t launch_refit_tail(DevAllocs &mem, const uint4 *m4, uint32_t N, double
                              double *d_F_out, hipStream_t s);
 // Hypotheses are generated GEN_BATCH rounds at a time (the generator kernels are bound by the latency of their serial f64
 // work on too few threads for the chip - 50 000 samples are 782 waves - so two rounds in one launch take what one
-// takes), into one of GEN_DEPTH buffers: the batch being scored and the two that may be generated ahead of it.  (Five - a buffer
-// per batch of the reference's twenty rounds - changed nothing for the thin-SVD pencil: 52.2 ms either way; what holds a
-// generator stream back there is the scoring chain's counting kernel when the two share a hardware pipe.)
-constexpr uint32_t GEN_BATCH = 4, GEN_DEPTH = 3;
+// takes), into one of GEN_DEPTH buffers, on one of GEN_STREAMS side streams of the handle.  Round 4: four streams and a
+// buffer per batch of the reference's twenty rounds - the generators' long Levenberg-Marquardt tails run side by side
+// instead of one behind the other, and the call's last batch is generated ~3 ms earlier, which is what its stragglers
+// (LateStage, below) need to finish under the scoring chain: config 5's RANSAC stage 50.9 -> 45.2 ms with the reference's
+// pencil, 15.8 -> 15.4 with the null-space one (streams / buffers / rounds per batch: 2/3/4 50.9, 3/4/4 48.0, 3/5/4 47.2,
+// 4/5/4 45.2, 5/5/4 45.3, 6/6/4 45.4, 5/6/2 48.5, 4/4/5 48.8 ms; five buffers on two streams had changed nothing).
+#ifndef CVHIP_GEN_BATCH
+#define CVHIP_GEN_BATCH 4
+#endif
+#ifndef CVHIP_GEN_DEPTH
+#define CVHIP_GEN_DEPTH 5
+#endif
+#ifndef CVHIP_GEN_STREAMS
+#define CVHIP_GEN_STREAMS 4
+#endif
+constexpr uint32_t GEN_BATCH = CVHIP_GEN_BATCH, GEN_DEPTH = CVHIP_GEN_DEPTH;
 // The call's stragglers (thin-SVD pencil; batched scoring only): roots whose Levenberg-Marquardt loop outlasts the thread
 // kernels' budget - a handful per 100 000, but each keeps ONE wave busy for up to 1000 trips (~5 ms), and run inside their
 // batch they held that batch's generator stream, and with it every later batch, for that long (2.6 of the 6.7 ms a batch
@@ -2788,9 +2800,10 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     // smaller slot stays among equals - and round q's slots follow round q - 1's): half as many counting launches and
     // round ends (the latter are single-workgroup kernels: 20 - 70 us of an otherwise idle chip each).
     const bool score_batches = !may_exit_early;
-    constexpr uint32_t GEN_STREAMS = 2;
+    constexpr uint32_t GEN_STREAMS = CVHIP_GEN_STREAMS;
     static_assert(GEN_DEPTH + 2 <= sizeof(Device::RansacQueues::ready) / sizeof(hipEvent_t), // (ready[6], ready[7]: the stragglers' events)
-                  "Device holds two side streams and RansacQueues' events");
+                  "RansacQueues holds eight events per kind");
+    static_assert(GEN_STREAMS <= sizeof(Device::aux) / sizeof(hipStream_t), "Device holds the side streams");
     Device::RansacQueues &rq = dev->d.rq; // (kept on the handle: created once)
     hipStream_t g[GEN_STREAMS] = {};
     for (uint32_t k = 0; k < GEN_STREAMS && e == hipSuccess; k++) e = aux_stream(dev->d, (int)k, &g[k]);
