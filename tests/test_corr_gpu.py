@@ -383,22 +383,26 @@ def test_result_bands_give_the_same_grid(gpu_device, oracle, name, bands, expect
             pc.close()
 
 
-def test_result_bands_large_pair(gpu_device):
+@pytest.mark.parametrize("tilt", [0.0, 1.5])
+def test_result_bands_large_pair(gpu_device, tilt):
     """Four and eight result bands on a 1536 x 1280 pair with disparity discontinuities against the unbanded level (both on
-    the device: the oracle would take minutes), host destinations."""
-    a, b, _ = synth.make_pair(1536, 1280, seed=91)
-    c = {"img1": a, "img2": b, "F": synth.F_HORIZONTAL, "projection": 0, "steps": synth.optimal_scale_steps(1536, 1280)}
+    the device: the oracle would take minutes), host destinations.  Tilted by 1.5 degrees the bands are the stepped
+    launches', one per direction with the second on the handle's side stream (levels from 1024^2), and the filter's reach
+    is ~50 rows."""
+    a, b, _ = synth.make_pair(1536, 1280, seed=91, tilt_deg=tilt)
+    c = {"img1": a, "img2": b, "F": synth.f_tilt(tilt) if tilt else synth.F_HORIZONTAL, "projection": 0,
+         "steps": synth.optimal_scale_steps(1536, 1280)}
     want = run_gpu(gpu_device, c, both=True)
     p1, p2 = cases.pyramids(c)
-    for bands in (4, 8):
+    for bands in ((4, 8) if tilt == 0.0 else (3, 5)):
         pc = correlation.PointCorrelations(gpu_device, (1536, 1280), (1536, 1280), c["F"])
         pc.set_exact_scores(True)
         pc.set_result_bands(bands)
-        pc.set_fuse_level_calls(bands == 8)
+        pc.set_fuse_level_calls(bands in (8, 5))
         try:
             for i in range(c["steps"] + 1):
                 k = c["steps"] - i
-                pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=bands == 4)
+                pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=bands in (4, 3))
             assert pc.result_bands() == bands
             cells, co = pc.complete_packed()
             assert_same_grid((pc.unpack_cells(cells), co), want[0], f"{bands} bands forward, packed")
