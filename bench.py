@@ -46,7 +46,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DOT4_PEAK_TMACS = 256 * 4 * 64 * 4 / 4 * 2.4e9 / 1e12   # = 157.3 T multiply-adds/s, the filter kernel's roof
 
 
-RESULT_BANDS = 6                 # cvhip_ctx_set_result_bands in the host-destination modes (scripts/result_bands_probe.py)
+RESULT_BANDS = 0                 # cvhip_ctx_set_result_bands in the host-destination modes: 0 = the library's choice by size (the
+                                 # binding's setting; 6 bands at 4096^2, scripts/result_bands_probe.py)
 SEARCH_KERNEL = "search3_box_kernel"   # the kernel class "search" times (search version 3, the default)
 
 
@@ -526,7 +527,8 @@ def main():
         same_b = bool((hxy == want_xy).all())
         pcb.set_result_bands(RESULT_BANDS)  # (the binding's setting: the grid always goes to the host there)
         ms_4h = timed_pairs(hp1, hp2, False, True)
-        same_b = same_b and bool((hxy == want_xy).all()) and pcb.result_bands() == RESULT_BANDS
+        live_b = pcb.result_bands()
+        same_b = same_b and bool((hxy == want_xy).all()) and live_b > 1
         ms_4hp = timed_pairs(hp1, hp2, False, "packed")
         same_b = same_b and bool((correlation.PointCorrelations.unpack_cells(hcells) == want_xy).all())
         ms_lh = timed_pairs(hp1, hp2, True, True)
@@ -539,7 +541,7 @@ def main():
         pcb.close()
         boundary_path = {"four_call_host_ms": round(ms_4h, 3), "four_call_host_mpixels_per_s": round(W * H / 1e6 / (ms_4h / 1e3), 1),
                          "four_call_host_packed_cells_ms": round(ms_4hp, 3), "four_call_host_one_band_ms": round(ms_4h_flat, 3),
-                         "result_bands": RESULT_BANDS,
+                         "result_bands": live_b,
                          "level_call_host_ms": round(ms_lh, 3), "four_call_device_ms": round(ms_4d, 3),
                          "four_call_device_vs_headline": round(ms_4d / (dt * 1e3 / args.steps), 3),
                          "results_equal_headline": same_b,

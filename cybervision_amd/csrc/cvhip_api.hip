@@ -1058,12 +1058,15 @@ int level_search(cvhip_ctx *ctx, bool with_filters, uint32_t w1, uint32_t h1, ui
     // where the geometry is row-local (the bound D of independent-band mode) and the bands are tall enough; the reverse
     // filter of the last level is deferred anyway (rev_cross_check_pending).
     uint32_t nb = 1, reach = 0;
-    if (with_filters && k == 0 && !first_pass && ctx->result_bands > 1 && !sharded && !ctx->band_mode && !ctx->time_kernels &&
+    if (with_filters && k == 0 && !first_pass && ctx->result_bands != 1 && !sharded && !ctx->band_mode && !ctx->time_kernels &&
         !ctx->count_candidates && h1 == h2) {
         double df = 0.0, dr = 0.0;
         if (host_minor_offset_bound(ctx, 0, 0, w1, h1, w2, h2, &df) && host_minor_offset_bound(ctx, 1, 0, w2, h2, w1, h1, &dr)) {
             reach = ((uint32_t)std::max(df, dr) + CROSS_CHECK_SEARCH_AREA + 4 + 3) / 4 * 4;
-            nb = std::min<uint32_t>(ctx->result_bands, 16u);
+            // (0 = the library's choice: a band of at least half a megapixel, six at most - 1024^2: 2, 2048^2 and up: 6;
+            // smaller bands cost more in launch tails than their transfer hides, scripts/result_bands_probe.py)
+            nb = ctx->result_bands ? std::min<uint32_t>(ctx->result_bands, 16u)
+                                   : (uint32_t)std::min<size_t>(6, std::max<size_t>(1, ((size_t)w1 * h1) >> 19));
             while (nb > 1 && (h1 / nb) / 4 * 4 < 2 * reach + 64) nb--;
         }
     }
@@ -1221,7 +1224,7 @@ int cvhip_correlate_images(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uin
         lc.img2 == img1 && lc.w1 == w2 && lc.h1 == h2 && lc.w2 == w1 && lc.h2 == h1) {
         // the reverse call of the level whose forward call was taken in: the images are staged (exchanged), their
         // statistics computed - both search passes go out together, as in cvhip_correlate_level
-        if (k == 0 && !first_pass && ctx->result_bands > 1) {
+        if (k == 0 && !first_pass && ctx->result_bands != 1) {
             // result bands: the last level's launches interleave search and filter, so they wait for the two filter calls
             // (any other call first: flush_level_calls runs what was asked for so far, unbanded)
             lc.stage = cvhip_ctx::LevelCalls::HELD;
@@ -1735,7 +1738,7 @@ int cvhip_ctx_set_fuse_level_calls(cvhip_ctx *ctx, int enable)
 int cvhip_ctx_set_result_bands(cvhip_ctx *ctx, uint32_t bands)
 {
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
-    if (bands == 0 || bands > 16) return fail(CVHIP_ERR_INVALID, "result bands: 1 .. 16");
+    if (bands > 16) return fail(CVHIP_ERR_INVALID, "result bands: 0 (the library's choice), 1 .. 16");
     CVHIP_TRY(flush_level_calls(ctx));
     ctx->result_bands = bands;
     return CVHIP_OK;

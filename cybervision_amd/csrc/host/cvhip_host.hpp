@@ -103,7 +103,7 @@ class PointCorrelations { // correlation/mod.rs:63-245, GPU branch
               "cvhip_ctx_create");
         // complete() always lands in host memory: the last level goes out in row bands, each crossing PCIe under the
         // search of the next (same grid)
-        check(cvhip_ctx_set_result_bands(ctx_, 6), "cvhip_ctx_set_result_bands");
+        check(cvhip_ctx_set_result_bands(ctx_, 0), "cvhip_ctx_set_result_bands"); // (0: the library's choice by size)
     }
     ~PointCorrelations() { cvhip_ctx_destroy(ctx_); }
     PointCorrelations(const PointCorrelations &) = delete;

@@ -112,7 +112,9 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
  * `bands` row bands, and cvhip_complete_dir(dir 0) into HOST memory expands and copies band b out on the copy stream
  * while the bands behind it are still being searched - the 201 MB grid of a 4096^2 pair then costs ~1.5 ms beyond the
  * search instead of ~4.5.  The result is the one of bands == 1, bit for bit (tests/test_corr_gpu.py).  In the fused
- * four-call mode the last level's launches wait for its two cross_check_filter calls.  Default 1; at most 16.
+ * four-call mode the last level's launches wait for its two cross_check_filter calls.  Default 1 (off); at most 16;
+ * 0 = the library chooses by size (bands of at least half a megapixel, six at most - what a binding whose grid always goes
+ * to the host should pass).
  * Replaces nothing in the reference (its complete() maps one buffer after the last submission, gpu/mod.rs:321-349). */
 int cvhip_ctx_set_result_bands(cvhip_ctx *ctx, uint32_t bands);
 /* How many bands the grid now held went out in (1: not banded - the geometry, the size or the call order ruled it out). */

@@ -14,8 +14,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bands", default="1,2,4,6,8,12,16")
 ap.add_argument("--modes", default="pinned,four_call_host,device,pinned_packed,four_call_host_packed")
 ap.add_argument("--pairs", type=int, default=8)
+ap.add_argument("--size", type=int, default=4096)
 args = ap.parse_args()
-W = H = 4096
+W = H = args.size
 steps = synth.optimal_scale_steps(W, H)
 a, b, _ = synth.make_pair_torch(W, H, device="cuda")
 pa, pb = synth.box_pyramid_torch(a, steps), synth.box_pyramid_torch(b, steps)
