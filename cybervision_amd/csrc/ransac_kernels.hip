@@ -2782,7 +2782,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     std::memset(&h_best, 0, sizeof(h_best));
     uint32_t late_count = 0;
     const uint4 *m4 = reinterpret_cast<const uint4 *>(d_m);
-    // Two streams, GEN_DEPTH hypothesis buffers of GEN_BATCH rounds: the batches after the one being SCORED (the handle's
+    // GEN_STREAMS side streams, GEN_DEPTH hypothesis buffers of GEN_BATCH rounds: the batches after the one being SCORED (the handle's
     // stream; the best-so-far chain lives there) are GENERATED on the side streams (samples depend on the seed and the
     // round number only), one batch per stream at a time.  The generator's tail - a few long Levenberg-Marquardt loops
     // on a few hundred waves that need a whole SIMD's registers each - cannot get onto the chip while the counting kernel
@@ -2874,7 +2874,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
                 uint32_t k = GEN_STREAMS;
                 for (uint32_t c = 0; c < GEN_STREAMS && k == GEN_STREAMS; c++)
                     if (generated(stream_unit[(turn + c) % GEN_STREAMS])) k = (turn + c) % GEN_STREAMS; // an idle stream, in turn
-                if (k == GEN_STREAMS) break; // both are busy - one of them perhaps for long: decided when one comes free
+                if (k == GEN_STREAMS) break; // all are busy - one of them perhaps for long: decided when one comes free
                 turn = k + 1;
                 e = generate_unit_on(next_gen, b, k, buf_used[b]);
                 buf_of[next_gen] = b;
