@@ -58,7 +58,7 @@ for it in range(N):
         if four_calls:
             pc.set_fuse_level_calls(True)
         # result bands (cvhip_ctx_set_result_bands; taken where the geometry and the height allow) and packed cells
-        bands = int(rng.integers(1, 5))
+        bands = int(rng.integers(0, 5))   # (0: the library's choice by size)
         pc.set_result_bands(bands)
         for i in range(steps + 1):
             k = steps - i
