@@ -49,6 +49,7 @@ DOT4_PEAK_TMACS = 256 * 4 * 64 * 4 / 4 * 2.4e9 / 1e12   # = 157.3 T multiply-add
 RESULT_BANDS = 0                 # cvhip_ctx_set_result_bands in the host-destination modes: 0 = the library's choice by size (the
                                  # binding's setting; 6 bands at 4096^2, scripts/result_bands_probe.py)
 SEARCH_KERNEL = "search3_box_kernel"   # the kernel class "search" times (search version 3, the default)
+SEARCH_KERNEL_INST = "search3_box_kernel<false, false, false>"   # the instantiation the timed region launches (no candidate counter)
 
 
 def algorithmic_work(level_dims, candidates):
@@ -101,7 +102,7 @@ def traffic_per_launch(world):
     d = _profile_json("current_traffic.json")
     if world != 1 or not d:
         return None
-    k = d["kernels"].get(SEARCH_KERNEL)
+    k = d["kernels"].get(SEARCH_KERNEL_INST)
     return round(k["hbm_bytes_per_step"] / k["launches_per_step"]) if k else None
 
 
@@ -118,9 +119,9 @@ def valu_profile(world):
     (scripts/collect_pmc.py -> profiles/current_pmc.json): wave-instructions per step, and for the full-resolution
     launch the pipe-busy fraction SQ_ACTIVE_INST_VALU * 4 / SIMDs / (GRBM_GUI_ACTIVE / XCDs)."""
     d = _profile_json("current_pmc.json")
-    if world != 1 or not d or SEARCH_KERNEL not in d["kernels"]:
+    if world != 1 or not d or SEARCH_KERNEL_INST not in d["kernels"]:
         return None
-    k = d["kernels"][SEARCH_KERNEL]
+    k = d["kernels"][SEARCH_KERNEL_INST]
     big = k.get("largest_launch", {})
     return {"wave_instr_per_step": k.get("SQ_INSTS_VALU"), "valu_busy": big.get("valu_busy"),
             "cycles_per_valu_instr": big.get("cycles_per_valu_instr")}
@@ -220,6 +221,9 @@ def main():
                     help="dense4096 (default): the headline metric; sfm3: BASELINE config 5, a secondary line")
     ap.add_argument("--pencil", type=int, default=0, choices=[0, 1], help="--config sfm3: 7-point pencil (0 = the reference's thin-SVD rows, 1 = null space)")
     ap.add_argument("--no-extras", action="store_true", help="skip readback / geometry_sweep / sfm3 in the headline line")
+    ap.add_argument("--no-count-step", action="store_true",
+                    help="profiling runs (scripts/_run_prof.sh): skip the untimed candidate-counting step, so that every step of the "
+                         "run launches the same kernel instantiations; the line then carries no candidate count")
     ap.add_argument("--sweep-tilts", default="3,10,30,45,60,90", help="tilts (degrees) of geometry_sweep")
     args = ap.parse_args()
     if args.config == "sfm3":
@@ -388,11 +392,13 @@ def main():
         torch.cuda.synchronize()
 
     # one counting pass (untimed): candidates evaluated per step, needed for the flop count
-    pc.set_profiling(False, True)
-    step()
-    cand_local = pc.get_counters()["candidates"]
-    pc.set_profiling(False, False)
-    for _ in range(max(args.warmup - 1, 0)):
+    cand_local = 0
+    if not args.no_count_step:
+        pc.set_profiling(False, True)
+        step()
+        cand_local = pc.get_counters()["candidates"]
+        pc.set_profiling(False, False)
+    for _ in range(max(args.warmup - (0 if args.no_count_step else 1), 0)):
         step()
     fence()
     # The timed region: K steps.  HIP events are live inside it - they bracket every launch of the dominant

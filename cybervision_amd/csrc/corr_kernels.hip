@@ -1574,11 +1574,13 @@ __device__ __forceinline__ uint32_t load_dword_checked(const uint8_t *__restrict
 // Launch bound of the lean instantiation: 6 waves/SIMD (76 VGPRs, no spill).  7 waves - what its 22.5 KB of LDS would
 // admit - was measured 1.8 % faster (5.89 vs 6.00 ms per 4096^2 pair) but only with 10 VGPRs spilled: 28 B of scratch
 // per lane x 54 M threads put +1.17 GB per step on the L2 write-back counter (whole step 3.0 -> 4.2 GB).  Not taken.
+// (the candidate-counting instantiations - profiling and tests only - need 85 registers (lean) and ~100 (stepped): five and
+// four waves rather than 28 B of scratch)
 #ifndef CVHIP_STEP_WAVES
 #define CVHIP_STEP_WAVES 5
 #endif
 template <bool COUNT, bool STEP, bool TR>
-__global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void search3_box_kernel(SearchJob ja, SearchJob jb)
+__global__ __launch_bounds__(256, STEP ? (COUNT ? 4 : CVHIP_STEP_WAVES) : ((TR || COUNT) ? 5 : 6)) void search3_box_kernel(SearchJob ja, SearchJob jb)
 {
     const SearchJob &j = this_job(); // both directions of a level in one launch (see search_range_kernel)
     const CorrParams &p = j.p;
@@ -1597,7 +1599,7 @@ __global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void s
 // either 24 spilled VGPRs or one wave of occupancy (3-degree pair, level 0: 5.7 ms -> 7.6 / 6.6 ms), so their two
 // directions stay two launches of this form.
 template <bool COUNT, bool STEP, bool TR, bool WIDE>
-__global__ __launch_bounds__(256, STEP ? CVHIP_STEP_WAVES : (TR ? 5 : 6)) void search3_box_single_kernel(
+__global__ __launch_bounds__(256, STEP ? (COUNT ? 4 : CVHIP_STEP_WAVES) : (TR ? 5 : 6)) void search3_box_single_kernel(
     CorrParams p, const uint8_t *__restrict__ img1, const uint8_t *__restrict__ img2, const uint2 *__restrict__ stats1,
     const uint2 *__restrict__ istats1, const uint2 *__restrict__ istats2, const uint32_t *__restrict__ range,
     unsigned long long *__restrict__ contenders, uint32_t *__restrict__ out, float *__restrict__ out_score,

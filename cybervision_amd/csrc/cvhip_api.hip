@@ -208,6 +208,7 @@ static int copy_stream_reserve(Device &d)
     if (rb.stream) return CVHIP_OK;
     CVHIP_TRY_HIP(hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
     CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.ready, hipEventDisableTiming));
+    CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.expanded, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.done[i], hipEventDisableTiming));
     return CVHIP_OK;
 }
@@ -684,6 +685,7 @@ void device_free(cvhip_device *dev)
             if (rb.done[i]) (void)hipEventDestroy(rb.done[i]);
         }
         if (rb.ready) (void)hipEventDestroy(rb.ready);
+        if (rb.expanded) (void)hipEventDestroy(rb.expanded);
         auto &up = dev->d.up; // (the copy stream has drained: no transfer reads the ring any more)
         for (auto &c : up.busy) (void)hipEventDestroy(c.done);
         for (hipEvent_t ev : up.spare) (void)hipEventDestroy(ev);
@@ -1058,8 +1060,10 @@ int level_search(cvhip_ctx *ctx, bool with_filters, uint32_t w1, uint32_t h1, ui
     // where the geometry is row-local (the bound D of independent-band mode) and the bands are tall enough; the reverse
     // filter of the last level is deferred anyway (rev_cross_check_pending).
     uint32_t nb = 1, reach = 0;
-    if (with_filters && k == 0 && !first_pass && ctx->result_bands != 1 && !sharded && !ctx->band_mode && !ctx->time_kernels &&
-        !ctx->count_candidates && h1 == h2) {
+    // (not under asynchronous readback: there the whole transfer runs under the NEXT pair's search, and the context's stream
+    // must follow the last band's expansion, which would stand behind the earlier bands' copies)
+    if (with_filters && k == 0 && !first_pass && ctx->result_bands != 1 && !ctx->async_readback && !sharded && !ctx->band_mode &&
+        !ctx->time_kernels && !ctx->count_candidates && h1 == h2) {
         double df = 0.0, dr = 0.0;
         if (host_minor_offset_bound(ctx, 0, 0, w1, h1, w2, h2, &df) && host_minor_offset_bound(ctx, 1, 0, w2, h2, w1, h1, &dr)) {
             reach = ((uint32_t)std::max(df, dr) + CROSS_CHECK_SEARCH_AREA + 4 + 3) / 4 * 4;
@@ -1403,6 +1407,12 @@ static int complete_grid(cvhip_ctx *ctx, int dir, int32_t *out_xy, float *out_co
             CVHIP_TRY_HIP(hipStreamWaitEvent(rb.stream, ctx->band_done[b], 0));
             launch_expand_grid(ds.cells[ds.cur], ds.scores_valid ? ds.scores : nullptr, ds.lw, ds.lh, 0, ds.gw, ds.gh, d_xy, d_corr,
                                rb.stream, r0, r1, packed);
+            // The expansions read this level's match and score planes on the COPY stream: whatever the context's stream does
+            // next (the next pair's levels rewrite both) must follow the last of them, host-synchronous call or not.
+            if (b + 1 == ctx->live_bands) {
+                CVHIP_TRY_HIP(hipEventRecord(rb.expanded, rb.stream));
+                CVHIP_TRY_HIP(hipStreamWaitEvent(s, rb.expanded, 0));
+            }
             if (!xy_dev)
                 CVHIP_TRY_HIP(hipMemcpyAsync(out_xy + words * o, d_xy + words * o, m * words * sizeof(int32_t), hipMemcpyDeviceToHost, rb.stream));
             if (out_corr && !corr_dev)

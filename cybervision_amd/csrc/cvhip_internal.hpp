@@ -217,6 +217,7 @@ struct Device {
         size_t cap_px = 0;
         hipStream_t stream = nullptr;
         hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
+        hipEvent_t expanded = nullptr; // behind the last band's expansion on the copy stream (complete_grid)
         bool pending[2] = {false, false};
         int next = 0;
     } rb;

@@ -1406,11 +1406,13 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
         // ---- the images with a keypoint inside the guard band (rare), or all of them with the guard off: orientation
         // on the host with libm, exactly as the reference (orb.rs:337-341, 365-366), and their descriptors again
         std::vector<OrbJob *> redo;
+        // (the describe step's status word: open-count | ORB_BAD_INDEX; written by every describe(), first pass or redo)
+        const auto status_of = [&](const OrbJob &j) { return reinterpret_cast<const uint32_t *>(stage + j.pack_off)[1]; };
+        const char *const bad_index = "orb_extract: a sorted corner index is outside the corner list (device sort failed)";
         for (OrbJob &j : jobs)
-            if (j.n_fast && guard > 0.0 && (reinterpret_cast<const uint32_t *>(stage + j.pack_off)[1] & ORB_BAD_INDEX))
-                return fail(CVHIP_ERR_DEVICE, "orb_extract: a sorted corner index is outside the corner list (device sort failed)");
+            if (j.n_fast && guard > 0.0 && (status_of(j) & ORB_BAD_INDEX)) return fail(CVHIP_ERR_DEVICE, bad_index);
         for (OrbJob &j : jobs)
-            if (j.n_fast && (guard <= 0.0 || reinterpret_cast<const uint32_t *>(stage + j.pack_off)[1] != 0u)) redo.push_back(&j);
+            if (j.n_fast && (guard <= 0.0 || (status_of(j) & ~ORB_BAD_INDEX) != 0u)) redo.push_back(&j);
         if (!redo.empty()) {
             if (guard > 0.0) {
                 for (OrbJob *j : redo) CVHIP_TRY_HIP(hipMemcpyAsync(stage + j->mom_off, j->d_mom, j->mom_bytes, hipMemcpyDeviceToHost, s));
@@ -1463,6 +1465,9 @@ extern "C" int cvhip_orb_extract_batch(cvhip_device *dev, uint32_t n_images, con
             }
             CVHIP_TRY_HIP(hipStreamSynchronize(s));
             CVHIP_TRY_HIP(hipGetLastError());
+            // the redone descriptions report a bad index the same way - with the guard off they are the only ones
+            for (const OrbJob *j : redo)
+                if (status_of(*j) & ORB_BAD_INDEX) return fail(CVHIP_ERR_DEVICE, bad_index);
         }
         for (uint32_t i = 0; i < n_images; i++) {
             OrbJob &j = jobs[i];

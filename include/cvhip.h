@@ -112,7 +112,8 @@ int cvhip_correlate_level(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint
  * `bands` row bands, and cvhip_complete_dir(dir 0) into HOST memory expands and copies band b out on the copy stream
  * while the bands behind it are still being searched - the 201 MB grid of a 4096^2 pair then costs ~1.5 ms beyond the
  * search instead of ~4.5.  The result is the one of bands == 1, bit for bit (tests/test_corr_gpu.py).  In the fused
- * four-call mode the last level's launches wait for its two cross_check_filter calls.  Default 1 (off); at most 16;
+ * four-call mode the last level's launches wait for its two cross_check_filter calls.  Under cvhip_ctx_set_async_readback
+ * the level is not banded (the whole transfer runs under the next pair's search there).  Default 1 (off); at most 16;
  * 0 = the library chooses by size (bands of at least half a megapixel, six at most - what a binding whose grid always goes
  * to the host should pass).
  * Replaces nothing in the reference (its complete() maps one buffer after the last submission, gpu/mod.rs:321-349). */
@@ -238,8 +239,12 @@ int cvhip_ctx_level_grid(cvhip_ctx *ctx, int dir, void **cells, void **scores, u
 /* Use device-resident level images where they are instead of copying them into the context's own padded
  * buffers first.  By enabling this the caller guarantees, for every DEVICE pointer it passes as a level image:
  * at least 64 readable bytes after the last pixel (the kernels read whole dwords at row ends), and that the
- * image stays unchanged until the work of the call has completed on the device's stream.  Host images are
- * still copied.  Off by default. */
+ * image stays unchanged until the work of the call has completed on the device's stream.  Under
+ * cvhip_ctx_set_fuse_level_calls the work of a level's correlate calls is enqueued by LATER calls - both directions in
+ * one launch at the reverse call, and with result bands (cvhip_ctx_set_result_bands != 1) the whole last level at its
+ * second cvhip_cross_check_filter call - so borrowed images of a level must then stay unchanged until that level's
+ * second cvhip_cross_check_filter call (or cvhip_complete) has completed on the stream.  Host images are still
+ * copied.  Off by default. */
 int cvhip_ctx_set_borrow_inputs(cvhip_ctx *ctx, int borrow);
 /* The reference issues FOUR backend calls per pyramid level (PointCorrelations::correlate_images, correlation/mod.rs:
  * 217-245): correlate_images forward, correlate_images reverse with the SAME two images exchanged, cross_check_filter

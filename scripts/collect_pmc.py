@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Turn a rocprofv3 --pmc SQ pass of `bench.py --steps 1 --warmup 1 --no-cpu-baseline` into profiles/<tag>_pmc.json:
-per kernel (template instantiations together), summed over the launches of ONE bench step.
+"""Turn a rocprofv3 --pmc SQ pass of `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-count-step` into
+profiles/<tag>_pmc.json: per kernel INSTANTIATION (template arguments kept: `search3_box_kernel<false, false, false>` is the
+timed one, `<true, ...>` the candidate-counting one - they are different kernels), summed over the launches of ONE bench
+step.  The profiled run must hold identical steps only (--no-count-step: timed step + instrumented step = 2).
 
     rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
               GRBM_GUI_ACTIVE -d <dir> --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
@@ -24,7 +26,7 @@ launches = defaultdict(set)
 per_dispatch = defaultdict(lambda: defaultdict(float))
 grid = {}
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cvhip::", "").split("<")[0]
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cvhip::", "").strip()
     acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
     launches[name].add(r["Dispatch_Id"])
     per_dispatch[(name, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -61,7 +63,7 @@ for _rel in ("cybervision_amd/csrc/corr_kernels.hip", "cybervision_amd/csrc/box_
 res["kernel_source_sha16"] = _h.hexdigest()[:16]
 res["git_head"] = os.environ.get("CVHIP_GIT_HEAD")
 json.dump(res, open(out, "w"), indent=1)
-for n in ("search3_box_kernel", "window_stats_kernel", "search_range_kernel", "cross_check_kernel"):
-    if n in res["kernels"]:
+for n in sorted(res["kernels"]):
+    if n.split("<")[0] in ("search3_box_kernel", "window_stats_kernel", "search_range_kernel", "cross_check_kernel"):
         k = res["kernels"][n]
         print(n, {x: k.get(x) for x in ("launches_per_step", "valu_busy", "valu_instr_per_wave", "SQ_INSTS_VALU", "SQ_WAVES")})

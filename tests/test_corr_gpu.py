@@ -383,6 +383,50 @@ def test_result_bands_give_the_same_grid(gpu_device, oracle, name, bands, expect
             pc.close()
 
 
+def test_result_bands_with_async_readback_on_one_context(gpu_device):
+    """Result bands requested together with cvhip_ctx_set_async_readback on ONE context over four pairs (the
+    band expansions read the level's planes on the copy stream while the context's stream may already rewrite them for the
+    next pair).  Under asynchronous readback the level is not banded, and a banded grid completed after the mode was
+    switched on is ordered by an event behind its last expansion: every pair's page-locked grid must be the synchronous
+    one, bit for bit.  Two different pairs alternate so that a stale plane would show."""
+    import torch
+
+    pairs = []
+    for seed in (5, 6):
+        a, b, _ = synth.make_pair(1280, 1024, seed=seed)
+        c = {"img1": a, "img2": b, "F": synth.F_HORIZONTAL, "projection": 0, "steps": synth.optimal_scale_steps(1280, 1024)}
+        pairs.append((c, cases.pyramids(c), run_gpu(gpu_device, c)))
+    for switch_late in (False, True):
+        pc = correlation.PointCorrelations(gpu_device, (1280, 1024), (1280, 1024), synth.F_HORIZONTAL)
+        pc.set_result_bands(4)
+        host = [(torch.empty((1024, 1280, 2), dtype=torch.int32).pin_memory(), torch.empty((1024, 1280), dtype=torch.float32).pin_memory())
+                for _ in range(4)]
+        try:
+            if not switch_late:
+                pc.set_async_readback(True)
+            for it in range(4):
+                c, (p1, p2), _ = pairs[it & 1]
+                pc.first_pass = True
+                for i in range(c["steps"] + 1):
+                    k = c["steps"] - i
+                    pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+                assert pc.result_bands() == (4 if switch_late else 1)
+                if switch_late:
+                    pc.set_async_readback(True)   # the level went out in bands; the completion is asynchronous
+                host[it][0].fill_(7)
+                pc.complete(out_xy=host[it][0].numpy(), out_corr=host[it][1].numpy())
+                if switch_late:
+                    pc.set_async_readback(False)
+            gpu_device.synchronize()
+            for it in range(4):
+                want = pairs[it & 1][2]
+                valid = want[0][..., 0] >= 0
+                assert (host[it][0].numpy() == want[0]).all(), (switch_late, it)
+                assert (host[it][1].numpy().view(np.uint32)[valid] == want[1].view(np.uint32)[valid]).all(), (switch_late, it)
+        finally:
+            pc.close()
+
+
 @pytest.mark.parametrize("tilt", [0.0, 1.5])
 def test_result_bands_large_pair(gpu_device, tilt):
     """Four and eight result bands on a 1536 x 1280 pair with disparity discontinuities against the unbanded level (both on
@@ -926,6 +970,12 @@ def test_config3_4096_matches_oracle_digest(gpu_device):
         assert hashlib.sha256(np.ascontiguousarray(xy, dtype=np.int32).tobytes()).hexdigest() == want[name]["xy_sha256"], name
         score_bits = np.where(valid, corr.view(np.uint32), np.uint32(0))
         assert hashlib.sha256(np.ascontiguousarray(score_bits).tobytes()).hexdigest() == want[name]["score_sha256"], name
+    # the default mode - no counters, i.e. the <COUNT = false> instantiations the bench times; scores of the observable pass
+    # only - gives the same forward grid: positions everywhere, score bits wherever there is a match
+    got = run_gpu(gpu_device, c)
+    assert (got[0] == fwd[0]).all()
+    valid = fwd[0][..., 0] >= 0
+    assert (got[1].view(np.uint32)[valid] == fwd[1].view(np.uint32)[valid]).all()
 
 
 @pytest.mark.parametrize("fixture", ["corr_tilt10_4096_digest.json", "corr_tilt45_4096_digest.json", "corr_tilt60_4096_digest.json",
@@ -1240,3 +1290,31 @@ def test_library_rccl_path_world1(oracle):
         pc.close()
         dev.close()    # deferred: the communicator still references the handle
         comm.close()   # releases both
+
+
+def test_library_rccl_path_world2():
+    """The library's RCCL path at world size 2, one process per GPU (tests/_rccl_gpu_worker.py): runs wherever the box has two
+    or more GPUs - the first multi-GPU node this suite meets - and is skipped on the one-GPU boxes of this pool.  The in-place
+    ncclAllGather after every sharded pass must leave the golden grid on every rank; the grouped ncclSend / ncclRecv gather of
+    independent-band mode must leave it on rank 0."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(root / "tests" / "_rccl_gpu_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {rank} ok" in out, out
