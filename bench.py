@@ -127,7 +127,7 @@ def valu_profile(world):
             "cycles_per_valu_instr": big.get("cycles_per_valu_instr")}
 
 
-def measure_sfm3(size, steps, warmup, dev=None, pencil=0, listener=True):
+def measure_sfm3(size, steps, warmup, dev=None, pencil=0, listener=True, lanczos=False):
     """BASELINE config 5 ("3-image perspective SFM: ORB + RANSAC F-matrix on GPU + pairwise dense correlation"):
     three synthetic size^2 perspective views, resident in HBM as u8 pyramids; one step = per-level ORB on the three
     images, 3 x matcher (threshold 48), 3 x perspective find_ransac (device RANSAC + LM refit), 3 x dense correlation
@@ -147,6 +147,9 @@ def measure_sfm3(size, steps, warmup, dev=None, pencil=0, listener=True):
     pyr = [[torch.from_numpy(l).cuda() for l in synth.box_pyramid(v, lsteps)] for v in views]
     # (resident, padded, complete before the timed region: the dense stage uses the levels in place)
     pyr = [reconstruction.padded_pyramid(p)[0] for p in pyr]
+    # lanczos: the reference's own pyramids instead - Lanczos3 resizes of the full-resolution views on the device, inside the
+    # step, rebuilt per stage as reconstruction.rs:146-162, 421-422, 567-568 does (a different workload: other level images)
+    images = [torch.from_numpy(v).cuda() for v in views] if lanczos else None
     # the 7-point pencil: 0 = rows 5 / 6 of the thin SVD as the reference writes it (the library's default), 1 = null space
     fundamentalmatrix.set_pencil(dev, pencil)
     acc, n_pairs, matches, inliers, dense_cells = {}, 0, [], [], []
@@ -156,7 +159,7 @@ def measure_sfm3(size, steps, warmup, dev=None, pencil=0, listener=True):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             acc = {}
-        res = reconstruction.reconstruct_pairs(dev, pyr, ProjectionMode.Perspective, seed=5, borrow=True, listener=listener)
+        res = reconstruction.reconstruct_pairs(dev, pyr, ProjectionMode.Perspective, seed=5, borrow=True, listener=listener, images=images)
         for k, v in res["timings_ms"].items():
             acc[k] = acc.get(k, 0.0) + v
     torch.cuda.synchronize()
@@ -170,7 +173,9 @@ def measure_sfm3(size, steps, warmup, dev=None, pencil=0, listener=True):
     if own_dev:
         dev.close()
     stage_ms = {k: round(v / steps, 3) for k, v in acc.items()}
-    return {"pencil": "thin_svd_rows_5_6 (reference)" if pencil == 0 else "null_space (textbook)",
+    return {"pyramids": ("Lanczos3 on the device inside the step (cvhip_resize_lanczos3), rebuilt per stage as the reference does" if lanczos
+                         else "2x2 box pyramids, prebuilt and resident: SourceImage::resize (reconstruction.rs:146-162) is EXCLUDED from the step"),
+            "pencil": "thin_svd_rows_5_6 (reference)" if pencil == 0 else "null_space (textbook)",
             "ransac_listener": "report_status + report_matches attached (reconstruction.rs:510-518)" if listener else "none", "size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
             "dense_mpixels_per_s": round(n_pairs * size * size / 1e6 / (stage_ms["dense"] / 1e3), 2),
             "whole_pipeline_mpixels_per_s": round(3 * size * size / 1e6 / (dt / steps), 2),
@@ -557,6 +562,47 @@ def main():
                                  "device = the headline's resident pyramid and resident grid through the same four calls"}
         del hp1, hp2, hxy, hcorr, hcells
 
+        # the same four-call host path (pageable level images in, pageable grid out, the binding's settings) on pairs that are
+        # NOT rectified - what an unmodified pipeline sees on real inputs: the 4096^2 pair tilted by 10 degrees (stepped box
+        # launches) and a 2048^2 perspective pair of synth.make_sfm_views with its true F (perspective parameter set)
+        def host_four_call(p1, p2, Fm, proj, n=5):
+            hh, ww = p1[0].shape
+            oxy, oco = np.empty((hh, ww, 2), dtype=np.int32), np.empty((hh, ww), dtype=np.float32)
+            q = correlation.PointCorrelations(dev, (ww, hh), (ww, hh), Fm, proj)
+            q.set_fuse_level_calls(True)
+            q.set_result_bands(RESULT_BANDS)
+            ns = len(p1) - 1
+
+            def one():
+                q.first_pass = True
+                for j in range(ns + 1):
+                    k = ns - j
+                    q.correlate_images(p1[k], p2[k], 1.0 / float(1 << k), fused=False)
+                q.complete(out_xy=oxy, out_corr=oco)
+
+            one()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                one()
+            fence()
+            ms = (time.perf_counter() - t1) * 1e3 / n
+            live = q.result_bands()
+            q.close()
+            return {"ms": round(ms, 3), "mpixels_per_s": round(ww * hh / 1e6 / (ms / 1e3), 1), "size": int(ww), "result_bands": live,
+                    "matched_fraction": round(float((oxy[..., 0] >= 0).mean()), 4)}
+
+        t1p, t2p = resident_pyramids(10.0)
+        boundary_path["four_call_host_tilt10"] = host_four_call([p.cpu().numpy() for p in t1p], [p.cpu().numpy() for p in t2p],
+                                                               synth.f_tilt(10.0), correlation.ProjectionMode.Affine)
+        del t1p, t2p
+        psize = 2048 if W >= 2048 else W
+        views, Kc, poses = synth.make_sfm_views(psize)
+        psteps = synth.optimal_scale_steps(psize, psize)
+        boundary_path["four_call_host_perspective"] = host_four_call(synth.box_pyramid(views[0], psteps), synth.box_pyramid(views[1], psteps),
+                                                                     synth.sfm_true_f(Kc, poses[0], poses[1]), correlation.ProjectionMode.Perspective)
+        del views
+
     pc.close()
     pc = None
     if extras:
@@ -606,8 +652,11 @@ def main():
         sfm3 = measure_sfm3(sfm_size, 5, 1, dev=dev)
         alt = measure_sfm3(sfm_size, 3, 1, dev=dev, pencil=1)
         bare = measure_sfm3(sfm_size, 3, 1, dev=dev, listener=False)
+        lz = measure_sfm3(sfm_size, 3, 1, dev=dev, lanczos=True)
         sfm3["other_modes"] = {"null_space_pencil_with_listener": {"ms_per_step": alt["ms_per_step"], "stage_ms": alt["stage_ms"], "ransac_inliers": alt["ransac_inliers"]},
-                               "reference_pencil_without_listener": {"ms_per_step": bare["ms_per_step"], "stage_ms": bare["stage_ms"]}}
+                               "reference_pencil_without_listener": {"ms_per_step": bare["ms_per_step"], "stage_ms": bare["stage_ms"]},
+                               "lanczos_pyramids_built_in_the_step": {"ms_per_step": lz["ms_per_step"], "stage_ms": lz["stage_ms"], "pyramids": lz["pyramids"],
+                                                                      "ransac_inliers": lz["ransac_inliers"], "dense_matches": lz["dense_matches"]}}
 
     sharded_ok = None
     if world > 1:
@@ -719,6 +768,9 @@ def main():
                                         if band_mode else f"row-sharded x{world}, RCCL all-gather per sharded pass"))
                                       + (f" [EMULATION of shard {sim[0]}/{sim[1]} on one GPU, no collective]" if sim else ""),
                        "candidates_per_step": candidates},
+            # SURVEY 8(d) defines t_dense WITH the final readback of the forward grid (page-locked host destination, the last
+            # level in result bands); `value` is the HBM -> HBM rate the task's bench contract asks for (inputs and grid resident)
+            "value_survey_8d": readback["mpixels_per_s_with_readback_banded"] if readback else None,
             "roofline": roofline,
             # every kernel class, from one extra fully instrumented step after the timed region
             "kernel_ms_per_step": {k: round(v["ms"], 4) for k, v in ktimes.items()},

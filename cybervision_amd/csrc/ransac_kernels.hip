@@ -2245,12 +2245,238 @@ __global__ __launch_bounds__(64) void ransac_lm_run_kernel(const PerspPencil *__
     for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = ok ? f[i] : nan;
 }
 
+// The same two passes with the lanes REFILLED (round 5; cvhip_ransac_set_lm_pipeline(dev, 2), the default).  Above, a wave runs
+// for its slowest root - 8-25 trips in the second pass for a mean of 14, 0-7 in the first - on one wave per SIMD (the scalar
+// loop holds a whole register file), and a launch is a grid of waves most of which find the queue empty: the counters showed
+// 0.6-0.85 waves per SIMD while these kernels run, each issuing well (6-8 cycles per vector instruction) - what was missing
+// was work in the lanes, not issue slots.  Here the grid is persistent (a wave per SIMD) and a lane whose root has left the
+// loop takes the next one off the queue: roots are fetched for all idle lanes of a wave at once, when enough of them are
+// idle (the start of a root - residuals, Jacobian, J'J at the start parameters - is a code path of its own, paid per fetch,
+// not per root), and so is the acceptance tail of the finished ones.  A root's arithmetic is lm::levenberg_marquardt7_lean's,
+// statement for statement - only WHEN a lane executes it has changed - so the values are the scalar loop's, bit for bit
+// (test_device_reference_pencil_matches_thin_svd_rows_per_sample runs all three forms against each other).
+// STOP = true: the first pass (every queued root; a root leaves at its first accepted step, onto `out_queue`);
+// STOP = false: the second pass (the roots of `queue` from their start; a root still running after `budget` trips goes
+// to the call's straggler list, or onto `out_queue` when there is none).  cursor: one zeroed word per launch.
+template <bool STOP>
+__global__ __launch_bounds__(64) void ransac_lm_refill_kernel(const PerspPencil *__restrict__ pencils, double t, double *__restrict__ F,
+                                                               const uint32_t *__restrict__ queue, uint32_t *__restrict__ out_queue, int budget,
+                                                               uint32_t *__restrict__ late_list, uint32_t late_cap, uint32_t *__restrict__ cursor)
+{
+    constexpr uint32_t REFILL_AT = STOP ? 24u : 12u; // idle lanes that trigger a fetch (all of them once the queue is empty)
+    const uint32_t n_items = queue[0];
+    const uint32_t lane = threadIdx.x;
+    const double nan = __builtin_nan("");
+    // lane state: 0 = idle, 1 = in the loop, 2 = left the loop (status in `left`), waiting for the next flush
+    int state = 0, left = 0, iteration = 0;
+    uint32_t g = 0;
+    uint4 sm[7]; // (the sample as integers: 28 registers across the trips; an observation's doubles are made where they are used)
+    // (J'J between the trips lives in LDS, a column per lane: written once per linearisation, read once per trip - 56
+    // registers less across the loop, where the compiler otherwise went to scratch)
+    __shared__ double s_jj[28][64];
+    double q[7], r[7], gv[7], M[9], mu = 0.0, nu = 2.0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        sm[i] = make_uint4(0u, 0u, 0u, 0u);
+        q[i] = r[i] = gv[i] = 0.0;
+    }
+    const auto evaluate = [&](const double (&at)[7], double (&into)[7]) {
+        lm::matrix_of(at, M);
+#pragma unroll
+        for (int i = 0; i < 7; i++) into[i] = lm::residual_of(M, lm::make_obs(sm[i].x, sm[i].y, sm[i].z, sm[i].w));
+    };
+    const auto linearise = [&](const double (&at)[7], const double (&res)[7]) { // J'r and J'J at `at` (levenberg_marquardt7_lean's)
+        lm::matrix_of(at, M);
+        double jj[28];
+#pragma unroll
+        for (int j = 0; j < 7; j++) gv[j] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 28; m++) jj[m] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            double row[7];
+            lm::gradient_of(M, lm::make_obs(sm[k].x, sm[k].y, sm[k].z, sm[k].w), row);
+            int m = 0;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                gv[i] += row[i] * res[k];
+#pragma unroll
+                for (int j = i; j < 7; j++) jj[m++] += row[i] * row[j];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 28; m++) s_jj[m][lane] = jj[m];
+    };
+    const auto largest = [](const double (&v)[7]) {
+        double m = v[0];
+#pragma unroll
+        for (int j = 1; j < 7; j++)
+            if (m < v[j]) m = v[j];
+        return m;
+    };
+    const auto norm7 = [](const double (&v)[7]) { return sqrt(lm::long_dot(v, 1, v, 1, 7)); };
+
+    bool exhausted = false; // (wave-uniform) the queue has been handed out
+    for (;;) {
+        const unsigned long long busy = __builtin_amdgcn_ballot_w64(state == 1);
+        const uint32_t n_free = 64u - (uint32_t)__builtin_popcountll(busy);
+        const bool refill = !exhausted && (n_free >= REFILL_AT || busy == 0ull);
+        const bool drain = exhausted && busy == 0ull; // the queue is handed out and every root has left the loop: the last flush
+        if (refill || drain) {
+            // ---- flush: the acceptance tail of the roots that have left the loop (validate_f after the LM, :206-209, 412-423)
+            if (state == 2) {
+                if (left == lm::LM_EVENT_ACCEPTED) {
+                    out_queue[1u + atomicAdd(&out_queue[0], 1u)] = g; // (F[g] still holds the start parameters)
+                } else if (left == lm::LM_EVENT_BUDGET) {
+                    if (!late_list) {
+                        out_queue[1u + atomicAdd(&out_queue[0], 1u)] = g;
+                    } else {
+                        const uint32_t at = atomicAdd(&late_list[0], 1u);
+                        if (at < late_cap) {
+                            LateRoot &lr = reinterpret_cast<LateRoot *>(late_list + 64)[at];
+#pragma unroll
+                            for (int i = 0; i < 7; i++) {
+                                lr.sm[i] = sm[i];
+                                lr.q[i] = F[(size_t)g * 9 + i];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = nan;
+                    }
+                } else {
+                    double f[9];
+                    const bool ok = left == 1 && perspective_root_accept(q, sm, t, f);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) F[(size_t)g * 9 + i] = ok ? f[i] : nan;
+                }
+                state = 0;
+            }
+            // ---- fetch: the next roots of the queue for the idle lanes, and the start of least_squares for them (:542-558)
+            if (!exhausted) {
+                const unsigned long long idle = __builtin_amdgcn_ballot_w64(state == 0);
+                const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(cursor, n_idle);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t item = base + rank;
+                exhausted = base + n_idle >= n_items;
+                if (state == 0 && item < n_items) {
+                    g = queue[1u + item];
+                    const PerspPencil &pc = pencils[g / 3u];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) sm[i] = pc.sm[i];
+#pragma unroll
+                    for (int j = 0; j < 7; j++) q[j] = F[(size_t)g * 9 + j];
+                    evaluate(q, r);
+                    linearise(q, r);
+                    state = 1;
+                    iteration = 0;
+                    if (fabs(largest(gv)) <= 1e-12) {
+                        state = 2;
+                        left = 1;
+                    }
+                    mu = 0.0;
+                    {
+                        int m = 0;
+#pragma unroll
+                        for (int j = 0; j < 7; j++) {
+                            const double djj = s_jj[m][lane];
+                            if (j == 0 || djj >= mu) mu = djj;
+                            m += 7 - j;
+                        }
+                    }
+                    mu *= 1e-3;
+                    nu = 2.0;
+                }
+            }
+            if (drain) break;
+            continue;
+        }
+        // ---- one trip of the loop (:560-617) for the lanes that are in it
+        if (state == 1) {
+            if (iteration >= budget) { // (the reference's cap is 1000)
+                state = 2;
+                left = lm::LM_EVENT_BUDGET;
+            } else {
+                double A[49], step[7];
+                {
+                    int m = 0;
+#pragma unroll
+                    for (int i = 0; i < 7; i++)
+#pragma unroll
+                        for (int j = i; j < 7; j++) {
+                            const double v = s_jj[m++][lane];
+                            A[i * 7 + j] = v;
+                            A[j * 7 + i] = v;
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < 7; i++) A[i * 7 + i] += mu;
+#pragma unroll
+                for (int j = 0; j < 7; j++) step[j] = gv[j];
+                if (!lm::solve7(A, step)) {
+                    state = 2;
+                    left = 0;
+                } else if (norm7(step) <= 1e-12 * (norm7(q) + 1e-12)) {
+                    state = 2;
+                    left = 1;
+                } else {
+                    double trial[7], damped[7], r_new[7];
+#pragma unroll
+                    for (int j = 0; j < 7; j++) trial[j] = q[j] + step[j];
+                    evaluate(trial, r_new);
+                    const double before = lm::long_dot(r, 1, r, 1, 7);
+                    const double after = lm::long_dot(r_new, 1, r_new, 1, 7);
+#pragma unroll
+                    for (int j = 0; j < 7; j++) damped[j] = step[j] * mu + gv[j];
+                    const double rho = (before - after) / lm::long_dot(step, 1, damped, 1, 7);
+                    if (rho > 0.0) {
+                        if (STOP) {
+                            state = 2;
+                            left = lm::LM_EVENT_ACCEPTED;
+                        } else {
+                            const bool converged = sqrt(before) - sqrt(after) < 0.0 * sqrt(before);
+#pragma unroll
+                            for (int j = 0; j < 7; j++) {
+                                r[j] = r_new[j];
+                                q[j] = trial[j];
+                            }
+                            linearise(q, r);
+                            if (converged || fabs(largest(gv)) <= 1e-12) {
+                                state = 2;
+                                left = 1;
+                            }
+                            const double w = 2.0 * rho - 1.0, shrink = 1.0 - w * w * w;
+                            mu *= shrink > 1.0 / 3.0 ? shrink : 1.0 / 3.0;
+                            nu = 2.0;
+                        }
+                    } else {
+                        mu *= nu;
+                        nu *= 2.0;
+                    }
+                    if (state == 1 && sqrt(lm::long_dot(r, 1, r, 1, 7)) <= 1e-12) {
+                        state = 2;
+                        left = 1;
+                    }
+                    iteration++;
+                    if (state == 1 && iteration >= 1000) { // "Levenberg-Marquardt failed to converge"
+                        state = 2;
+                        left = 0;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // queues: LM_QUEUES lists of 1 + 3 H words, `stride` words apart (the root kernel's queue, the roots whose first step was
 // accepted, the stragglers)
 // H samples: `per_round` each of the rounds round0, round0 + 1, ... (H a multiple of per_round)
+constexpr uint32_t LM_REFILL_WAVES = 1024; // persistent waves of the refilled LM kernels: one per SIMD (256 CUs x 4)
 constexpr int LM_THREAD_BUDGET = 48; // iterations a root gets in a thread-per-root kernel (thin-SVD pencil: the oracle's longest of 3 000 was 30)
-constexpr int LM_QUEUES = 3;
-static void launch_generate_perspective(int pencil, bool lm_pipeline, const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round0,
+constexpr int LM_QUEUES = 4; // (the last list is not a list: its first words are the refilled kernels' queue cursors)
+static void launch_generate_perspective(int pencil, int lm_pipeline, const uint4 *m4, uint32_t limit, double t, unsigned long long seed, uint32_t round0,
                                         uint32_t per_round, uint32_t H, const uint32_t *sample_idx, PerspPencil *pencils,
                                         uint32_t *queues, size_t stride, uint32_t *late_list, uint32_t late_cap, double *d_F, hipStream_t s)
 {
@@ -2271,8 +2497,18 @@ static void launch_generate_perspective(int pencil, bool lm_pipeline, const uint
     if (thin) {
         // every queued root runs least_squares: the start and the rejected steps after it for all of them, the roots that
         // have a step accepted densely packed after that, the stragglers on a wave of their own
-        uint32_t *late = queues + (LM_QUEUES - 1) * stride;
-        if (lm_pipeline) {
+        uint32_t *late = queues + 2 * stride;
+        if (lm_pipeline == 2) {
+            // the two passes on refilled lanes, a persistent wave per SIMD (the loop's registers leave room for no more)
+            uint32_t *cursors = queues + 3 * stride;
+            (void)hipMemsetAsync(cursors, 0, 128, s);
+            const uint32_t waves = std::min<uint32_t>((3 * H + 63) / 64, LM_REFILL_WAVES);
+            hipLaunchKernelGGL(ransac_lm_refill_kernel<true>, dim3(waves), dim3(64), 0, s, pc, t, d_F, (const uint32_t *)queue, queue + stride, 1000,
+                               (uint32_t *)nullptr, 0u, cursors);
+            hipLaunchKernelGGL(ransac_lm_refill_kernel<false>, dim3(waves), dim3(64), 0, s, pc, t, d_F, (const uint32_t *)(queue + stride), late,
+                               LM_THREAD_BUDGET, late_list, late_cap, cursors + 16);
+            if (late_list) return; // (the call's stragglers run once, behind its last batch: ransac_rounds)
+        } else if (lm_pipeline) {
             hipLaunchKernelGGL(ransac_lm_start_kernel, roots_grid, dim3(64), 0, s, pc, t, d_F, (const uint32_t *)queue, queue + stride);
             hipLaunchKernelGGL(ransac_lm_run_kernel, roots_grid, dim3(64), 0, s, pc, t, d_F, (const uint32_t *)(queue + stride), late, LM_THREAD_BUDGET,
                                late_list, late_cap);
@@ -3139,7 +3375,7 @@ int ransac_perspective(cvhip_device *dev, const uint32_t *matches, uint32_t N, d
         [&](const uint4 *m4, uint32_t round0, uint32_t n_rounds, int buffer, double *d_F, hipStream_t s, bool defer_late) {
             PerspPencil *pencils = (PerspPencil *)(d_gen + (size_t)buffer * gen_bytes);
             char *queues = (char *)pencils + (GEN_BATCH * (size_t)CHECK_INTERVAL * sizeof(PerspPencil) + 255) / 256 * 256;
-            launch_generate_perspective(pencil, dev->d.ransac_lm_pipeline != 0, m4, limit, t, (unsigned long long)seed, round0, CHECK_INTERVAL,
+            launch_generate_perspective(pencil, dev->d.ransac_lm_pipeline, m4, limit, t, (unsigned long long)seed, round0, CHECK_INTERVAL,
                                         n_rounds * CHECK_INTERVAL, nullptr, pencils, (uint32_t *)queues, queue_bytes / sizeof(uint32_t),
                                         defer_late ? late.list : nullptr, late.cap, d_F, s);
         },
@@ -3166,7 +3402,7 @@ extern "C" int cvhip_ransac_set_in_order(cvhip_device *dev, int enable)
 extern "C" int cvhip_ransac_set_lm_pipeline(cvhip_device *dev, int enable)
 {
     if (!dev) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_lm_pipeline: null device");
-    dev->d.ransac_lm_pipeline = enable ? 1 : 0;
+    dev->d.ransac_lm_pipeline = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return CVHIP_OK;
 }
 
@@ -3225,7 +3461,7 @@ extern "C" int cvhip_ransac_perspective_models(cvhip_device *dev, const uint32_t
     const int pencil = dev->d.ransac_pencil;
     const int rc = models_of_samples(dev, matches, N, sample_idx, B, 7, 3, out_F, "ransac_perspective_models",
                                      [&](const uint4 *m4, const uint32_t *idx, double *d_F, hipStream_t s) {
-                                         launch_generate_perspective(pencil, dev->d.ransac_lm_pipeline != 0, m4, N, t, 0ull, 0u, B, B, idx, d_pencils, d_queue, stride, nullptr, 0u, d_F, s);
+                                         launch_generate_perspective(pencil, dev->d.ransac_lm_pipeline, m4, N, t, 0ull, 0u, B, B, idx, d_pencils, d_queue, stride, nullptr, 0u, d_F, s);
                                          if (getenv("CVHIP_LM_CENSUS")) { // (diagnostic: how many roots each stage of the LM funnel received)
                                              uint32_t n[LM_QUEUES] = {};
                                              for (int k = 0; k < LM_QUEUES; k++) (void)hipMemcpyAsync(&n[k], d_queue + k * stride, 4, hipMemcpyDeviceToHost, s);

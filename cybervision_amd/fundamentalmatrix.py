@@ -24,9 +24,11 @@ def set_pencil(device, pencil: int):
     _lib.check(_lib.lib().cvhip_ransac_set_pencil(device.handle, int(pencil)), "cvhip_ransac_set_pencil")
 
 
-def set_lm_pipeline(device, enable: bool):
-    """cvhip_ransac_set_lm_pipeline (test hook): validate_f's LM as two kernels (default) or as the scalar loop."""
-    _lib.check(_lib.lib().cvhip_ransac_set_lm_pipeline(device.handle, int(bool(enable))), "cvhip_ransac_set_lm_pipeline")
+def set_lm_pipeline(device, enable):
+    """cvhip_ransac_set_lm_pipeline (test hook): validate_f's LM as two passes on refilled lanes (2 or True: the default), as
+    two passes with a root per thread (1) or as the scalar loop in one kernel (0 or False)."""
+    mode = 2 if enable is True else int(enable)
+    _lib.check(_lib.lib().cvhip_ransac_set_lm_pipeline(device.handle, mode), "cvhip_ransac_set_lm_pipeline")
 
 
 def set_in_order(device, enable: bool):

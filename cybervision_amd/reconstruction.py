@@ -130,13 +130,20 @@ class ProgressBar:
 
 
 def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = ProjectionMode.Perspective, seed: int = 0,
-                      dense: bool = True, borrow: bool = False, listener: bool = False):
+                      dense: bool = True, borrow: bool = False, listener: bool = False, images=None):
     """The two pair loops of `reconstruct` (reconstruction.rs:261-277 sparse, :680-730 dense) over n images:
     for every i < j the sparse stage (ORB on both, matcher, RANSAC); then, for every pair that produced an F, the
     dense correlation.  The reference re-extracts an image's keypoints for every pair it takes part in; the result
     is a pure function of the image, so they are extracted once per image here.
     -> dict: keypoints [n], pairs {(i, j): {matches, f, inliers, (xy, corr)}}, timings_ms per stage."""
     rec = ImageReconstruction(device, projection_mode)
+    if images is not None:
+        # The reference's own pyramids: SourceImage::resize (Lanczos3, reconstruction.rs:146-162) per level, rebuilt by every
+        # stage that needs them - match_keypoints for both images of a pair (:421-422; once per image here, like the
+        # keypoints) and correlate_dense for both images of a pair (:567-568).  `pyramids` is ignored; the resizes run on the
+        # device (cvhip_resize_lanczos3) and are timed as their own stage.
+        pyramids = [rec._timed("resize", lambda im=im: correlation.lanczos_pyramid(
+            device, im, orb.optimal_scale_steps(int(im.shape[1]), int(im.shape[0])))) for im in images]
     n = len(pyramids)
     keypoints = rec.extract_keypoints_set(pyramids)
     pairs = {}
@@ -157,7 +164,12 @@ def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = Projec
         for (i, j), entry in pairs.items():
             if entry["f"] is None:
                 continue
-            entry["xy"], entry["corr"] = rec.correlate_dense(pyramids[i], pyramids[j], entry["f"], borrow=borrow)
+            pi, pj = pyramids[i], pyramids[j]
+            if images is not None:
+                dsteps = correlation.optimal_scale_steps(int(images[i].shape[1]), int(images[i].shape[0]))
+                pi, pj = rec._timed("resize", lambda: (correlation.lanczos_pyramid(device, images[i], dsteps),
+                                                       correlation.lanczos_pyramid(device, images[j], dsteps)))
+            entry["xy"], entry["corr"] = rec.correlate_dense(pi, pj, entry["f"], borrow=borrow and images is None)
     return {"keypoints": keypoints, "pairs": pairs, "timings_ms": dict(rec.timings_ms)}
 
 

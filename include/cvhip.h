@@ -408,8 +408,10 @@ int cvhip_ransac_affine(cvhip_device *dev, const uint32_t *matches, uint32_t N, 
 #define CVHIP_PENCIL_THIN_SVD 0
 #define CVHIP_PENCIL_NULL_SPACE 1
 int cvhip_ransac_set_pencil(cvhip_device *dev, int pencil);
-/* Test hook: with the thin-SVD pencil validate_f's least_squares runs as two kernels (linearise / iterate while steps are
- * rejected; enable = 1, default) or as the scalar loop itself, one thread per root (0).  Same values, bit for bit. */
+/* Test hook: with the thin-SVD pencil validate_f's least_squares runs as two passes over the roots - up to the first
+ * accepted step for all of them, then the accepting ones from their start - on persistent waves whose lanes take the next
+ * root off the queue as they finish (enable = 2, default), as the same two passes with a root per thread (1), or as the
+ * scalar loop itself in one kernel (0).  Same values, bit for bit. */
 int cvhip_ransac_set_lm_pipeline(cvhip_device *dev, int enable);
 /* Test hook of the round scheduler: batches of rounds are normally scored as their generators finish (the host polls
  * their events, for at most 50 ms per decision); enable = 1 takes the branch that polling falls back to - the oldest

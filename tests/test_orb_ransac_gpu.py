@@ -422,6 +422,14 @@ def test_device_reference_pencil_matches_thin_svd_rows_per_sample(gpu_device, or
     assert (scalar.view(np.uint64) == got.view(np.uint64)).all()
     piped_inf = fundamentalmatrix.perspective_models_device(gpu_device, m, idx[:1500], 1e300)
     assert (scalar_inf.view(np.uint64) == piped_inf.view(np.uint64)).all() and np.isfinite(piped_inf[:, :, 0, 0]).sum() > 1500
+    # ... and so does the root-per-thread form of the two passes (mode 1; the default above is mode 2, the refilled lanes)
+    fundamentalmatrix.set_lm_pipeline(gpu_device, 1)
+    try:
+        threads = fundamentalmatrix.perspective_models_device(gpu_device, m, idx, t)
+        threads_inf = fundamentalmatrix.perspective_models_device(gpu_device, m, idx[:1500], 1e300)
+    finally:
+        fundamentalmatrix.set_lm_pipeline(gpu_device, True)
+    assert (scalar.view(np.uint64) == threads.view(np.uint64)).all() and (scalar_inf.view(np.uint64) == threads_inf.view(np.uint64)).all()
     assert n_ref >= 20, n_ref                      # a few per cent of the roots fit their own sample
     assert abs(n_dev - n_ref) <= max(2, 0.05 * n_ref), (n_dev, n_ref)
     assert matched >= n_ref - max(2, 0.05 * n_ref), (matched, n_ref, unmatched[:5])
