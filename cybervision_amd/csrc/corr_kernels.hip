@@ -922,11 +922,13 @@ struct PixTile {
 __device__ __forceinline__ PixTile tile_of_entry(uint32_t entry, uint32_t row0)
 {
     PixTile t;
-    t.tr = ((entry >> 30) & 1u) != 0u;
+    // (bits 31:30 = 11: a row-major tile 58 pixels wide - half of a two-columns-per-lane box tile, search3_box2_kernel)
+    const bool half_pair = (entry >> 30) == 3u;
+    t.tr = ((entry >> 30) & 1u) != 0u && !half_pair;
     t.x0 = entry & 0xFFFFu;
     const uint32_t idx = (entry >> 16) & 0x3FFFu;
     t.y0 = row0 + idx * (t.tr ? (uint32_t)S3_OUT_PX : 4u);
-    t.nl = t.tr ? (uint32_t)S3_OUT_PX : ((entry >> 31) ? 64u : (uint32_t)S3_OUT_PX);
+    t.nl = t.tr ? (uint32_t)S3_OUT_PX : (half_pair ? 58u : ((entry >> 31) ? 64u : (uint32_t)S3_OUT_PX));
     return t;
 }
 __device__ __forceinline__ bool tile_pixel(const PixTile &t, uint32_t &x, uint32_t &y)
@@ -1435,7 +1437,7 @@ __device__ __forceinline__ bool search2_filter_tile(const CorrParams &p, const u
         }
     }
     if (whole_list.count && threadIdx.x == 0 && any_whole)
-        worklist_push(whole_list, tl.x0 | (((tl.y0 - p.row0) / 4u) << 16) | (tl.nl == 64u ? 0x80000000u : 0u));
+        worklist_push(whole_list, tl.x0 | (((tl.y0 - p.row0) / 4u) << 16) | (tl.nl == 64u ? 0x80000000u : (tl.nl == 58u ? 0xC0000000u : 0u)));
     return any_whole != 0;
 }
 
@@ -1606,6 +1608,552 @@ __global__ __launch_bounds__(256, STEP ? (COUNT ? 4 : CVHIP_STEP_WAVES) : (TR ? 
     unsigned long long *__restrict__ counters, WorkList declined, WorkList whole_list)
 {
 #include "box_body.inc"
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// search3_box2_kernel: the lean box walk (rectified pairs: exactly axis-parallel row-major lines, rectangles only) with TWO
+// image columns per lane (round 5; scripts/micro/box_group.hip: 0.70-0.77 of the one-column group's time per pixel and plane).
+// Lane l >= 1 owns the image columns cE = X0 - 7 + 2l and cO = cE + 1 (lane 0 is a dummy pair with zero products, so that the
+// prefix sum needs no special case at the left edge) and lanes 6..63 own the two searched pixels whose windows END in those
+// columns: x = X0 + 2 (l - 6) + {0, 1}, 116 pixels per wave.  With C_E, C_O the lane's column products of one displacement,
+// Q = wave prefix sum of C_E + C_O (the second dot4 chain accumulates onto the first) and R = Q - C_O,
+//     S12(window ending at cE) = R(l) - Q(l - 6),      S12(window ending at cO) = Q(l) - R(l - 5)
+// - per plane two chains of 3-4 v_dot4_u32_u8, ONE six-step DPP prefix sum and two ds_bpermute for two pixels.  The integers
+// (N = 121 S12 - s1 s2), the band test, the contender bookkeeping, DELTA and the exact re-evaluation are search3_box_kernel's.
+// LDS (33 KB): the target lines as four row-shifted copies of 20 bytes like the lean plan, 192 columns per copy with the even
+// and the odd columns in separate halves (a lane's two 16-byte reads are then unit-stride across the wave at every step),
+// tails and candidate statistics in plain column order (two adjacent 4- / 8-byte cells: ds_read2).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int P2_OUT = 116, P2_LANE0 = 6;
+constexpr int P2_COLS = 192; // staged target columns per copy: 126 + 61 - 1 + 3
+constexpr int P2_ISP = 192;  // cells per row of candidate statistics: 116 + 61 - 1
+constexpr int P2_MAXH = 9, P2_NDW = 5;
+constexpr int P2_B16_OFF = 0, P2_TAIL_OFF = 4 * P2_COLS * 16, P2_IS_OFF = P2_TAIL_OFF + 4 * P2_COLS * 4;
+constexpr int P2_LDS_BYTES = P2_IS_OFF + (P2_MAXH + 3) * P2_ISP * 8;
+struct P2Pixel { // one of a lane's two searched pixels
+    bool is_out, active, has, whole;
+    uint32_t x, r0;
+    int lox, loy;
+    uint32_t wx, wy;
+    uint32_t s1;
+    float k1, c1, limk, runmax;
+    unsigned long long clist, word;
+    uint32_t count, evaluated, ecount;
+    uint2 cell;
+};
+template <bool COUNT>
+__global__ __launch_bounds__(256, 3) void search3_box2_kernel(SearchJob ja, SearchJob jb)
+{
+    const SearchJob &j = this_job();
+    const CorrParams &p = j.p;
+    const uint8_t *__restrict__ const img1 = j.img1, *__restrict__ const img2 = j.img2;
+    const uint2 *__restrict__ const stats1 = j.stats1, *__restrict__ const istats2 = j.stats2;
+    const uint32_t *__restrict__ const range = j.range;
+    unsigned long long *__restrict__ const contenders = j.contenders, *__restrict__ const counters = j.counters;
+    uint32_t *__restrict__ const out = j.out;
+    float *__restrict__ const out_score = j.out_score;
+    const WorkList declined = j.declined, whole_list = j.whole;
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[P2_LDS_BYTES];
+    __shared__ int bb[6]; // min dx, min dy, max dx, max dy, max candidates of one pixel, 1 = some pixel is not a rectangle
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const TileId tid = xcd_tile();
+    const int X0 = (int)tid.x * P2_OUT;
+    const uint32_t V0 = p.row0 + tid.y * 4, y = V0 + w;
+    const int cs = p.corridor_size;
+    if (threadIdx.x == 0) {
+        bb[0] = 0x7FFFFFFF;
+        bb[1] = 0x7FFFFFFF;
+        bb[2] = -0x7FFFFFFF;
+        bb[3] = -0x7FFFFFFF;
+        bb[4] = 0;
+        bb[5] = 0;
+    }
+    // ---- the two pixels' candidate sets in displacement space (box_body.inc's setup, rectangles only) ------------------
+    P2Pixel px[2];
+    bool any_odd = false;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        P2Pixel &o = px[s];
+        const int xi = X0 + 2 * ((int)lane - P2_LANE0) + s;
+        o.x = (uint32_t)xi;
+        o.is_out = lane >= (uint32_t)P2_LANE0 && o.x < p.w1 && y < p.row1;
+        o.whole = false;
+        o.word = 0ull;
+        o.cell = make_uint2(CELL_NONE, 0x7FC00000u);
+        o.evaluated = o.ecount = o.count = 0u;
+        o.clist = 0ull;
+        o.runmax = -__builtin_inff();
+        o.lox = o.loy = 0;
+        o.wx = o.wy = 0u;
+        o.r0 = 0u;
+        PixelSetup ps;
+        ps.st1 = make_float2(0.0f, 1.0f);
+        ps.e.cx = ps.e.cy = ps.e.ax = ps.e.ay = 0.0;
+        ps.e.ox = ps.e.oy = 0;
+        ps.r0 = ps.r1 = 0;
+        o.active = o.is_out && pixel_setup(p, o.x, y, stats1, range, ps);
+        bool simple = true;
+        if (o.active) {
+            const Line &e = ps.e;
+            const bool major_x = e.ox == 0;
+            const double cmn = major_x ? e.cy : e.cx, amn = major_x ? e.ay : e.ax;
+            const int omn = major_x ? e.oy : e.ox;
+            const double vf = cmn * (double)ps.r0 + amn;
+            uint32_t m0 = 0;
+            bool consecutive = true;
+            for (int off = -cs; off <= cs; off++) {
+                const uint32_t mf = f64_to_u32_sat(floor(vf + (double)(off * omn)));
+                if (off == -cs) m0 = mf;
+                consecutive = consecutive && mf == m0 + (uint32_t)(off + cs);
+            }
+            const uint32_t lim2 = major_x ? p.w2 : p.h2;
+            const uint32_t ilo = max(ps.r0, (uint32_t)KERNEL_SIZE), ihi = min(ps.r1, sat_sub_u32(lim2, KERNEL_SIZE));
+            const uint32_t nmaj = ihi > ilo ? ihi - ilo : 0u;
+            const bool sane = (ps.r1 - ps.r0) <= CW_MAX_LEN && m0 < 0x40000000u && ilo < 0x40000000u;
+            // (this kernel is only launched for exactly axis-parallel row-major lines; anything else declines)
+            simple = consecutive && sane && major_x && e.cy == 0.0;
+            o.r0 = ps.r0;
+            o.lox = (int)ilo - xi;
+            o.wx = nmaj;
+            o.loy = (int)m0 - (int)y;
+            o.wy = (uint32_t)(2 * cs + 1);
+        }
+        o.has = o.active && simple && o.wx > 0u && o.wy > 0u;
+        any_odd = any_odd || (o.active && !simple);
+        o.s1 = o.has ? (stats1[(size_t)y * p.w1 + o.x].x & 0x7FFFFFFFu) : 0u;
+        o.k1 = ps.st1.y * (float)(KERNEL_POINT_COUNT * KERNEL_POINT_COUNT); // 121*121*sd1
+        o.c1 = 1.0f / o.k1;
+    }
+    const float thr_lo = p.threshold - S2_DELTA;
+#pragma unroll
+    for (int s = 0; s < 2; s++) px[s].limk = px[s].has ? thr_lo * px[s].k1 * (1.0f - 9.5367431640625e-7f) : __builtin_inff();
+    // wave-uniform bounds of the wave's displacement box
+    const int big = 0x7FFFFFFF;
+    const int mnx = wave_min_i32(min(px[0].has ? px[0].lox : big, px[1].has ? px[1].lox : big));
+    const int mny = wave_min_i32(min(px[0].has ? px[0].loy : big, px[1].has ? px[1].loy : big));
+    const int mxx = wave_max_i32(max(px[0].has ? px[0].lox + (int)px[0].wx - 1 : -big, px[1].has ? px[1].lox + (int)px[1].wx - 1 : -big));
+    const int mxy = wave_max_i32(max(px[0].has ? px[0].loy + (int)px[0].wy - 1 : -big, px[1].has ? px[1].loy + (int)px[1].wy - 1 : -big));
+    const int need = wave_max_i32(max(px[0].has ? (int)min(px[0].wx * px[0].wy, 0x3FFFFFFFu) : 0, px[1].has ? (int)min(px[1].wx * px[1].wy, 0x3FFFFFFFu) : 0));
+    const bool wave_has = mxx >= mnx;
+    const bool wave_odd = __any(any_odd);
+    __syncthreads(); // bb initialised
+    if (lane == 0) {
+        if (wave_has) {
+            atomicMin(&bb[0], mnx);
+            atomicMin(&bb[1], mny);
+            atomicMax(&bb[2], mxx);
+            atomicMax(&bb[3], mxy);
+            atomicMax(&bb[4], need);
+        }
+        if (wave_odd) atomicOr(&bb[5], 1);
+    }
+    __syncthreads();
+    const bool any_has = bb[2] >= bb[0];
+    const int dx0 = bb[0], dy0 = bb[1];
+    const int W = bb[2] - bb[0] + 1, H = bb[3] - bb[1] + 1;
+    const int C0 = X0 - 5 + dx0;   // target column of lane 1's first slot at the box's first step
+    const int C0a = C0 & ~3;
+    const int colshift = C0 - C0a;
+    const int ncol = colshift + 126 + W - 1;
+    bool eligible = !bb[5];
+    if (any_has) eligible = eligible && ncol <= P2_COLS && 116 + W - 1 <= P2_ISP && H <= P2_MAXH && (long long)W * H <= 3ll * bb[4] + 16;
+    if (!eligible || !any_has) {
+        // nothing to search (every pixel None), or left to the candidate-by-candidate kernel: two 58-pixel tiles on its list
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            if (px[s].is_out) {
+                const size_t pix = (size_t)y * p.w1 + px[s].x;
+                const bool fb = px[s].active && !eligible;
+                if (!eligible) contenders[pix] = fb ? (CW_FALLBACK << 60) : 0ull;
+                if (!fb) out[pix] = CELL_NONE;
+            }
+        if (!eligible && threadIdx.x == 0) {
+            worklist_push(declined, (uint32_t)X0 | (tid.y << 16) | 0xC0000000u);
+            if ((uint32_t)X0 + 58u < p.w1) worklist_push(declined, ((uint32_t)X0 + 58u) | (tid.y << 16) | 0xC0000000u);
+        }
+        return;
+    }
+    const int NPL = H > 5 ? 9 : 5; // planes staged: group A = 0..4, group B = 5..8
+
+    // ---- stage the target lines (4 row-shifted copies of 20 bytes, even / odd columns apart) and the candidate statistics
+    {
+        const int R0 = (int)V0 + dy0 - KERNEL_SIZE; // first row of copy 0
+        const int nb = (ncol + 3) >> 2;             // groups of four columns (<= 48)
+        const int kmax = NPL > 5 ? P2_NDW : P2_NDW - 1; // (five planes never read the tail dword)
+        const bool inside = R0 >= 0 && R0 + 3 + 4 * (P2_NDW - 1) + 3 < (int)p.h2 && C0a >= 0 && C0a + 4 * nb <= (int)p.w2;
+        const int b = (int)(threadIdx.x & 63u);
+        if (b < nb) {
+            for (int wk = (int)(threadIdx.x >> 6); wk < 4 * P2_NDW; wk += 4) {
+                const int cw = wk / P2_NDW, k = wk - cw * P2_NDW;
+                if (k >= kmax) continue;
+                const int rr = R0 + cw + 4 * k, col = C0a + 4 * b;
+                uint32_t d0, d1, d2, d3;
+                if (inside) {
+                    const uint8_t *src = img2 + (size_t)rr * p.w2 + (size_t)col;
+                    __builtin_memcpy(&d0, src, 4);
+                    __builtin_memcpy(&d1, src + p.w2, 4);
+                    __builtin_memcpy(&d2, src + 2 * (size_t)p.w2, 4);
+                    __builtin_memcpy(&d3, src + 3 * (size_t)p.w2, 4);
+                } else {
+                    d0 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 0, col);
+                    d1 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 1, col);
+                    d2 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 2, col);
+                    d3 = load_dword_checked(img2, (int)p.w2, (int)p.h2, rr + 3, col);
+                }
+                // 4x4 byte transpose: t.c = rows rr..rr+3 of column col + c
+                const uint32_t p01 = __builtin_amdgcn_perm(d1, d0, 0x05010400u), q01 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);
+                const uint32_t p23 = __builtin_amdgcn_perm(d3, d2, 0x05010400u), q23 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+                uint4 t;
+                t.x = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                t.y = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+                t.z = __builtin_amdgcn_perm(q23, q01, 0x05040100u);
+                t.w = __builtin_amdgcn_perm(q23, q01, 0x07060302u);
+                if (k < 4) {
+                    // columns 4b, 4b + 2 -> even half entries 2b, 2b + 1; columns 4b + 1, 4b + 3 -> odd half, the same entries
+                    uint32_t *ev = reinterpret_cast<uint32_t *>(lds + P2_B16_OFF + (size_t)(cw * P2_COLS + 2 * b) * 16u) + k;
+                    uint32_t *od = ev + (P2_COLS / 2) * 4;
+                    ev[0] = t.x;
+                    od[0] = t.y;
+                    ev[4] = t.z;
+                    od[4] = t.w;
+                } else {
+                    *reinterpret_cast<uint4 *>(lds + P2_TAIL_OFF + (size_t)(cw * P2_COLS + 4 * b) * 4u) = t;
+                }
+            }
+        }
+        const int isp = 116 + W - 1, isrows = NPL + 3;
+        const int gu0 = X0 + dx0; // target x of pixel 0 at the box's first step
+        const int gv0 = (int)V0 + dy0;
+        const int c = (int)threadIdx.x;
+        if (c < isp) {
+            const int gx = gu0 + c;
+            for (int r = 0; r < isrows; r++) {
+                const int gy = gv0 + r;
+                // {-window sum, f32 stdev}; centres outside the image or skipped by the reference (mod.rs:430-441): stdev = +inf
+                uint2 v = make_uint2(0u, 0x7F800000u);
+                if (gy >= 0 && gy < (int)p.h2 && gx >= 0 && gx < (int)p.w2) {
+                    const uint2 tt = istats2[(size_t)gy * p.w2 + (size_t)gx];
+                    if (tt.x & 0x80000000u) v = make_uint2(0u - (tt.x & 0x7FFFFFFFu), tt.y);
+                }
+                *reinterpret_cast<uint2 *>(lds + P2_IS_OFF + (size_t)(r * P2_ISP + c) * 8u) = v;
+            }
+        }
+    }
+    // this lane's two searched columns, rows y-5 .. y+5, packed and pre-shifted by 0..3 bytes (lane 0: zeros)
+    uint32_t a[2][4][4];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int uc = X0 - 7 + 2 * (int)lane + s;
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+        if (lane >= 1u && uc >= 0 && uc < (int)p.w1 && y >= (uint32_t)KERNEL_SIZE && y + KERNEL_SIZE < p.h1) {
+            const uint8_t *pc = img1 + (size_t)(y - KERNEL_SIZE) * p.w1 + (size_t)uc;
+            uint32_t bv[KERNEL_WIDTH];
+#pragma unroll
+            for (int r = 0; r < KERNEL_WIDTH; r++) bv[r] = pc[(size_t)r * p.w1];
+            a0 = bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24);
+            a1 = bv[4] | (bv[5] << 8) | (bv[6] << 16) | (bv[7] << 24);
+            a2 = bv[8] | (bv[9] << 8) | (bv[10] << 16);
+        }
+        a[s][0][0] = a0;
+        a[s][0][1] = a1;
+        a[s][0][2] = a2;
+        a[s][0][3] = 0u;
+#pragma unroll
+        for (int q = 1; q < 4; q++) { // 128-bit left shift by q bytes
+            a[s][q][0] = a0 << (8 * q);
+            a[s][q][1] = __builtin_amdgcn_alignbyte(a1, a0, 4 - q);
+            a[s][q][2] = __builtin_amdgcn_alignbyte(a2, a1, 4 - q);
+            a[s][q][3] = __builtin_amdgcn_alignbyte(0u, a2, 4 - q);
+        }
+    }
+    __syncthreads();
+
+    const auto record = [&](P2Pixel &o, float g, uint32_t code) {
+        const float lim = fmaxf(o.runmax - 2.0f * S2_DELTA, thr_lo);
+        if (g >= lim) {
+            if (g > o.runmax + 2.0f * S2_DELTA) { // everything recorded so far is out of the band
+                o.count = 0;
+                o.clist = 0ull;
+            }
+            o.runmax = fmaxf(o.runmax, g);
+            o.limk = fmaxf(o.runmax - 2.0f * S2_DELTA, thr_lo) * o.k1 * (1.0f - 9.5367431640625e-7f);
+            if (o.count < (uint32_t)S2_K) o.clist |= (unsigned long long)code << (15u * o.count);
+            o.count = min(o.count + 1u, (uint32_t)S2_K + 1u);
+        }
+    };
+
+    if (wave_has) {
+        // staged column of the lane's first slot at the wave's first step (lane 0 reads lane 1's: its products are zeros anyway)
+        const int j0 = colshift + 2 * ((int)max(lane, 1u) - 1) + (mnx - dx0);
+        const uint8_t *const bCopy = lds + P2_B16_OFF + (size_t)(w * P2_COLS) * 16u;
+        const uint8_t *const bTail = lds + P2_TAIL_OFF + (size_t)(w * P2_COLS + j0) * 4u;
+        // candidate statistics of the lane's first pixel at the wave's first step (lanes below 6 read lane 6's)
+        const int p0 = 2 * ((int)max(lane, (uint32_t)P2_LANE0) - P2_LANE0) + (mnx - dx0);
+        const uint8_t *const bIS = lds + P2_IS_OFF + (size_t)(w * P2_ISP + p0) * 8u;
+        const int idx5 = (int)(lane >= 5u ? lane - 5u : 0u) * 4, idx6 = (int)(lane >= 6u ? lane - 6u : 0u) * 4;
+        const int nsteps = mxx - mnx + 1;
+        const int mid = nsteps >> 1;
+        for (int t = 0; t < nsteps; t++) {
+            const int step = t < nsteps - mid ? mid + t : nsteps - 1 - t; // inside out (see box_body.inc)
+            const int dx = mnx + step;
+            const bool mxe = px[0].has && (uint32_t)(dx - px[0].lox) < px[0].wx, mxo = px[1].has && (uint32_t)(dx - px[1].lox) < px[1].wx;
+            // the two columns' lines: staged columns jE = j0 + step (first slot) and jE + 1, in the half of their parity
+            const int jE = j0 + step;
+            const uint8_t *const pE = bCopy + (size_t)((jE & 1) * (P2_COLS / 2) + (jE >> 1)) * 16u;
+            const uint8_t *const pO = bCopy + (size_t)(((jE + 1) & 1) * (P2_COLS / 2) + ((jE + 1) >> 1)) * 16u;
+            const uint4 ra = *reinterpret_cast<const uint4 *>(pE), rb = *reinterpret_cast<const uint4 *>(pO);
+            const uint32_t *const tl = reinterpret_cast<const uint32_t *>(bTail + step * 4);
+            const uint32_t raw[2][P2_NDW] = {{ra.x, ra.y, ra.z, ra.w, tl[0]}, {rb.x, rb.y, rb.z, rb.w, tl[1]}};
+            const uint8_t *const pIS = bIS + step * 8;
+            auto group = [&](auto s0_tag, auto n_tag) {
+                constexpr int S0 = decltype(s0_tag)::value, N = decltype(n_tag)::value;
+                int num[2][N];
+                float sd[2][N], mg[2][N];
+#pragma unroll
+                for (int q = 0; q < N; q++) {
+                    const int sp = S0 + q, sh = sp & 3, o = sp >> 2;
+                    const uint2 ise = *reinterpret_cast<const uint2 *>(pIS + sp * (P2_ISP * 8));
+                    const uint2 iso = *reinterpret_cast<const uint2 *>(pIS + sp * (P2_ISP * 8) + 8);
+                    uint32_t c1 = __builtin_amdgcn_udot4(a[1][sh][0], raw[1][o], 0u, false);
+                    c1 = __builtin_amdgcn_udot4(a[1][sh][1], raw[1][o + 1], c1, false);
+                    c1 = __builtin_amdgcn_udot4(a[1][sh][2], raw[1][o + 2], c1, false);
+                    if (sh >= 2) c1 = __builtin_amdgcn_udot4(a[1][sh][3], raw[1][o + 3 < P2_NDW ? o + 3 : P2_NDW - 1], c1, false);
+                    uint32_t d = __builtin_amdgcn_udot4(a[0][sh][0], raw[0][o], c1, false); // the first column on top: the pair sum
+                    d = __builtin_amdgcn_udot4(a[0][sh][1], raw[0][o + 1], d, false);
+                    d = __builtin_amdgcn_udot4(a[0][sh][2], raw[0][o + 2], d, false);
+                    if (sh >= 2) d = __builtin_amdgcn_udot4(a[0][sh][3], raw[0][o + 3 < P2_NDW ? o + 3 : P2_NDW - 1], d, false);
+                    const uint32_t Q = wave_prefix_sum(d), R = Q - c1;
+                    const uint32_t s_odd = Q - (uint32_t)__builtin_amdgcn_ds_bpermute(idx5, (int)R);
+                    const uint32_t s_even = R - (uint32_t)__builtin_amdgcn_ds_bpermute(idx6, (int)Q);
+                    num[0][q] = __mul24((int)s_even, KERNEL_POINT_COUNT) + __mul24((int)px[0].s1, (int)ise.x);
+                    num[1][q] = __mul24((int)s_odd, KERNEL_POINT_COUNT) + __mul24((int)px[1].s1, (int)iso.x);
+                    sd[0][q] = __uint_as_float(ise.y);
+                    sd[1][q] = __uint_as_float(iso.y);
+                }
+#pragma unroll
+                for (int q = 0; q < N; q++) {
+                    mg[0][q] = __builtin_fmaf(-px[0].limk, sd[0][q], (float)num[0][q]);
+                    mg[1][q] = __builtin_fmaf(-px[1].limk, sd[1][q], (float)num[1][q]);
+                }
+                float margin = fmaxf(mg[0][0], mg[1][0]);
+#pragma unroll
+                for (int q = 1; q < N; q++) margin = fmaxf(margin, fmaxf(mg[0][q], mg[1][q]));
+                if (COUNT) {
+#pragma unroll
+                    for (int q = 0; q < N; q++) {
+                        if (mxe && (uint32_t)(dy0 + S0 + q - px[0].loy) < px[0].wy && sd[0][q] < __builtin_inff()) px[0].evaluated++;
+                        if (mxo && (uint32_t)(dy0 + S0 + q - px[1].loy) < px[1].wy && sd[1][q] < __builtin_inff()) px[1].evaluated++;
+                    }
+                }
+                if (margin >= 0.0f) { // rarely taken; planes from the middle outwards (see box_body.inc)
+#pragma unroll
+                    for (int qi = 0; qi < N; qi++) {
+                        const int q = (N - 1) / 2 + ((qi & 1) ? (qi + 1) / 2 : -(qi / 2));
+                        const int dy = dy0 + S0 + q;
+#pragma unroll
+                        for (int s = 0; s < 2; s++) {
+                            P2Pixel &o = px[s];
+                            const bool mx = s ? mxo : mxe;
+                            if (mg[s][q] >= 0.0f && mx && (uint32_t)(dy - o.loy) < o.wy && sd[s][q] < __builtin_inff() &&
+                                (float)num[s][q] >= o.limk * sd[s][q]) {
+                                const uint32_t code = ((uint32_t)(dy - o.loy) << 11) | (uint32_t)((int)o.x + dx - (int)o.r0);
+                                record(o, (float)num[s][q] * (o.c1 * __builtin_amdgcn_rcpf(sd[s][q])), code);
+                            }
+                        }
+                    }
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I4 = std::integral_constant<int, 4>;
+            using I5 = std::integral_constant<int, 5>;
+            group(I0{}, I5{});
+            if (NPL > 5) group(I5{}, I4{});
+        }
+    }
+
+    // ---- exact re-evaluation of the contenders (mod.rs:442-464; box_body.inc's exact phase): a lane evaluates its first
+    // pixel's first contender itself, every other contender of its two pixels goes through the queue in LDS (the wave's own
+    // copy of the target lines, dead after the walk) to whichever lanes are free - with two pixels per lane that is a second
+    // pass of the chain for the wave, as one pass per 58 pixels was before.
+    const auto chain = [&](uint32_t qx1, uint32_t qy1, uint32_t qx, uint32_t qy) -> float {
+        const float2 st1x = stats_of(stats1[(size_t)qy1 * p.w1 + qx1]);
+        const uint2 is2 = istats2[(size_t)qy * p.w2 + qx];
+        const float avg1 = st1x.x, sdev1 = st1x.y;
+        const float avg2 = (float)(is2.x & 0x7FFFFFFFu) / (float)KERNEL_POINT_COUNT; // == compute_point_avg
+        const float sdev2 = __uint_as_float(is2.y);
+        const uint8_t *base1 = img1 + (size_t)(qy1 - KERNEL_SIZE) * p.w1 + (qx1 - KERNEL_SIZE);
+        const uint8_t *base2 = img2 + (size_t)(qy - KERNEL_SIZE) * p.w2 + (qx - KERNEL_SIZE);
+        float corr = 0.0f;
+#pragma unroll 1
+        for (int rb = 0; rb < 12; rb += 4) {
+            Row12 av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rr = min(rb + r, KERNEL_WIDTH - 1);
+                av[r] = load_row12(base1 + (size_t)rr * p.w1);
+                bv[r] = load_row12(base2 + (size_t)rr * p.w2);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (rb + r < KERNEL_WIDTH) corr = row_corr_acc(corr, av[r], bv[r], avg1, avg2);
+        }
+        return corr / (sdev1 * sdev2 * (float)KERNEL_POINT_COUNT); // mod.rs:454
+    };
+    // the candidate a contender code names (rectified lines: x2 = i, y2 = the stripe's row - candidate_xy with the line re-derived)
+    const auto cand_of = [&](const P2Pixel &o, uint32_t code) -> uint32_t {
+        const Line ex = epipolar_line(p, o.x, y);
+        const CandXY c = candidate_xy(ex, o.r0 + (code & 0x7FFu), (int)(code >> 11) - cs);
+        return c.x | (c.y << 16);
+    };
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        P2Pixel &o = px[s];
+        if (o.has) {
+            if (o.count > (uint32_t)S2_K) {
+                o.word = CW_WHOLE << 60;
+                o.whole = true;
+                o.evaluated = 0; // the exact kernel walks (and counts) the whole corridor
+            } else if (o.count > 0u) {
+                o.ecount = o.count;
+                if (!p.need_scores && o.count == 1u && o.runmax >= p.threshold + S2_DELTA) { // settled without the chain
+                    o.cell = make_uint2(cand_of(o, (uint32_t)o.clist & 0x7FFFu), __float_as_uint(o.runmax));
+                    o.ecount = 0u;
+                }
+            }
+        }
+    }
+    constexpr uint32_t QCAP = 192;
+    static_assert(QCAP * 12u <= P2_COLS * 16u, "the queue lives in one wave's copy of the target lines");
+    uint32_t *const q_pix = reinterpret_cast<uint32_t *>(lds + P2_B16_OFF + (size_t)(w * P2_COLS) * 16u);
+    uint32_t *const q_cand = q_pix + QCAP;
+    float *const q_corr = reinterpret_cast<float *>(q_cand + QCAP);
+    // queue items of this lane: the first pixel's contenders beyond its first, all of the second pixel's
+    uint32_t extras = (px[0].ecount > 1u ? px[0].ecount - 1u : 0u) + px[1].ecount;
+    uint32_t q_incl = wave_prefix_sum(extras);
+    uint32_t q_total = (uint32_t)__builtin_amdgcn_readlane((int)q_incl, 63);
+    if (q_total > QCAP) {
+        // more than the queue holds (synthetic ties): the pixels behind the limit re-evaluate their whole corridor in the fallback kernel
+        if (q_incl > QCAP && extras > 0u) {
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                if (px[s].ecount > 0u) {
+                    px[s].word = CW_WHOLE << 60;
+                    px[s].whole = true;
+                    px[s].evaluated = 0;
+                    px[s].ecount = 0;
+                }
+            extras = 0;
+        }
+        q_incl = wave_prefix_sum(extras);
+        q_total = (uint32_t)__builtin_amdgcn_readlane((int)q_incl, 63);
+    }
+    const uint32_t q_base = q_incl - extras;
+    {
+        uint32_t at = q_base;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            for (uint32_t jx = s == 0 ? 1u : 0u; jx < px[s].ecount; jx++) {
+                q_pix[at] = px[s].x | (y << 16);
+                q_cand[at] = cand_of(px[s], (uint32_t)(px[s].clist >> (15u * jx)) & 0x7FFFu);
+                at++;
+            }
+    }
+    uint32_t own_cxy = 0;
+    if (px[0].ecount >= 1u) own_cxy = cand_of(px[0], (uint32_t)px[0].clist & 0x7FFFu);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float own_corr = 0.0f;
+    uint32_t exact_evals = 0;
+    const unsigned long long idle = __ballot(px[0].ecount == 0u);
+    const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+    const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+    uint32_t done = 0;
+    bool first_round = true;
+    while (first_round || done < q_total) { // (wave-uniform)
+        const bool own = first_round && px[0].ecount >= 1u;
+        const uint32_t item = done + (first_round ? my_rank : lane);
+        const bool take = !own && (!first_round || px[0].ecount == 0u) && item < q_total;
+        uint32_t pxy = px[0].x | (y << 16), cxy = own_cxy;
+        if (take) {
+            pxy = q_pix[item];
+            cxy = q_cand[item];
+        }
+        if (own || take) {
+            const float corr = chain(pxy & 0xFFFFu, pxy >> 16, cxy & 0xFFFFu, cxy >> 16);
+            exact_evals++;
+            if (own) own_corr = corr;
+            else q_corr[item] = corr;
+        }
+        done += first_round ? min(n_idle, q_total) : 64u;
+        first_round = false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        uint32_t at = q_base;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            P2Pixel &o = px[s];
+            bool have = false;
+            float bcorr = 0.0f;
+            uint32_t bxy = 0, bcode = 0;
+            for (uint32_t jx = 0; jx < o.ecount; jx++) { // mod.rs:456-464; "first maximum" = the smallest code among equals
+                const uint32_t code = (uint32_t)(o.clist >> (15u * jx)) & 0x7FFFu;
+                float corr;
+                uint32_t cxy;
+                if (s == 0 && jx == 0) {
+                    corr = own_corr;
+                    cxy = own_cxy;
+                } else {
+                    corr = q_corr[at];
+                    cxy = q_cand[at];
+                    at++;
+                }
+                if (corr >= p.threshold && (!have || corr > bcorr || (corr == bcorr && code < bcode))) {
+                    have = true;
+                    bcorr = corr;
+                    bcode = code;
+                    bxy = cxy;
+                }
+            }
+            if (have) o.cell = make_uint2(bxy, __float_as_uint(bcorr));
+            if (o.is_out && !o.whole) store_cell(p, out, out_score, (size_t)y * p.w1 + o.x, o.cell);
+        }
+    }
+    if (counters) {
+        uint32_t v0 = px[0].evaluated + px[1].evaluated, v1 = exact_evals;
+        uint32_t v2 = (px[0].ecount > 1u ? 1u : 0u) + (px[1].ecount > 1u ? 1u : 0u), v3 = (px[0].whole ? 1u : 0u) + (px[1].whole ? 1u : 0u);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            v0 += __shfl_down(v0, sft, 64);
+            v1 += __shfl_down(v1, sft, 64);
+            v2 += __shfl_down(v2, sft, 64);
+            v3 += __shfl_down(v3, sft, 64);
+        }
+        if (lane == 0) {
+            if (v0) atomicAdd(&counters[0], (unsigned long long)v0);
+            if (v1) atomicAdd(&counters[1], (unsigned long long)v1);
+            if (v2) atomicAdd(&counters[2], (unsigned long long)v2);
+            if (v3) atomicAdd(&counters[3], (unsigned long long)v3);
+        }
+    }
+    {
+        // only a tile that goes onto the whole-corridor list has its contender words read (all of them)
+        const int any_whole = __syncthreads_or((px[0].whole || px[1].whole) ? 1 : 0);
+        if (any_whole) {
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                if (px[s].is_out) contenders[(size_t)y * p.w1 + px[s].x] = px[s].word;
+            if (threadIdx.x == 0) {
+                worklist_push(whole_list, (uint32_t)X0 | (tid.y << 16) | 0xC0000000u);
+                if ((uint32_t)X0 + 58u < p.w1) worklist_push(whole_list, ((uint32_t)X0 + 58u) | (tid.y << 16) | 0xC0000000u);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2321,9 +2869,28 @@ void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipS
         hipLaunchKernelGGL(search3_fallback_kernel<false>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
 }
 
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s,
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, int form, hipStream_t s,
                         hipStream_t side, hipEvent_t fork, hipEvent_t join)
 {
+    // form (rectified affine pairs only - lines that never step, row-major): 0 = the box walk, one column per lane; 1 = the
+    // filter on the matrix pipe (search version 5); 2 = the box walk with two columns per lane (search3_box2_kernel)
+    const bool mfma = form == 1;
+    if (form == 2 && !stepped_lines && !transposed) {
+        uint32_t gx = 0, gy = 0;
+        for (int i = 0; i < n; i++) {
+            const CorrParams &p = jobs[i].p;
+            if (!job_active(jobs[i])) continue;
+            gx = std::max(gx, (p.w1 + P2_OUT - 1) / P2_OUT);
+            gy = std::max(gy, (p.row1 - p.row0 + 3) / 4);
+        }
+        if (!gx || !gy) return;
+        const dim3 grid(gx, gy, (unsigned)n);
+        if (jobs[0].counters)
+            hipLaunchKernelGGL(search3_box2_kernel<true>, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]);
+        else
+            hipLaunchKernelGGL(search3_box2_kernel<false>, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]);
+        return;
+    }
     // rectified affine pairs under search version 5: the filter on the matrix pipe (search4_mfma_kernel); a pass that counts
     // candidates (profiling) takes the box kernel - the matrix-pipe walk does not know, value by value, which pixel ends up
     // re-evaluating its whole corridor

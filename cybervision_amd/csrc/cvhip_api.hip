@@ -355,7 +355,7 @@ struct PassPlan {
     int dir = 0, next = 0;
     uint32_t lw = 0, lh = 0, k = 0;
     enum Kind { EXACT_V1, BOX, FILTER } kind = FILTER;
-    bool stepped = false, transposed = false, mfma = false;
+    bool stepped = false, transposed = false, mfma = false, pair = false;
 };
 
 static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uint32_t lw2, uint32_t lh2, float scale,
@@ -512,7 +512,9 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
         plan.stepped = f_minor != 0.0 || c->force_box; // exactly axis-parallel lines never step: the leaner instantiation
         plan.transposed = transposed;
         // rectified affine pairs (five stripes, row-major lines that never step): the filter as a matrix product
-        plan.mfma = !plan.stepped && !plan.transposed && affine_form && c->corridor_size == 2 && c->search_version >= 5;
+        plan.mfma = !plan.stepped && !plan.transposed && affine_form && c->corridor_size == 2 && c->search_version == 5;
+        // ... or the box walk with two image columns per lane (search3_box2_kernel; any corridor size up to nine planes)
+        plan.pair = !plan.stepped && !plan.transposed && affine_form && c->search_version == 6;
         if (plan.stepped) {
             // LDS of the stepped launch, sized for displacement boxes of up to ~32 steps along lines of this slope: H
             // rows of planes -> H + 3 rows of candidate statistics and H + 26 bytes of every target line (an odd number
@@ -534,7 +536,7 @@ static int plan_pass(cvhip_ctx *c, int a, int b, uint32_t lw1, uint32_t lh1, uin
 static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts, hipStream_t s, hipEvent_t stats_done = nullptr)
 {
     const bool together = n == 2 && plans[0].kind == plans[1].kind && plans[0].kind != PassPlan::EXACT_V1 &&
-                          plans[0].stepped == plans[1].stepped && plans[0].transposed == plans[1].transposed && plans[0].mfma == plans[1].mfma &&
+                          plans[0].stepped == plans[1].stepped && plans[0].transposed == plans[1].transposed && plans[0].mfma == plans[1].mfma && plans[0].pair == plans[1].pair &&
                           plans[0].job.p.first_pass == plans[1].job.p.first_pass;
     for (int i = 0; i < n; i += together ? 2 : 1) {
         const int m = together ? 2 : 1;
@@ -565,7 +567,7 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
                     CVHIP_TRY_HIP(aux_stream(d, 1, &side));
                 }
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                    launch_search3_box(jobs, m, pl.stepped, pl.transposed, pl.mfma, s, side, d.box_ev[0], d.box_ev[1]);
+                    launch_search3_box(jobs, m, pl.stepped, pl.transposed, pl.mfma ? 1 : (pl.pair ? 2 : 0), s, side, d.box_ev[0], d.box_ev[1]);
                 }, s));
                 CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s); }, s));
             } else {
@@ -1791,7 +1793,7 @@ int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version)
     if (!ctx) return fail(CVHIP_ERR_INVALID, "ctx is null");
     CVHIP_TRY(flush_level_calls(ctx));
     // 4 = version 3 with the box kernel launched for every geometry (tests: exercises its per-workgroup decline)
-    if (version < 1 || version > 5) return fail(CVHIP_ERR_INVALID, "search version must be 1 .. 5");
+    if (version < 1 || version > 6) return fail(CVHIP_ERR_INVALID, "search version must be 1 .. 6");
     ctx->force_box = version == 4;
     ctx->search_version = version == 4 ? 3 : version;
     return CVHIP_OK;

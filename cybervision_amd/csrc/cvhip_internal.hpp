@@ -119,7 +119,7 @@ void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s);
 void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s);
 // (side / fork / join: the stepped instantiations launch one kernel per direction - with a side stream the second one goes
 // there, between the two events, so that the first launch's tail is filled)
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, bool mfma, hipStream_t s,
+void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, int form, hipStream_t s,
                         hipStream_t side = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
@@ -433,7 +433,8 @@ struct cvhip_ctx {
     bool pool_waited = false;          // stream waits for it before its first upload into the pool
     bool async_readback = false; // cvhip_ctx_set_async_readback
     bool exact_scores = false; // cvhip_ctx_set_exact_scores: every pass writes the reference's scores (tests)
-    int search_version = 3; // (5: version 3 with the rectified box launches on the matrix pipe, search4_mfma_kernel - measured slower)
+    int search_version = 3; // (5: version 3 with the rectified box launches on the matrix pipe, search4_mfma_kernel - measured slower;
+                            //  6: version 3 with the rectified box launches on two columns per lane, search3_box2_kernel)
     int range_mode = 0; // search_range_kernel: 0 = integer box sums + chain where needed, 1 = chain only, 2 / 3 = test hooks
     bool force_box = false; // launch the box kernel whatever the geometry (it declines per workgroup)
     // per-direction scratch of a search pass (the two passes of a level are independent: one launch, blockIdx.z picks one)

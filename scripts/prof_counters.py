@@ -27,6 +27,9 @@ for a in sys.argv:
 proj = correlation.ProjectionMode.Perspective if "--perspective" in sys.argv else correlation.ProjectionMode.Affine
 pc = correlation.PointCorrelations(dev, (W, W), (W, W), F, proj)
 COUNT = "--count" in sys.argv
+for a in sys.argv:
+    if a.startswith("--version="):
+        pc.set_search_version(int(a.split("=")[1]))
 pc.set_profiling(True, COUNT)
 for i in range(steps + 1):
     k = steps - i

@@ -12,6 +12,7 @@ from cybervision_amd import correlation, synth  # noqa: E402
 
 W = 4096
 tilts = [float(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,3,10,30,60,90").split(",")]
+VERSION = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--version=")), None)  # cvhip_ctx_set_search_version
 proj = correlation.ProjectionMode.Affine
 steps = synth.optimal_scale_steps(W, W)
 stream = torch.cuda.current_stream()
@@ -23,6 +24,8 @@ for tilt in tilts:
     d1, d2 = synth.box_pyramid_torch(a, steps), synth.box_pyramid_torch(b, steps)
     F = synth.f_tilt(tilt) if tilt != 0.0 else synth.F_HORIZONTAL
     pc = correlation.PointCorrelations(dev, (W, W), (W, W), F, proj)
+    if VERSION is not None:
+        pc.set_search_version(VERSION)
 
     def step(ev=None):
         pc.first_pass = True

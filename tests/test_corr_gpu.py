@@ -207,6 +207,39 @@ def test_matrix_pipe_filter_matches_oracle(gpu_device, oracle, name):
         assert_same_grid(run_gpu(gpu_device, big, version=5), run_gpu(gpu_device, big, version=3), "1024x768 v5 vs v3")
 
 
+@pytest.mark.parametrize("name", ["h256", "sem320x200", "periodic", "periodic16", "low_contrast", "noisy", "big"])
+def test_two_column_box_walk_matches_oracle(gpu_device, oracle, name):
+    """search3_box2_kernel (search version 6): the rectified box walk with two image columns per lane - pair sums through
+    one prefix sum, S12 = R(l) - Q(l - 6) / Q(l) - R(l - 5) - computes the one-column walk's integers, so both directions'
+    grids are the oracle's bit for bit: ordinary pairs, the adversarial inputs of the decision rule (exact ties: contender
+    lists through the queue, whole-corridor pixels, tiles on the 58-wide work-list entries), with and without the candidate
+    counter (whose count must be the oracle's), and a larger pair with disparity discontinuities against version 3."""
+    if name == "big":
+        a, b, _ = synth.make_pair(1100, 700, seed=77)
+        big = {"img1": a, "img2": b, "F": synth.F_HORIZONTAL, "projection": 0, "steps": synth.optimal_scale_steps(1100, 700)}
+        cnt6, cnt3 = {}, {}
+        v6, v3 = run_gpu(gpu_device, big, version=6, both=True, counters=cnt6), run_gpu(gpu_device, big, version=3, both=True, counters=cnt3)
+        assert_same_grid(v6[0], v3[0], "1100x700 v6 vs v3 forward")
+        assert_same_grid(v6[1], v3[1], "1100x700 v6 vs v3 reverse")
+        assert cnt6["candidates"] == cnt3["candidates"]
+        assert_same_grid(run_gpu(gpu_device, big, version=6), run_gpu(gpu_device, big, version=3), "1100x700 v6 vs v3, default mode")
+        return
+    c = adversarial_case(name) if name in ("periodic", "periodic16", "low_contrast", "noisy") else cases.make_case(name)
+    want = run_oracle(oracle, c, both=True)
+    cnt = {}
+    got = run_gpu(gpu_device, c, version=6, both=True, counters=cnt)
+    assert_same_grid(got[0], want[0], f"{name} v6 forward")
+    assert_same_grid(got[1], want[1], f"{name} v6 reverse")
+    cnt3 = {}
+    run_gpu(gpu_device, c, version=3, both=True, counters=cnt3)
+    assert cnt["candidates"] == cnt3["candidates"], (cnt, cnt3)
+    again = run_gpu(gpu_device, c, version=6, both=True)
+    assert_same_grid(again[0], want[0], f"{name} v6 forward, no counters")
+    assert_same_grid(again[1], want[1], f"{name} v6 reverse, no counters")
+    default = run_gpu(gpu_device, c, version=6)   # scores of the observable pass only
+    assert_same_grid(default, want[0], f"{name} v6 forward, default score mode")
+
+
 @pytest.mark.parametrize("name", ["tilt3_200x150", "persp_240x180", "ragged_dims"])
 def test_fused_level_calls_equal_independent_calls(gpu_device, oracle, name):
     """cvhip_ctx_set_fuse_level_calls: the reference's four calls per level, in the reference's order, executed as one
