@@ -17,7 +17,7 @@ from cybervision_amd import correlation, synth  # noqa: E402
 from oracle import cvref  # noqa: E402
 
 
-def run(n_cases=40, seed=1, maxdim=420, perspective=False, dev=None, versions=(3, 4, 5), log=print):
+def run(n_cases=40, seed=1, maxdim=420, perspective=False, dev=None, versions=(3, 4, 5, 6), log=print):
     """n_cases random pairs x `versions` against the oracle; returns the number of mismatching (case, version) runs."""
     rng = np.random.default_rng(seed)
     own = dev is None
@@ -49,7 +49,7 @@ def run(n_cases=40, seed=1, maxdim=420, perspective=False, dev=None, versions=(3
         steps = synth.optimal_scale_steps(a.shape[1], a.shape[0])
         p1, p2 = synth.box_pyramid(a, steps), synth.box_pyramid(b, steps)
         want = cvref.correlate_dense(p1, p2, F, proj)
-        # (5: the rectified affine launches on the matrix pipe; everything else of a version-5 run is version 3's)
+        # (5: the rectified affine launches on the matrix pipe, 6: on two image columns per lane; everything else of such a run is version 3's)
         for version in versions:
             # a FRESH context per run, as the reference makes one per pair (the upload ring / pool hand-over are part of the sweep)
             pc = correlation.PointCorrelations(dev, (a.shape[1], a.shape[0]), (b.shape[1], b.shape[0]), F,
