@@ -375,7 +375,8 @@ def box_pyramid_device(device: GpuDevice, img, steps: int):
 def resize_lanczos3(device: GpuDevice, img, scale: float):
     """SourceImage::resize (reconstruction.rs:146-162): the level image at `scale` with the `image` crate's Lanczos3
     (cvhip_resize_lanczos3; tolerance parity, see include/cvhip.h).  img: numpy uint8 array or torch CUDA uint8 tensor;
-    the result lives where the input does."""
+    the result lives where the input does.  A device result is written in the order of the DEVICE HANDLE's stream (no host
+    synchronisation): with a handle on a stream of its own, `device.synchronize()` before another stream reads it."""
     p, w, h, keep = _ptr_shape(img)
     s = np.float32(scale)
     nw, nh = int(np.float32(w) * s), int(np.float32(h) * s)   # (w as f32 * scale) as u32
@@ -395,4 +396,7 @@ def resize_lanczos3(device: GpuDevice, img, scale: float):
 def lanczos_pyramid(device: GpuDevice, img, steps: int):
     """[level 0, ..., level `steps`]: every level resized from the FULL-RESOLUTION image, as the reference's level
     loops do (reconstruction.rs:421-422, 567-568), scale = 1 / (1 << k)."""
-    return [resize_lanczos3(device, img, 1.0 / float(1 << k)) for k in range(steps + 1)]
+    pyr = [resize_lanczos3(device, img, 1.0 / float(1 << k)) for k in range(steps + 1)]
+    if hasattr(img, "data_ptr"):
+        device.synchronize()  # (one wait per pyramid: the levels are complete for whichever stream reads them next)
+    return pyr

@@ -733,6 +733,12 @@ void device_free(cvhip_device *dev)
     if (dev->d.arena.base) (void)hipFree(dev->d.arena.base);
     if (dev->d.pinned) (void)hipHostFree(dev->d.pinned);
     if (dev->d.orb_pattern) (void)hipFree(dev->d.orb_pattern);
+    for (auto &t : dev->d.resize_tables) {
+        if (t.idx) (void)hipFree(t.idx);
+        if (t.weights) (void)hipFree(t.weights);
+    }
+    dev->d.resize_tables.clear();
+    if (dev->d.resize_tmp) (void)hipFree(dev->d.resize_tmp);
     delete dev;
 }
 

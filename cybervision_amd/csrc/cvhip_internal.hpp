@@ -204,6 +204,17 @@ struct Device {
     void *pinned = nullptr;
     size_t pinned_cap = 0;
     void *orb_pattern = nullptr; // the BRIEF pattern in device memory, uploaded once per handle
+    // cvhip_resize_lanczos3: the resampling tables of every (source size, output size) met so far, in device memory - a
+    // pipeline resizes equally sized images to the same few scales over and over (reconstruction.rs:421-422, 567-568) - and the
+    // intermediate f32 plane (grow-only); freed with the handle
+    struct ResizeTable {
+        uint32_t in_size = 0, out_size = 0, max_taps = 0;
+        uint32_t *idx = nullptr;  // left[out_size], count[out_size]
+        float *weights = nullptr; // out_size x max_taps
+    };
+    std::vector<ResizeTable> resize_tables;
+    float *resize_tmp = nullptr;
+    size_t resize_tmp_floats = 0;
     double orb_guard = 1e-9;     // cvhip_orb_set_orientation_guard
     int ransac_in_order = 0;     // cvhip_ransac_set_in_order (test hook): batches are scored in order, behind their events, without polling
     int ransac_lm_pipeline = 2;  // cvhip_ransac_set_lm_pipeline (test hook): validate_f's LM as 2 = two passes on refilled lanes (default), 1 = two passes, a root per thread, 0 = the scalar loop in one kernel

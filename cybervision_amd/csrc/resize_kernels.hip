@@ -136,44 +136,71 @@ extern "C" int cvhip_resize_lanczos3(cvhip_device *dev, const uint8_t *src, uint
             if (!src_dev || !dst_dev) CVHIP_TRY_HIP(hipStreamSynchronize(s));
             return CVHIP_OK;
         }
-        const ResampleTable tv = build_table(h, nh), th = build_table(w, nw);
+        // the tables of this (size, size) pair: built and uploaded once per device handle
+        const auto table_of = [&](uint32_t in_size, uint32_t out_size, const Device::ResizeTable *&out) -> hipError_t {
+            for (const auto &t : dev->d.resize_tables)
+                if (t.in_size == in_size && t.out_size == out_size) {
+                    out = &t;
+                    return hipSuccess;
+                }
+            const ResampleTable host = build_table(in_size, out_size);
+            Device::ResizeTable t;
+            t.in_size = in_size;
+            t.out_size = out_size;
+            t.max_taps = host.max_taps;
+            hipError_t e = hipMalloc(&t.idx, (size_t)2 * out_size * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(&t.weights, host.weights.size() * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpyAsync(t.idx, host.left.data(), (size_t)out_size * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(t.idx + out_size, host.count.data(), (size_t)out_size * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(t.weights, host.weights.data(), host.weights.size() * sizeof(float), hipMemcpyHostToDevice, s);
+            // (the host vectors go away with this scope: the uploads must have happened)
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                if (t.idx) (void)hipFree(t.idx);
+                if (t.weights) (void)hipFree(t.weights);
+                return e;
+            }
+            dev->d.resize_tables.push_back(t);
+            out = &dev->d.resize_tables.back();
+            return hipSuccess;
+        };
+        const Device::ResizeTable *tv = nullptr, *th = nullptr;
+        hipError_t e = table_of(h, nh, tv);
+        if (e == hipSuccess) {
+            const size_t at = tv - dev->d.resize_tables.data(); // (the second lookup may grow the vector)
+            e = table_of(w, nw, th);
+            tv = &dev->d.resize_tables[at];
+        }
         uint8_t *d_src = const_cast<uint8_t *>(src), *d_dst = dst;
-        float *d_tmp = nullptr, *d_wv = nullptr, *d_wh = nullptr;
-        uint32_t *d_iv = nullptr, *d_ih = nullptr; // left then count
-        hipError_t e = hipSuccess;
-        if (!src_dev) {
+        if (e == hipSuccess && !src_dev) {
             e = hipMalloc(&d_src, (size_t)w * h);
             if (e == hipSuccess) e = hipMemcpyAsync(d_src, src, (size_t)w * h, hipMemcpyHostToDevice, s);
         }
         if (e == hipSuccess && !dst_dev) e = hipMalloc(&d_dst, (size_t)nw * nh);
-        if (e == hipSuccess) e = hipMalloc(&d_tmp, (size_t)w * nh * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&d_wv, tv.weights.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&d_wh, th.weights.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&d_iv, (size_t)2 * nh * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_ih, (size_t)2 * nw * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpyAsync(d_wv, tv.weights.data(), tv.weights.size() * sizeof(float), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_wh, th.weights.data(), th.weights.size() * sizeof(float), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_iv, tv.left.data(), (size_t)nh * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_iv + nh, tv.count.data(), (size_t)nh * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_ih, th.left.data(), (size_t)nw * sizeof(uint32_t), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_ih + nw, th.count.data(), (size_t)nw * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && (size_t)w * nh > dev->d.resize_tmp_floats) {
+            // (the plane is reused by later calls in stream order; a larger one is needed: the old one's users must be through)
+            if (dev->d.resize_tmp) {
+                e = hipStreamSynchronize(s);
+                (void)hipFree(dev->d.resize_tmp);
+                dev->d.resize_tmp = nullptr;
+                dev->d.resize_tmp_floats = 0;
+            }
+            if (e == hipSuccess) e = hipMalloc(&dev->d.resize_tmp, (size_t)w * nh * sizeof(float));
+            if (e == hipSuccess) dev->d.resize_tmp_floats = (size_t)w * nh;
+        }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(lanczos_vertical_kernel, dim3((w + 255) / 256, nh), dim3(256), 0, s, d_src, w, d_iv, d_iv + nh, d_wv,
-                               tv.max_taps, nh, d_tmp);
-            hipLaunchKernelGGL(lanczos_horizontal_kernel, dim3((nw + 255) / 256, nh), dim3(256), 0, s, d_tmp, w, d_ih, d_ih + nw,
-                               d_wh, th.max_taps, nw, nh, d_dst);
+            float *d_tmp = dev->d.resize_tmp;
+            hipLaunchKernelGGL(lanczos_vertical_kernel, dim3((w + 255) / 256, nh), dim3(256), 0, s, d_src, w, tv->idx, tv->idx + nh, tv->weights,
+                               tv->max_taps, nh, d_tmp);
+            hipLaunchKernelGGL(lanczos_horizontal_kernel, dim3((nw + 255) / 256, nh), dim3(256), 0, s, d_tmp, w, th->idx, th->idx + nw,
+                               th->weights, th->max_taps, nw, nh, d_dst);
             e = hipGetLastError();
         }
         if (e == hipSuccess && !dst_dev) e = hipMemcpyAsync(dst, d_dst, (size_t)nw * nh, hipMemcpyDeviceToHost, s);
-        // the weight tables live in host vectors of this call: the uploads must have happened before they go away
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        // device -> device: in stream order, no host synchronisation; host buffers are complete (and free again) on return
+        if (e == hipSuccess && (!src_dev || !dst_dev)) e = hipStreamSynchronize(s);
         if (!src_dev && d_src) (void)hipFree(d_src);
         if (!dst_dev && d_dst) (void)hipFree(d_dst);
-        (void)hipFree(d_tmp);
-        (void)hipFree(d_wv);
-        (void)hipFree(d_wh);
-        (void)hipFree(d_iv);
-        (void)hipFree(d_ih);
         if (e != hipSuccess) return fail(CVHIP_ERR_DEVICE, std::string("resize_lanczos3: ") + hipGetErrorString(e));
         return CVHIP_OK;
     } catch (const std::bad_alloc &) {

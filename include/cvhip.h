@@ -334,7 +334,10 @@ int cvhip_downsample_box(cvhip_device *dev, const uint8_t *src, uint32_t w, uint
  * dimensions are a copy).  Weights come from glibc's sinf on the host (what Rust's f32::sin resolves to on linux-gnu);
  * every other step is a single IEEE f32 operation in the crate's order, so the bytes equal the oracle's restatement
  * (oracle/cvref_resize.py, same sinf) exactly - tested with MAX_DIFF = 0.  Nothing pins either to the crate itself
- * ("parity unpinned").  Host or device pointers. */
+ * ("parity unpinned").  Host or device pointers: with a host source or destination the call is complete on return; with
+ * both on the device the two kernels are enqueued on the handle's stream and the call returns (stream order, like
+ * cvhip_complete into device memory).  The resampling tables of every (source size, output size) met are kept in device
+ * memory with the handle - a pipeline resizes equally sized images to the same scales pair after pair. */
 int cvhip_resize_lanczos3(cvhip_device *dev, const uint8_t *src, uint32_t w, uint32_t h, uint8_t *dst, uint32_t nw,
                           uint32_t nh);
 
