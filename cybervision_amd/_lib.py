@@ -82,6 +82,7 @@ SIGNATURES = {
     "cvhip_ransac_perspective": (C.c_int, [_vp, _vp, _u32, C.c_double, C.c_uint64, _u32, _vp, C.POINTER(_u32), _vp]),
     "cvhip_ransac_set_pencil": (C.c_int, [_vp, C.c_int]),
     "cvhip_ransac_set_lm_pipeline": (C.c_int, [_vp, C.c_int]),
+    "cvhip_ransac_set_count_mfma": (C.c_int, [_vp, C.c_int]),
     "cvhip_ransac_set_in_order": (C.c_int, [_vp, C.c_int]),
     "cvhip_ransac_perspective_models": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp]),
     "cvhip_ransac_affine_models": (C.c_int, [_vp, _vp, _u32, _vp, _u32, C.c_double, _vp]),

@@ -31,7 +31,9 @@ FLAGS = [
 # v_pk_fma_f32, which holds a SIMD for ~8.8 cycles against 4 + 4 for the two plain instructions.
 # (The dense kernels' hand-written v_pk_add_f32 / v_pk_mul_f32 pairs are the other way round: written out as plain
 # instructions window_stats_kernel ran 0.54 -> 0.66 ms.)
-EXTRA_FLAGS = {"ransac_kernels.hip": ["-fno-slp-vectorize"]}
+# -amdgpu-mfma-vgpr-form: the counting screen's f32 MFMAs (ransac_count_mfma_kernel) write their results where the vector
+# instructions that decide on them read them - without it every accumulator is copied out of the AGPRs (8 v_accvgpr_read per chunk)
+EXTRA_FLAGS = {"ransac_kernels.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 LINK = ["-ldl", "-pthread"]  # cvhip_rccl.hip opens librccl.so.1 lazily (dlopen): no link-time dependency on RCCL
 
 

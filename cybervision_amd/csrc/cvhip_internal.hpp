@@ -217,6 +217,7 @@ struct Device {
     size_t resize_tmp_floats = 0;
     double orb_guard = 1e-9;     // cvhip_orb_set_orientation_guard
     int ransac_in_order = 0;     // cvhip_ransac_set_in_order (test hook): batches are scored in order, behind their events, without polling
+    int ransac_count_mfma = 0;   // cvhip_ransac_set_count_mfma: the counting screen's head as f32 matrix products (ransac_count_mfma_kernel) - exact, measured slower: off
     int ransac_lm_pipeline = 2;  // cvhip_ransac_set_lm_pipeline (test hook): validate_f's LM as 2 = two passes on refilled lanes (default), 1 = two passes, a root per thread, 0 = the scalar loop in one kernel
     int ransac_pencil = CVHIP_PENCIL_THIN_SVD; // cvhip_ransac_set_pencil: the 7-point pencil's basis (default: the reference's)
     // complete() into HOST memory (GpuContext::complete_process, gpu/mod.rs:210-216): two device staging sets that the

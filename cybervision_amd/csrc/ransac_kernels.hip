@@ -729,6 +729,13 @@ constexpr uint32_t COUNT_GROUP = 256;
 __host__ __device__ inline uint32_t ransac_padded(uint32_t N) { return (N + COUNT_GROUP - 1u) / COUNT_GROUP * COUNT_GROUP; }
 // (index of match i's value inside a plane of ransac_padded(N) floats)
 __host__ __device__ inline uint32_t ransac_plane_slot(uint32_t i) { return 4u * (64u * (i >> 8) + (i & 63u)) + ((i >> 6) & 3u); }
+// how far the matrix-pipe counting phase walks (ransac_count_mfma_kernel): no hypothesis can be abandoned before match N - bound
+__host__ __device__ inline uint32_t ransac_phase_len(uint32_t N, uint32_t bound)
+{
+    const uint32_t np = ransac_padded(N), head = N - (bound < N ? bound : N);
+    const uint32_t L = ransac_padded(head) + 2u * COUNT_GROUP;
+    return L < np ? L : np;
+}
 __global__ __launch_bounds__(1024) void ransac_coord_max_kernel(const uint4 *__restrict__ matches, uint32_t N,
                                                                  uint32_t *__restrict__ out, float4 *__restrict__ matches_f32)
 {
@@ -801,8 +808,11 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
                                                             const float4 *__restrict__ matches_f32,
                                                             uint32_t *__restrict__ out_count,
                                                             double *__restrict__ out_err_sum, uint32_t *__restrict__ cand,
-                                                            uint32_t live_first, uint32_t live_end)
+                                                            uint32_t live_first, uint32_t live_end,
+                                                            const uint32_t *__restrict__ start_count = nullptr)
 {
+    // start_count (phase 2 behind ransac_count_mfma_kernel): `live` is that kernel's survivor list, start_count[j] the inliers
+    // survivor j has among the first ransac_phase_len(N, bound) matches, and the walk continues there.
     // live_first / live_end: the part of the live list this launch scores (the first round goes in two parts: a small
     // head that gives the rest a bound and an order to be abandoned by)
     // cand (the device loops; optional): [0] the largest count completed so far in this launch, [1] the number of
@@ -813,6 +823,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     const uint32_t j0 = live_first + (blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * COUNT_K;
     if (j0 >= n_hyp || N == 0) return; // (an empty list: the counts stay at the zeros they were cleared to)
     uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
+    const uint32_t base0 = start_count ? ransac_phase_len(N, bound) : 0u; // (a multiple of COUNT_GROUP, at most the padded length)
     const double t_hi = t * (1.0 + 0x1p-40);
     const double W = (double)*coord_max, u = 0x1p-24;
     const float T_f = wave_uniform((float)t);
@@ -824,7 +835,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     for (int k = 0; k < COUNT_K; k++) {
         alive[k] = j0 + k < n_hyp;
         slot[k] = live[alive[k] ? j0 + k : j0];
-        count[k] = 0;
+        count[k] = start_count ? start_count[alive[k] ? j0 + k : j0] : 0u;
         double af[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -846,8 +857,9 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     }
     const uint32_t np = ransac_padded(N);
     const float4 *const px1 = matches_f32, *const py1 = px1 + np / 4, *const px2 = px1 + np / 2, *const py2 = px1 + 3 * (np / 4);
-    float4 p1x = px1[lane], p1y = py1[lane], p2x = px2[lane], p2y = py2[lane]; // the first step's matches
-    for (uint32_t base = 0; base < N; base += COUNT_GROUP) {
+    const uint32_t q0 = ((base0 < N ? base0 : 0u) >> 2) + lane;
+    float4 p1x = px1[q0], p1y = py1[q0], p2x = px2[q0], p2y = py2[q0]; // the first step's matches
+    for (uint32_t base = base0; base < N; base += COUNT_GROUP) {
         bool any_alive = false;
 #pragma unroll
         for (int k = 0; k < COUNT_K; k++) {
@@ -939,6 +951,293 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const double *__restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The counting screen on the matrix pipe (round 5).  Per (hypothesis, match) pair the screen needs two numbers:
+//   n   = p2' F p1             = sum_k F_k phi_k(match),     phi = (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1)
+//   t d = t (a0^2 + a1^2 + r0^2 + r1^2) = sum_k G_k psi_k(match),  psi = (x1^2, x1 y1, y1^2, x1, y1, 1, x2^2, x2 y2, y2^2, x2, y2, 1)
+// with G the twelve coefficients of the two quadratic forms (from F, in f64, times t) - two [hypotheses x 12] x [12 x matches]
+// products, i.e. GEMM-shaped work: v_mfma_f32_16x16x4_f32, sixteen hypotheses x sixteen matches x four terms per instruction, six
+// instructions per 256 pairs (192 matrix-pipe cycles per SIMD against ~350 vector-pipe cycles for the sixteen fmas per pair of
+// ransac_count_kernel), leaving the vector pipe the decision: q = n^2 - t d against its error bound, two comparisons, one count.
+// f32 MFMA accumulates with fma roundings in k order, so the bounds are those of a 9- / 12-term fma chain on exact operands
+// (phi, psi: integers below 2^24 for coordinates below 4096; one more rounding each above) with f32-rounded coefficients:
+//   |n_f32 - n| <= E_n = 14 u T_n,   T_n = (|F0|+|F1|+|F3|+|F4|) W^2 + (|F2|+|F5|+|F6|+|F7|) W + |F8|
+//   |d_f32 - t d| <= E_d = 18 u T_d, T_d = the same sum over |G_k| psi_k's largest values
+//   q = fma(n, n, -d):  |q_f32 - q| <= u |q_f32| + E_n (2 |n| + E_n) + E_d; the relative term cannot change q's sign, so with
+//   m = (2 E_n |n| + E_n^2 + E_d) (1 + 2^-20):  q < -m certainly an inlier (then d > E_d: the exact denominator is positive),
+//   q > m certainly none, anything else (NaN included) takes the reference's f64 expression (match_fits) - as before.
+// The kernel walks only the head of the list: a hypothesis can be abandoned no earlier than match N - bound, most are soon after,
+// and a wave holds sixteen of them - so phase 1 (this kernel) covers [0, L), L = N - bound rounded up + 512, for all live
+// hypotheses, and the few that are still alive there continue in ransac_count_kernel from L with the count they have (phase 2;
+// they are also the only ones that can reach the round's maximum, so the candidate logic stays there).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float mf_float4 __attribute__((ext_vector_type(4)));
+// phi / psi of the (re-sorted) match list, in the B-operand layout: per chunk of 16 matches six blocks of 64 floats, block s < 3:
+// phi[4 s + (lane >> 4)] of match 16 c + (lane & 15), block 3 + s: psi likewise - one coalesced dword per lane and block
+__global__ __launch_bounds__(256) void ransac_phi_kernel(const float *__restrict__ planes, uint32_t N, uint32_t np, float *__restrict__ phi)
+{
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, c = gid >> 6, l = gid & 63;
+    if (c * 16u >= np) return;
+    const uint32_t i = c * 16u + (l & 15u), kq = l >> 4;
+    float x1 = 0.0f, y1 = 0.0f, x2 = 0.0f, y2 = 0.0f, one = 0.0f;
+    if (i < N) {
+        const uint32_t slot = ransac_plane_slot(i);
+        x1 = planes[slot];
+        y1 = planes[np + slot];
+        x2 = planes[2u * np + slot];
+        y2 = planes[3u * np + slot];
+        one = 1.0f;
+    }
+    const float ph[3][4] = {{x2 * x1, x2 * y1, x2, y2 * x1}, {y2 * y1, y2, x1, y1}, {one, 0.0f, 0.0f, 0.0f}};
+    const float ps[3][4] = {{x1 * x1, x1 * y1, y1 * y1, x1}, {y1, one, x2 * x2, x2 * y2}, {y2 * y2, x2, y2, one}};
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const float a = kq == 0 ? ph[s][0] : (kq == 1 ? ph[s][1] : (kq == 2 ? ph[s][2] : ph[s][3]));
+        const float b = kq == 0 ? ps[s][0] : (kq == 1 ? ps[s][1] : (kq == 2 ? ps[s][2] : ps[s][3]));
+        phi[((size_t)c * 6u + s) * 64u + l] = a;
+        phi[((size_t)c * 6u + 3u + s) * 64u + l] = b;
+    }
+}
+
+// a pair the screen left open: the reference's expression (out of line: sixteen call sites in a rarely taken branch)
+__device__ __attribute__((noinline)) uint32_t mfma_open_pair(const double *__restrict__ F, uint32_t slot, uint4 mm, double t, double t_hi, bool mine)
+{
+    if (!mine) return 0u;
+    double ff[9], err;
+#pragma unroll
+    for (int k = 0; k < 9; k++) ff[k] = F[(size_t)slot * 9 + k];
+    return match_fits(ff, mm, t, t_hi, err) ? 1u : 0u;
+}
+
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v) // sum over the 16 lanes of a DPP row, in every lane of the row
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2, 3, 0, 1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); // row_mirror
+    return v;
+}
+
+// surv: [0] = survivors (atomic), [4 .. 4 + cap) their slots, [4 + cap .. 4 + 2 cap) their counts over [0, L)
+__global__ __launch_bounds__(256) void ransac_count_mfma_kernel(const double *__restrict__ F, const uint4 *__restrict__ matches, uint32_t N, double t,
+                                                                 const uint32_t *__restrict__ live, const uint32_t *__restrict__ n_live,
+                                                                 uint32_t min_count, const RansacBest *__restrict__ best,
+                                                                 const uint32_t *__restrict__ coord_max, const float *__restrict__ phi,
+                                                                 uint32_t *__restrict__ out_count, double *__restrict__ out_err_sum,
+                                                                 uint32_t *__restrict__ surv, uint32_t surv_cap, uint32_t live_first, uint32_t live_end)
+{
+    const uint32_t n_hyp = min(*n_live, live_end), lane = threadIdx.x & 63;
+    const uint32_t jb = live_first + blockIdx.x * 64u; // the workgroup's first hypothesis: its four waves take sixteen each
+    const uint32_t j0 = jb + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 16u;
+    if (jb >= n_hyp || N == 0) return; // (per WORKGROUP: a wave without hypotheses still takes part in the loads and barriers)
+    const uint32_t bound = best->valid ? max(min_count, best->matches_count) : min_count;
+    const uint32_t L = ransac_phase_len(N, bound);
+    const uint32_t i = lane & 15u, kq = lane >> 4;
+    const double t_hi = t * (1.0 + 0x1p-40);
+    // ---- this lane's hypothesis in its role as an A-operand row: coefficients, bounds
+    const bool have_i = j0 + i < n_hyp;
+    const uint32_t slot_i = live[have_i ? j0 + i : jb];
+    double f[9], af[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        f[k] = F[(size_t)slot_i * 9 + k];
+        af[k] = fabs(f[k]);
+    }
+    const double W = (double)*coord_max, u = 0x1p-24;
+    // t (a0^2 + a1^2): a0 = F0 x1 + F1 y1 + F2, a1 = F3 x1 + F4 y1 + F5;  t (r0^2 + r1^2): r0 = F0 x2 + F3 y2 + F6, r1 = F1 x2 + F4 y2 + F7
+    double G[12];
+    G[0] = t * (f[0] * f[0] + f[3] * f[3]);
+    G[1] = t * (2.0 * (f[0] * f[1] + f[3] * f[4]));
+    G[2] = t * (f[1] * f[1] + f[4] * f[4]);
+    G[3] = t * (2.0 * (f[0] * f[2] + f[3] * f[5]));
+    G[4] = t * (2.0 * (f[1] * f[2] + f[4] * f[5]));
+    G[5] = t * (f[2] * f[2] + f[5] * f[5]);
+    G[6] = t * (f[0] * f[0] + f[1] * f[1]);
+    G[7] = t * (2.0 * (f[0] * f[3] + f[1] * f[4]));
+    G[8] = t * (f[3] * f[3] + f[4] * f[4]);
+    G[9] = t * (2.0 * (f[0] * f[6] + f[1] * f[7]));
+    G[10] = t * (2.0 * (f[3] * f[6] + f[4] * f[7]));
+    G[11] = t * (f[6] * f[6] + f[7] * f[7]);
+    const double Tn = (af[0] + af[1] + af[3] + af[4]) * W * W + (af[2] + af[5] + af[6] + af[7]) * W + af[8];
+    // (the expanded quadratic forms: every |G_k| psi_k is at most the square sums' own bound, signs ignored)
+    const double Td = (fabs(G[0]) + fabs(G[1]) + fabs(G[2]) + fabs(G[6]) + fabs(G[7]) + fabs(G[8])) * W * W +
+                      (fabs(G[3]) + fabs(G[4]) + fabs(G[9]) + fabs(G[10])) * W + fabs(G[5]) + fabs(G[11]);
+    const double En = 1.001 * 14.0 * u * Tn, Ed = 1.001 * 18.0 * u * Td;
+    const float En2_i = (float)(2.0 * En * (1.0 + 0x1p-20)), C0_i = (float)((En * En + Ed) * (1.0 + 0x1p-20));
+    // the screen runs only where every bound and every product stays a NORMAL f32 number (false for NaN / inf coefficients)
+    const bool screen_i = Tn >= 1e-6 && Tn <= 1e15 && Td >= 1e-12 && Td <= 1e30 && t >= 1e-6 && t <= 1e12 && W < 16777216.0;
+    float an[3], ad[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        double vn = 0.0, vd = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((int)kq == k) {
+                vn = 4 * s + k < 9 ? f[4 * s + k < 9 ? 4 * s + k : 0] : 0.0;
+                vd = G[4 * s + k];
+            }
+        an[s] = (float)vn;
+        ad[s] = (float)vd;
+    }
+    // ---- the four hypotheses whose results this lane holds (accumulator rows 4 kq + r): constants, flags, slots
+    float En2r[4], C0r[4];
+    uint32_t slot_r[4], cnt[4] = {0u, 0u, 0u, 0u};
+    bool have_r[4];
+    unsigned long long alive_m[4]; // lane masks (scalar registers): the row's hypothesis is still alive
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int src = (int)(4u * kq) + r;
+        En2r[r] = __shfl(En2_i, src, 64);
+        C0r[r] = __shfl(C0_i, src, 64);
+        slot_r[r] = (uint32_t)__shfl((int)slot_i, src, 64);
+        if (__shfl(screen_i ? 1 : 0, src, 64) == 0) C0r[r] = __builtin_inff(); // not screened: every pair of the row stays open
+        have_r[r] = __shfl(have_i ? 1 : 0, src, 64) != 0;
+        alive_m[r] = __builtin_amdgcn_ballot_w64(have_r[r]);
+    }
+    // Pairs the screen leaves open (a few per 10 000) are not decided where they turn up - the f64 expression with its loads
+    // of the hypothesis would stall the wave every other trip - but parked on a small list per wave (row | match << 4) and
+    // decided together when the walk is over; until then they count as POSSIBLE inliers wherever a hypothesis is tested for
+    // abandonment (pendc), so nobody is abandoned who could still reach the bound.
+    constexpr uint32_t PCAP = 224;
+    __shared__ uint32_t s_pend[4][PCAP], s_pend_cnt[4][16];
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (lane < 16u) s_pend_cnt[wv][lane] = 0u;
+    uint32_t pend_n = 0u; // (wave-uniform)
+    uint32_t pendc[4] = {0u, 0u, 0u, 0u};
+    // Four chunks (64 matches) per trip: their 24 operand dwords are loaded a trip ahead, the 24 MFMAs are eight independent
+    // accumulator chains (no dependent-issue stalls), and the decision code is branch-free - masks are scalar.
+    constexpr uint32_t CH = 4;
+    // The four waves of a workgroup walk the SAME matches (different hypotheses), in step: a trip's operands (4 chunks x 6
+    // blocks x 64 floats = 6 KB) are loaded once per workgroup - six dwords per thread, a trip ahead - and handed round
+    // through a double buffer in LDS.  (Each wave loading its own: 24 loads per trip and wave, and Little's law on the L2
+    // latency held the kernel at 44 % of the matrix pipe.)
+    constexpr uint32_t TRIP_FLOATS = CH * 6u * 64u;
+    // (a ring of three buffers: the loads issued at the top of trip t - the operands of trip t + 2 - have the whole trip to arrive
+    // before they are written into the ring at the top of trip t + 1; with two buffers the trip itself had to outlast the L2
+    // latency, and the matrix pipe stood at 46 %)
+    __shared__ float s_b[3][TRIP_FLOATS];
+    const uint32_t last_c = (L >> 4) - CH; // first chunk of the last trip
+    float pre[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) s_b[0][threadIdx.x + 256u * j] = phi[threadIdx.x + 256u * j];
+    {
+        const float *const p1 = phi + (size_t)min(CH, last_c) * (6u * 64u);
+#pragma unroll
+        for (int j = 0; j < 6; j++) pre[j] = p1[threadIdx.x + 256u * j];
+    }
+    for (uint32_t base = 0, trip = 0, slot3 = 0; base < L; base += 16u * CH, trip++, slot3 = slot3 == 2u ? 0u : slot3 + 1u) {
+        // (L is a multiple of 256, the same for every wave)
+        const uint32_t next3 = slot3 == 2u ? 0u : slot3 + 1u;
+#pragma unroll
+        for (int j = 0; j < 6; j++) s_b[next3][threadIdx.x + 256u * j] = pre[j]; // trip + 1's operands (loaded during the last trip)
+        const float *const pn = phi + (size_t)min((trip + 2u) * CH, last_c) * (6u * 64u); // (past the end: the last trip's again)
+#pragma unroll
+        for (int j = 0; j < 6; j++) pre[j] = pn[threadIdx.x + 256u * j];
+        __syncthreads(); // this trip's buffer is complete (written a trip ago); the one being written was last read two trips ago
+        float b[CH][6];
+#pragma unroll
+        for (uint32_t c = 0; c < CH; c++)
+#pragma unroll
+            for (int s = 0; s < 6; s++) b[c][s] = s_b[slot3][(c * 6u + s) * 64u + lane];
+        mf_float4 accn[CH], accd[CH];
+#pragma unroll
+        for (uint32_t c = 0; c < CH; c++) {
+            accn[c] = mf_float4{0.0f, 0.0f, 0.0f, 0.0f};
+            accd[c] = mf_float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+#pragma unroll
+            for (uint32_t c = 0; c < CH; c++) {
+                accn[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(an[s], b[c][s], accn[c], 0, 0, 0);
+                accd[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad[s], b[c][3 + s], accd[c], 0, 0, 0);
+            }
+        // The decisions, in vector registers only (six instructions per pair, no mask arithmetic on the scalar unit): the
+        // count takes every certain inlier - a column beyond the list has n = d = 0 and is never one, a dead row's count is
+        // never read, an unscreened row has m = inf -, and one bit per pair notes what is open; which of those matter (the
+        // row alive, the column inside the list) is sorted out only in the trips that have any.
+        uint32_t openbits = 0u; // bit 15 - (4 c + r): this lane's pair (chunk c, row r) is open
+#pragma unroll
+        for (uint32_t c = 0; c < CH; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float nn = accn[c][r], d = accd[c][r];
+                const float q = __builtin_fmaf(nn, nn, -d);
+                const float m = __builtin_fmaf(__builtin_fabsf(nn), En2r[r], C0r[r]);
+                asm("v_cmp_lt_f32 vcc, %1, -%2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cnt[r]) : "v"(q), "v"(m) : "vcc");
+                asm("v_cmp_ngt_f32 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(openbits) : "v"(q), "v"(m) : "vcc");
+            }
+        if (__builtin_amdgcn_ballot_w64(openbits != 0u)) {
+#pragma unroll
+            for (uint32_t c = 0; c < CH; c++) {
+                const unsigned long long colv = __builtin_amdgcn_ballot_w64(base + 16u * c + i < N);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned long long om = __builtin_amdgcn_ballot_w64(((openbits >> (15u - (4u * c + (uint32_t)r))) & 1u) != 0u) & colv & alive_m[r];
+                    if (!om) continue;
+                    const uint32_t n_open = (uint32_t)__builtin_popcountll(om);
+                    const bool mine = ((om >> lane) & 1ull) != 0ull;
+                    const uint32_t mi = base + 16u * c + i;
+                    if (pend_n + n_open <= PCAP) {
+                        const uint32_t at = pend_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+                        if (mine) s_pend[wv][at] = (4u * kq + (uint32_t)r) | (mi << 4);
+                        asm("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(pendc[r]) : "s"(om) : "vcc");
+                        pend_n += n_open;
+                    } else { // the list is full (never seen): decided on the spot
+                        cnt[r] += mfma_open_pair(F, slot_r[r], matches[mi < N ? mi : 0u], t, t_hi, mine);
+                    }
+                }
+            }
+        }
+        if (((base >> 4) & 15u) == 16u - CH) { // every 256 matches: who cannot reach the bound any more?
+            unsigned long long any_alive = 0ull;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t tot = row16_sum(cnt[r] + pendc[r]); // (the parked pairs as if they were all inliers)
+                alive_m[r] &= ~__builtin_amdgcn_ballot_w64(tot + (N - min(N, base + 16u * CH)) < bound);
+                any_alive |= alive_m[r];
+            }
+            // (the workgroup leaves together: its waves share the operand stream and its barriers)
+            if (!__syncthreads_or(any_alive != 0ull ? 1 : 0)) break;
+        }
+    }
+    // ---- the parked pairs, one per lane: the reference's f64 expression (match_fits), tallied per row in LDS
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t e0 = 0; e0 < pend_n; e0 += 64u) {
+        const bool mine = e0 + lane < pend_n;
+        const uint32_t entry = mine ? s_pend[wv][e0 + lane] : 0u;
+        const uint32_t row = entry & 15u, mi = entry >> 4;
+        const uint32_t slot = (uint32_t)__shfl((int)slot_i, (int)row, 64);
+        if (mine) {
+            double ff[9], err;
+#pragma unroll
+            for (int k = 0; k < 9; k++) ff[k] = F[(size_t)slot * 9 + k];
+            if (match_fits(ff, matches[mi < N ? mi : 0u], t, t_hi, err)) atomicAdd(&s_pend_cnt[wv][row], 1u);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t tot = row16_sum(cnt[r]) + s_pend_cnt[wv][4u * kq + (uint32_t)r];
+        if (i == 0u && have_r[r]) {
+            if (!((alive_m[r] >> lane) & 1ull)) {
+                out_count[slot_r[r]] = 0u;
+                out_err_sum[slot_r[r]] = 0.0;
+            } else {
+                const uint32_t at = atomicAdd(&surv[0], 1u);
+                if (at < surv_cap) {
+                    surv[4u + at] = slot_r[r];
+                    surv[4u + surv_cap + at] = tot;
+                }
+            }
+        }
+    }
+}
 
 // the round's largest count, and the list of the live hypotheses that have it: tied[0] = their number, then the slots
 __global__ __launch_bounds__(1024) void ransac_round_max_kernel(const uint32_t *__restrict__ counts,
@@ -1354,6 +1653,20 @@ __global__ __launch_bounds__(1024) void ransac_round_tied_list_kernel(uint32_t *
 // The live slots of a round's hypothesis buffer, in slot order (count, scan, scatter).  Depends on the hypotheses only,
 // so the device loops run it on the GENERATOR's stream right behind the generation - off the scoring chain.
 // scratch: ceil(H / 1024) words.
+// workspace of the matrix-pipe counting phase (ransac_count_mfma_kernel): the B operands of the match list (24 floats per match of
+// the padded list) and the survivor list [4 + 2 cap] (cap = the most live hypotheses one scoring launch can see)
+struct CountMfmaWs {
+    float *phi = nullptr;
+    uint32_t *surv = nullptr;
+    uint32_t cap = 0;
+};
+template <typename Mem> static hipError_t alloc_count_mfma(Mem &mem, uint32_t N, uint32_t cap, CountMfmaWs &ws)
+{
+    hipError_t e = mem.alloc(&ws.phi, (size_t)ransac_padded(std::max(N, 1u)) * 24u);
+    if (e == hipSuccess) e = mem.alloc(&ws.surv, 4 + 2 * (size_t)cap);
+    ws.cap = cap;
+    return e;
+}
 static void launch_ransac_live(const double *F, uint32_t H, uint32_t *live, uint32_t *n_live, uint32_t *scratch, hipStream_t s)
 {
     const uint32_t nblocks = (H + 1023) / 1024;
@@ -1368,7 +1681,7 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
                                       uint32_t N, double t, uint32_t *live, uint32_t *n_live, uint32_t *tied,
                                       const uint32_t *coord_max, bool live_ready, bool approx_sums, uint32_t min_count,
                                       RansacBest *best, uint32_t *out_count, double *out_err_sum, hipStream_t s, uint32_t *cand = nullptr,
-                                      uint32_t live_first = 0, uint32_t live_end = 0xFFFFFFFFu)
+                                      uint32_t live_first = 0, uint32_t live_end = 0xFFFFFFFFu, const CountMfmaWs *ws = nullptr)
 {
     const uint4 *m4 = reinterpret_cast<const uint4 *>(matches);
     // (the device loops read the counts through the live list only, and the counting kernel writes every live slot when
@@ -1379,7 +1692,19 @@ static void launch_ransac_score_round(const double *F, uint32_t H, const uint32_
     // (grids are sized for the case that every slot is live; waves / workgroups beyond *n_live leave at once)
     // (count_matches / matches_f32: the counting kernel's own copy of the list - same matches, any order)
     const uint32_t span = std::min(H, live_end) > live_first ? std::min(H, live_end) - live_first : 0u;
-    if (span)
+    if (span && ws && ws->phi && N > 0 && span <= ws->cap) {
+        // phase 1 on the matrix pipe (every live hypothesis over the head of the list), phase 2 for whoever is still alive
+        const uint32_t np = ransac_padded(N);
+        (void)hipMemsetAsync(ws->surv, 0, 4 * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(ransac_phi_kernel, dim3((np * 4u + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const float *>(matches_f32), N, np, ws->phi);
+        hipLaunchKernelGGL(ransac_count_mfma_kernel, dim3((span + 63u) / 64u), dim3(256), 0, s, F, reinterpret_cast<const uint4 *>(count_matches), N, t,
+                           (const uint32_t *)live, (const uint32_t *)n_live, min_count, (const RansacBest *)best, coord_max, (const float *)ws->phi,
+                           out_count, out_err_sum, ws->surv, ws->cap, live_first, live_end);
+        hipLaunchKernelGGL(ransac_count_kernel, dim3((span + 4 * COUNT_K - 1) / (4 * COUNT_K)), dim3(256), 0, s, F,
+                           reinterpret_cast<const uint4 *>(count_matches), N, t, (const uint32_t *)(ws->surv + 4), (const uint32_t *)ws->surv, min_count,
+                           (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum, cand, 0u, 0xFFFFFFFFu,
+                           (const uint32_t *)(ws->surv + 4 + ws->cap));
+    } else if (span)
         hipLaunchKernelGGL(ransac_count_kernel, dim3((span + 4 * COUNT_K - 1) / (4 * COUNT_K)), dim3(256), 0, s, F,
                            reinterpret_cast<const uint4 *>(count_matches), N, t, (const uint32_t *)live, (const uint32_t *)n_live, min_count,
                            (const RansacBest *)best, coord_max, matches_f32, out_count, out_err_sum, cand, live_first, live_end);
@@ -2751,8 +3076,10 @@ extern "C" int cvhip_ransac_round_score(cvhip_device *dev, const double *F, uint
     CVHIP_TRY_HIP(mem.alloc(&d_mf, ransac_padded(std::max(N, 1u))));
     hipLaunchKernelGGL(ransac_coord_max_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4 *>(d_m), N,
                        d_live + H + 3 + TIED_CAP, d_mf);
+    CountMfmaWs ws;
+    if (dev->d.ransac_count_mfma) CVHIP_TRY_HIP(alloc_count_mfma(mem, N, H, ws));
     launch_ransac_score_round(d_F, H, d_m, d_m, d_mf, N, t, d_live, d_live + H, d_live + H + 1, d_live + H + 3 + TIED_CAP, false, false, 0u, d_best,
-                              d_cnt, d_err, s);
+                              d_cnt, d_err, s, nullptr, 0u, 0xFFFFFFFFu, dev->d.ransac_count_mfma ? &ws : nullptr);
     CVHIP_TRY_HIP(hipGetLastError());
     CVHIP_TRY_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)H * sizeof(uint32_t), dev_ptr(out_count) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     CVHIP_TRY_HIP(hipMemcpyAsync(out_err_sum, d_err, (size_t)H * sizeof(double), dev_ptr(out_err_sum) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
@@ -2791,6 +3118,8 @@ extern "C" int cvhip_ransac_rounds_pick(cvhip_device *dev, const double *F, uint
     CVHIP_TRY_HIP(mem.alloc(&d_cand, 2 + 2 * (size_t)TIED_CAP));
     CVHIP_TRY_HIP(mem.alloc(&d_best, 1));
     CVHIP_TRY_HIP(mem.alloc(&d_mf, ransac_padded(N)));
+    CountMfmaWs ws;
+    if (dev->d.ransac_count_mfma) CVHIP_TRY_HIP(alloc_count_mfma(mem, N, per, ws));
     uint32_t *const d_tied = d_live + live_words, *const d_coord_max = d_tied + 2 + TIED_CAP;
     CVHIP_TRY_HIP(hipMemcpyAsync(d_F, F, (size_t)H * 9 * sizeof(double), dev_ptr(F) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     CVHIP_TRY_HIP(hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
@@ -2805,7 +3134,7 @@ extern "C" int cvhip_ransac_rounds_pick(cvhip_device *dev, const double *F, uint
         const double *F_round = d_F + (size_t)first * 9;
         launch_ransac_live(F_round, n, d_live, d_live + per, d_live + per + 1, s);
         launch_ransac_score_round(F_round, n, d_m, d_mo, d_mf, N, t, d_live, d_live + per, d_tied, d_coord_max, true, true, min_count, d_best,
-                                  d_cnt, d_err, s, d_cand);
+                                  d_cnt, d_err, s, d_cand, 0u, 0xFFFFFFFFu, dev->d.ransac_count_mfma ? &ws : nullptr);
         hipLaunchKernelGGL(ransac_round_finish_kernel, dim3(1), dim3(1024), 0, s, F_round, m4, N, t, d_err, min_count, d_cand, d_tied, d_best,
                            reinterpret_cast<uint4 *>(d_mo), reinterpret_cast<float *>(d_mf), first);
     }
@@ -3001,6 +3330,9 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
     if (e == hipSuccess) e = mem.alloc(&d_mo, (size_t)N * 4);
     uint32_t *d_cand = nullptr; // the counting kernel's running maximum and candidate list (ransac_round_finish_kernel clears it per round)
     if (e == hipSuccess) e = mem.alloc(&d_cand, 2 + 2 * (size_t)TIED_CAP);
+    CountMfmaWs mfma_ws; // the counting screen's phase on the matrix pipe (cvhip_ransac_set_count_mfma)
+    const CountMfmaWs *const ws = dev->d.ransac_count_mfma ? &mfma_ws : nullptr;
+    if (e == hipSuccess && ws) e = alloc_count_mfma(mem, N, std::max<uint32_t>(GEN_BATCH * H, late ? late->cap : 0u), mfma_ws);
     if (e == hipSuccess) e = hipMemsetAsync(d_cand, 0, 2 * sizeof(uint32_t), s);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_m, matches, (size_t)N * 16, dev_ptr(matches) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
@@ -3211,7 +3543,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
             for (uint32_t part = 0; part < parts && e == hipSuccess; part++) {
                 const uint32_t first = part == 0 ? 0u : HEAD, end = parts == 2 && part == 0 ? HEAD : 0xFFFFFFFFu;
                 launch_ransac_score_round(F_unit, HS, d_m, d_mo, d_mf, N, t, lv, lv + HS, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt,
-                                          d_err, s, d_cand, first, end);
+                                          d_err, s, d_cand, first, end, ws);
                 hipLaunchKernelGGL(ransac_round_tied_list_kernel, dim3(1), dim3(1024), 0, s, d_cand, d_tied);
                 hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, F_unit, m4, N, t, (const uint32_t *)d_tied, d_best, d_err);
                 hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, F_unit, m4, N, t, (const uint32_t *)nullptr, d_err,
@@ -3237,7 +3569,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         if (e == hipSuccess && late && late_enqueued) { // the stragglers' hypotheses: one more round, met last
             e = hipStreamWaitEvent(s, rq.ready[7], 0);
             launch_ransac_score_round(late->F, late->cap, d_m, d_mo, d_mf, N, t, d_late_live, d_late_live + late->cap, d_tied, d_coord_max, true, true,
-                                      min_count, d_best, d_cnt, d_err, s, d_cand, 0u, 0xFFFFFFFFu);
+                                      min_count, d_best, d_cnt, d_err, s, d_cand, 0u, 0xFFFFFFFFu, ws);
             hipLaunchKernelGGL(ransac_round_tied_list_kernel, dim3(1), dim3(1024), 0, s, d_cand, d_tied);
             hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, late->F, m4, N, t, (const uint32_t *)d_tied, d_best, d_err);
             hipLaunchKernelGGL(ransac_pick_best_approx_kernel, dim3(1), dim3(1024), 0, s, late->F, m4, N, t, (const uint32_t *)nullptr, d_err, min_count,
@@ -3277,7 +3609,7 @@ int ransac_rounds(cvhip_device *dev, DevAllocs &mem, const uint32_t *matches, ui
         for (uint32_t part = 0; part < parts && !(score_batches && q != 0); part++) {
             const uint32_t first = part == 0 ? 0u : ROUND0_HEAD, end = parts == 2 && part == 0 ? ROUND0_HEAD : 0xFFFFFFFFu;
             launch_ransac_score_round(F_round, HS, d_m, d_mo, d_mf, N, t, lv, lv + HS, d_tied, d_coord_max, true, true, min_count, d_best, d_cnt, d_err,
-                                      s, d_cand, first, end);
+                                      s, d_cand, first, end, ws);
             if (score_batches) {
                 hipLaunchKernelGGL(ransac_round_tied_list_kernel, dim3(1), dim3(1024), 0, s, d_cand, d_tied);
                 hipLaunchKernelGGL(ransac_tied_approx_kernel, dim3(16), dim3(1024), 0, s, F_round, m4, N, t, (const uint32_t *)d_tied, d_best, d_err);
@@ -3389,6 +3721,13 @@ extern "C" int cvhip_ransac_set_pencil(cvhip_device *dev, int pencil)
     if (!dev) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_pencil: null device");
     if (pencil != CVHIP_PENCIL_THIN_SVD && pencil != CVHIP_PENCIL_NULL_SPACE) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_pencil: unknown mode");
     dev->d.ransac_pencil = pencil;
+    return CVHIP_OK;
+}
+
+extern "C" int cvhip_ransac_set_count_mfma(cvhip_device *dev, int enable)
+{
+    if (!dev) return fail(CVHIP_ERR_INVALID, "cvhip_ransac_set_count_mfma: null device");
+    dev->d.ransac_count_mfma = enable ? 1 : 0;
     return CVHIP_OK;
 }
 

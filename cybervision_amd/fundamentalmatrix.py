@@ -31,6 +31,11 @@ def set_lm_pipeline(device, enable):
     _lib.check(_lib.lib().cvhip_ransac_set_lm_pipeline(device.handle, mode), "cvhip_ransac_set_lm_pipeline")
 
 
+def set_count_mfma(device, enable: bool):
+    """cvhip_ransac_set_count_mfma: the counting screen's head as f32 matrix products (exact, measured slower: off by default)."""
+    _lib.check(_lib.lib().cvhip_ransac_set_count_mfma(device.handle, int(bool(enable))), "cvhip_ransac_set_count_mfma")
+
+
 def set_in_order(device, enable: bool):
     """cvhip_ransac_set_in_order (test hook): score the batches of rounds in order behind their events, without polling."""
     _lib.check(_lib.lib().cvhip_ransac_set_in_order(device.handle, int(bool(enable))), "cvhip_ransac_set_in_order")

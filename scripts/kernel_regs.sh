@@ -3,7 +3,7 @@
 # (compiles to assembly with the build's flags and reads the .amdhsa_ directives)
 src=$1; pat=${2:-.}
 root=$(cd "$(dirname "$0")/.." && pwd)
-extra=""; [ "$src" = "ransac_kernels.hip" ] && extra="-fno-slp-vectorize"
+extra=""; [ "$src" = "ransac_kernels.hip" ] && extra="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1"
 out=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt $extra \
     -S --cuda-device-only -o $out/k.s $root/cybervision_amd/csrc/$src 2>/dev/null || exit 1

@@ -184,11 +184,24 @@ def test_ransac_score_ragged_sizes(gpu_device, oracle):
         assert (got_c == want_c).all() and (got_e.view(np.uint64) == want_e.view(np.uint64)).all()
 
 
-def test_round_counting_kernel_is_exact(gpu_device, oracle, oracle_fm):
-    """The counting kernel of a RANSAC round decides most (hypothesis, match) pairs in packed f32 against error bounds
+@pytest.mark.parametrize("mfma", [True, False])
+def test_round_counting_kernel_is_exact(gpu_device, oracle, oracle_fm, mfma):
+    """(mfma: the screen's head as f32 matrix products - ransac_count_mfma_kernel, an option - or the vector kernel alone, the
+    default; cvhip_ransac_set_count_mfma.)
+    The counting kernel of a RANSAC round decides most (hypothesis, match) pairs in packed f32 against error bounds
     and only the guard band in f64: its counts must be the f64 counts - on good hypotheses whose inliers sit right at
     the threshold (t chosen AS the error of individual matches, and one ulp either side), on perturbed, random,
     huge, tiny and non-finite hypotheses; the ordered sums of the hypotheses tied at the maximum must be the oracle's."""
+    import cases
+
+    fundamentalmatrix.set_count_mfma(gpu_device, mfma)
+    try:
+        _round_counting_cases(gpu_device, oracle, oracle_fm)
+    finally:
+        fundamentalmatrix.set_count_mfma(gpu_device, False)
+
+
+def _round_counting_cases(gpu_device, oracle, oracle_fm):
     import cases
 
     m, truth, _, _ = cases.perspective_matches(n=5000, outlier_frac=0.3)
@@ -683,9 +696,16 @@ def test_ransac_scheduler_paths_agree(gpu_device):
                 fundamentalmatrix.set_in_order(gpu_device, False)
             pl3 = Listener()
             F3, _, mask3 = fmx.find_ransac(gpu_device, m, seed=9, progress_listener=pl3)
+            # ... and with the counting screen's head as f32 matrix products (cvhip_ransac_set_count_mfma: phase 1 on
+            # ransac_count_mfma_kernel, survivors in the vector kernel) - the same exact counts, hence the same winner
+            fundamentalmatrix.set_count_mfma(gpu_device, True)
+            try:
+                F4, _, mask4 = fmx.find_ransac(gpu_device, m, seed=9)
+            finally:
+                fundamentalmatrix.set_count_mfma(gpu_device, False)
         finally:
             fundamentalmatrix.set_pencil(gpu_device, fundamentalmatrix.PENCIL_THIN_SVD)
-        for F, mask in ((F1, mask1), (F2, mask2), (F3, mask3)):
+        for F, mask in ((F1, mask1), (F2, mask2), (F3, mask3), (F4, mask4)):
             assert (F.view(np.uint64) == F0.view(np.uint64)).all() and (mask == mask0).all(), pencil
         assert len(pl.matches) == 6 and len(pl3.matches) == 6 and pl.matches[-1] == pl3.matches[-1]
         assert (mask0 & truth).sum() > 0.9 * truth.sum(), (pencil, (mask0 & truth).sum(), truth.sum())
