@@ -207,6 +207,7 @@ static int copy_stream_reserve(Device &d)
     auto &rb = d.rb;
     if (rb.stream) return CVHIP_OK;
     CVHIP_TRY_HIP(hipStreamCreateWithFlags(&rb.stream, hipStreamNonBlocking));
+    CVHIP_TRY_HIP(hipStreamCreateWithFlags(&d.up.stream, hipStreamNonBlocking));
     CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.ready, hipEventDisableTiming));
     CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.expanded, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) CVHIP_TRY_HIP(hipEventCreateWithFlags(&rb.done[i], hipEventDisableTiming));
@@ -323,15 +324,15 @@ static int stage_images(cvhip_ctx *c, int k, const uint8_t *img1, size_t n1, con
         }
         host_copy(ring, src[i], n[i]);
         if (!c->pool_waited) { // (the pool's clearing at context creation is work of the context's stream)
-            if (c->pool_ready) CVHIP_TRY_HIP(hipStreamWaitEvent(d.rb.stream, c->pool_ready, 0));
+            if (c->pool_ready) CVHIP_TRY_HIP(hipStreamWaitEvent(d.up.stream, c->pool_ready, 0));
             c->pool_waited = true;
         }
         if (!waited_readers && k < 16 && c->level_read[k]) {
-            CVHIP_TRY_HIP(hipStreamWaitEvent(d.rb.stream, c->level_read[k], 0));
+            CVHIP_TRY_HIP(hipStreamWaitEvent(d.up.stream, c->level_read[k], 0));
             waited_readers = true;
         }
-        CVHIP_TRY_HIP(hipMemcpyAsync(c->img[i] + off, ring, n[i], hipMemcpyHostToDevice, d.rb.stream));
-        CVHIP_TRY_HIP(hipEventRecord(done, d.rb.stream));
+        CVHIP_TRY_HIP(hipMemcpyAsync(c->img[i] + off, ring, n[i], hipMemcpyHostToDevice, d.up.stream));
+        CVHIP_TRY_HIP(hipEventRecord(done, d.up.stream));
         CVHIP_TRY_HIP(hipStreamWaitEvent(s, done, 0));
     }
     return CVHIP_OK;
@@ -681,6 +682,7 @@ void device_free(cvhip_device *dev)
     {
         auto &rb = dev->d.rb;
         if (rb.stream) (void)hipStreamSynchronize(rb.stream);
+        if (dev->d.up.stream) (void)hipStreamSynchronize(dev->d.up.stream);
         for (int i = 0; i < 2; i++) {
             if (rb.xy[i]) (void)hipFree(rb.xy[i]);
             if (rb.corr[i]) (void)hipFree(rb.corr[i]);
@@ -696,6 +698,7 @@ void device_free(cvhip_device *dev)
         if (up.base) (void)hipHostFree(up.base);
         up.base = nullptr;
         if (rb.stream) (void)hipStreamDestroy(rb.stream);
+        if (up.stream) (void)hipStreamDestroy(up.stream);
     }
     {
         auto &rq = dev->d.rq;
@@ -924,7 +927,10 @@ void cvhip_ctx_destroy(cvhip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->dev->d.ordinal);
-    if (ctx->dev->d.rb.stream) (void)hipStreamSynchronize(ctx->dev->d.rb.stream); // (uploads into the image pool)
+    // (uploads into the image pool: their own stream.  The copy stream's band expansions read this context's planes, but the
+    // context's stream - synchronised next - was made to follow the last of them, complete_grid; the host-bound copies read the
+    // handle's staging sets and need not hold a context's destruction up)
+    if (ctx->dev->d.up.stream) (void)hipStreamSynchronize(ctx->dev->d.up.stream);
     (void)hipStreamSynchronize(ctx->dev->d.stream);
     for (hipEvent_t &ev : ctx->level_read)
         if (ev) (void)hipEventDestroy(ev);

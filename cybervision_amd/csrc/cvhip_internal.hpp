@@ -237,6 +237,8 @@ struct Device {
     // copied into the ring on the calling thread(s), the H2D transfer runs on the copy stream (rb.stream) under whatever
     // the main stream is doing, and the call returns without synchronising - the caller's buffer is free on return.
     struct UploadRing {
+        hipStream_t stream = nullptr; // uploads have a stream of their own (H2D and D2H are separate DMA engines): the next pair's
+                                      // level images do not queue behind the last pair's readback
         uint8_t *base = nullptr;
         size_t cap = 0, head = 0;
         struct Chunk {
