@@ -298,8 +298,10 @@ int cvhip_ctx_get_counters(cvhip_ctx *ctx, uint64_t out[4], int reset);
  * every other geometry and as the per-workgroup fallback; 4 = 3 with the box kernel launched for every geometry
  * (testing); 5 = 3 with the rectified affine launches (exactly axis-parallel row-major lines, five stripes) as int8
  * matrix products on the matrix pipe (search4_mfma_kernel: the formulation the north star names; bit-exact, and
- * measured SLOWER than the box sums on MI355X - DESIGN.md section 4.7 - so it is not the default).  All give
- * identical results. */
+ * measured SLOWER than the box sums on MI355X - DESIGN.md section 4.7 - so it is not the default); 6 = 3 with the
+ * rectified affine launches on TWO image columns per lane (search3_box2_kernel: one prefix sum and two permutes for two
+ * pixels; bit-exact, 0.7-0.77 of the one-column group per pixel in isolation and SLOWER as a kernel - its 116-pixel waves walk
+ * longer unions of displacement ranges - DESIGN.md section 4.2).  All give identical results. */
 int cvhip_ctx_set_search_version(cvhip_ctx *ctx, int version);
 /* Which passes write the reference's SCORES.  Match positions are the reference's in every pass, always.  Scores are
  * only observable for the forward grid of the last (full-resolution) level: the reference overwrites every cell a
