@@ -210,35 +210,35 @@ struct StatsJob { // one image's statistics pass
     uint2 *istats;
 };
 
-// sd += (f_k - avg)^2, k = 0..10, on an already converted row (same operations as row_sq_acc)
-__device__ __forceinline__ float row_sq_acc_f(float sd, const float (&f)[KERNEL_WIDTH], float avg)
+// Two pixels' chains at once: sd.x += (g_k.x - avg.x)^2 and sd.y += (g_k.y - avg.y)^2, k = 0..10 - each half is the serial
+// chain of row_sq_acc on its own pixel (v_pk_add_f32 / v_pk_mul_f32 round each half like the scalar instructions), three
+// instructions per two squared deviations instead of four.
+__device__ __forceinline__ v2f row_sq_acc2(v2f sd, const v2f (&g)[KERNEL_WIDTH], v2f avg)
 {
-    const v2f a1 = {avg, avg};
 #pragma unroll
-    for (int c = 0; c < KERNEL_WIDTH - 1; c += 2) {
-        const v2f fa = {f[c], f[c + 1]};
-        const v2f d = fa - a1;
-        const v2f pr = d * d;
-        sd += pr.x;
-        sd += pr.y;
+    for (int c = 0; c < KERNEL_WIDTH; c++) {
+        const v2f d = g[c] - avg;
+        sd += d * d;
     }
-    const float d1 = f[KERNEL_WIDTH - 1] - avg;
-    return sd + d1 * d1;
+    return sd;
 }
 
 // Both images of a level in one launch (blockIdx.z picks the image; the grid covers the larger one).  zero_words:
 // eight u32 cleared by the first thread - the work-list counts of the level's two search passes, which start
 // after this kernel on the same stream.
-constexpr int WS_ROWS = 8; // pixel rows per workgroup: every lane owns two vertically adjacent pixels
+constexpr int WS_PX = 4;                     // vertically adjacent pixels per lane
+constexpr int WS_ROWS = 4 * WS_PX;           // pixel rows per workgroup
+constexpr int WS_LROWS = KERNEL_WIDTH + WS_PX - 1; // image rows one lane's four windows cover
 __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob jb, float min_stdev,
                                                             uint32_t *__restrict__ zero_words)
 {
-    // The 64x8 tile's 74x18 source bytes are staged once in LDS (one dword load per thread instead of 33
+    // The 64x16 tile's 74x26 source bytes are staged once in LDS (one dword load per thread instead of 33
     // unaligned loads per pixel, which made the kernel address-unit-bound); each lane then reads its 12
-    // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.  A lane's two pixels
-    // (x, y) and (x, y + 1) share 10 of their 11 window rows: the 12 rows are extracted, summed and converted to
-    // f32 once, and each pixel runs its own serial chain over its 11 of them - the per-pixel operation order of
-    // mod.rs:727-733 is untouched.
+    // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.  A lane's four pixels
+    // (x, y) .. (x, y + 3) cover 14 image rows R0 .. R13, extracted and summed once.  The serial chains of mod.rs:727-733
+    // run two pixels to a packed instruction: pixel q's window row j is image row j + q, so the pair of rows
+    // {R_r, R_r+2}, converted into the two halves of 11 register pairs, feeds step (r, .) of pixels 0 and 2 and step
+    // (r - 1, .) of pixels 1 and 3 - the per-pixel operation order is untouched.
     __shared__ uint32_t tile[(WS_ROWS + KERNEL_WIDTH - 1) * (WS_PITCH / 4)];
     if (zero_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) zero_words[threadIdx.x] = 0u;
     const StatsJob &job = blockIdx.z == 0 ? ja : jb;
@@ -259,22 +259,27 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t x = x0 + lane, ya = y0 + 2 * wv, yb = ya + 1;
-    if (x >= w || ya >= row1) return;
+    const uint32_t x = x0 + lane, yq = y0 + WS_PX * wv;
+    if (x >= w || yq >= row1) return;
     const float nan = __builtin_nanf("");
-    float2 out_a = make_float2(nan, nan), out_b = out_a;
-    uint2 iout_a = make_uint2(0u, __float_as_uint(nan)), iout_b = iout_a; // outside the border: not VALID, stdev NaN
+    uint2 iout[WS_PX];
+    bool in[WS_PX];
+    bool any_in = false;
     const bool col_in = x >= KERNEL_SIZE && x + KERNEL_SIZE < w;
-    const bool in_a = col_in && ya >= KERNEL_SIZE && ya + KERNEL_SIZE < h;
-    const bool in_b = col_in && yb >= KERNEL_SIZE && yb + KERNEL_SIZE < h && yb < row1;
-    if (in_a || in_b) {
+#pragma unroll
+    for (int q = 0; q < WS_PX; q++) {
+        iout[q] = make_uint2(0u, __float_as_uint(nan)); // outside the border: not VALID, stdev NaN
+        in[q] = col_in && yq + q >= KERNEL_SIZE && yq + q + KERNEL_SIZE < h && yq + q < row1;
+        any_in = any_in || in[q];
+    }
+    if (any_in) {
         const uint32_t off = lane + 3u; // window starts at byte (x - 5) - (x0 - 8) of the staged row
         const uint32_t d0 = off >> 2, sh = off & 3u;
-        Row12 rows[KERNEL_WIDTH + 1];
-        uint32_t rs[KERNEL_WIDTH + 1];
+        Row12 rows[WS_LROWS];
+        uint32_t rs[WS_LROWS];
 #pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH + 1; r++) {
-            const uint32_t *src = &tile[(2 * wv + r) * (WS_PITCH / 4) + d0];
+        for (int r = 0; r < WS_LROWS; r++) {
+            const uint32_t *src = &tile[(WS_PX * wv + r) * (WS_PITCH / 4) + d0];
             const uint32_t q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
             rows[r].a = __builtin_amdgcn_alignbyte(q1, q0, sh);
             rows[r].b = __builtin_amdgcn_alignbyte(q2, q1, sh);
@@ -283,35 +288,40 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
             t = __builtin_amdgcn_udot4(rows[r].b, 0x01010101u, t, false);
             rs[r] = __builtin_amdgcn_udot4(rows[r].c, 0x00010101u, t, false);
         }
-        uint32_t isum_a = 0;
+        uint32_t isum[WS_PX];
+        isum[0] = 0;
 #pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH; r++) isum_a += rs[r];
-        const uint32_t isum_b = isum_a - rs[0] + rs[KERNEL_WIDTH];
-        const float avg_a = (float)isum_a / (float)KERNEL_POINT_COUNT, avg_b = (float)isum_b / (float)KERNEL_POINT_COUNT;
-        float sd_a = 0.0f, sd_b = 0.0f;
+        for (int r = 0; r < KERNEL_WIDTH; r++) isum[0] += rs[r];
+#pragma unroll
+        for (int q = 1; q < WS_PX; q++) isum[q] = isum[q - 1] - rs[q - 1] + rs[q - 1 + KERNEL_WIDTH];
+        float avg[WS_PX];
+#pragma unroll
+        for (int q = 0; q < WS_PX; q++) avg[q] = (float)isum[q] / (float)KERNEL_POINT_COUNT;
+        const v2f avg02 = {avg[0], avg[2]}, avg13 = {avg[1], avg[3]};
+        v2f sd02 = {0.0f, 0.0f}, sd13 = {0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < KERNEL_WIDTH + 1; r++) {
-            // one row at a time: without this the compiler converts all 12 rows up front (132 live floats)
-            asm volatile("" : "+v"(rows[r].a), "+v"(rows[r].b), "+v"(rows[r].c), "+v"(sd_a), "+v"(sd_b));
-            float f[KERNEL_WIDTH];
+            // one pair of rows at a time: without this the compiler converts all rows up front
+            asm volatile("" : "+v"(rows[r].a), "+v"(rows[r].b), "+v"(rows[r].c), "+v"(sd02), "+v"(sd13));
+            v2f g[KERNEL_WIDTH];
 #pragma unroll
-            for (int c = 0; c < KERNEL_WIDTH; c++) f[c] = byte_f32(row12_word(rows[r], c), c & 3);
-            if (r < KERNEL_WIDTH) sd_a = row_sq_acc_f(sd_a, f, avg_a);
-            if (r >= 1) sd_b = row_sq_acc_f(sd_b, f, avg_b);
+            for (int c = 0; c < KERNEL_WIDTH; c++)
+                g[c] = v2f{byte_f32(row12_word(rows[r], c), c & 3), byte_f32(row12_word(rows[r + 2], c), c & 3)};
+            if (r < KERNEL_WIDTH) sd02 = row_sq_acc2(sd02, g, avg02);
+            if (r >= 1) sd13 = row_sq_acc2(sd13, g, avg13);
         }
-        if (in_a) {
-            out_a = make_float2(avg_a, sqrtf(sd_a / (float)KERNEL_POINT_COUNT));
-            const bool valid = finite_f32(out_a.y) && !(fabsf(out_a.y) < min_stdev);
-            iout_a = make_uint2(isum_a | (valid ? 0x80000000u : 0u), __float_as_uint(out_a.y));
-        }
-        if (in_b) {
-            out_b = make_float2(avg_b, sqrtf(sd_b / (float)KERNEL_POINT_COUNT));
-            const bool valid = finite_f32(out_b.y) && !(fabsf(out_b.y) < min_stdev);
-            iout_b = make_uint2(isum_b | (valid ? 0x80000000u : 0u), __float_as_uint(out_b.y));
+        const float sd[WS_PX] = {sd02.x, sd13.x, sd02.y, sd13.y};
+#pragma unroll
+        for (int q = 0; q < WS_PX; q++) {
+            if (!in[q]) continue;
+            const float stdev = sqrtf(sd[q] / (float)KERNEL_POINT_COUNT);
+            const bool valid = finite_f32(stdev) && !(fabsf(stdev) < min_stdev);
+            iout[q] = make_uint2(isum[q] | (valid ? 0x80000000u : 0u), __float_as_uint(stdev));
         }
     }
-    istats[(size_t)ya * w + x] = iout_a;
-    if (yb < row1) istats[(size_t)yb * w + x] = iout_b;
+#pragma unroll
+    for (int q = 0; q < WS_PX; q++)
+        if (yq + q < row1) istats[(size_t)(yq + q) * w + x] = iout[q];
 }
 
 void launch_window_stats_pair(const uint8_t *img_a, uint32_t wa, uint32_t ha, uint2 *istats_a,
@@ -511,23 +521,33 @@ __device__ __forceinline__ void search_range_body(const CorrParams &p, const uin
             }
         }
         __syncthreads();
-        for (uint32_t u = threadIdx.x; u < (uint32_t)(SRF_H * 64); u += 256) {
-            const uint32_t r = u >> 6, c = u & 63u;
-            uint32_t sa = 0u, sb = 0u;
+        {
+            // rows first: column t of FA (waves 0 and 1) or of FB (waves 2 and 3), its four 10-row sums by sliding - 15
+            // additions for the column - then 10 taps along the row per block (integer sums: any order)
+            const uint32_t wv = threadIdx.x >> 6, col = (wv & 1u) * 64u + (threadIdx.x & 63u);
+            if (col < (uint32_t)SRF_W) {
+                const uint32_t *src = (wv & 2u) ? FB : FA;
+                uint32_t *dst = (wv & 2u) ? HB : HA;
+                uint32_t v[SRF_H];
 #pragma unroll
-            for (int j = 0; j < SRF_TAPS; j++) {
-                sa += FA[r * SRF_PITCH + c + j];
-                sb += FB[r * SRF_PITCH + c + j];
+                for (int r = 0; r < SRF_H; r++) v[r] = src[r * SRF_PITCH + col];
+                uint32_t sum = 0u;
+#pragma unroll
+                for (int r = 0; r < SRF_TAPS; r++) sum += v[r];
+                dst[col] = sum;
+#pragma unroll
+                for (int r = 1; r < SRF_H - SRF_TAPS + 1; r++) {
+                    sum += v[r + SRF_TAPS - 1] - v[r - 1];
+                    dst[r * SRF_PITCH + col] = sum;
+                }
             }
-            HA[u] = sa;
-            HB[u] = sb;
         }
         __syncthreads();
         const uint32_t r0 = threadIdx.x >> 6, c = threadIdx.x & 63u;
 #pragma unroll
         for (int j = 0; j < SRF_TAPS; j++) {
-            win_a += HA[(r0 + j) * 64 + c];
-            win_b += HB[(r0 + j) * 64 + c];
+            win_a += HA[r0 * SRF_PITCH + c + j];
+            win_b += HB[r0 * SRF_PITCH + c + j];
         }
     } else {
         // window of the whole tile = union of its corner pixels' windows (the bounds are monotone in x, y)
@@ -649,16 +669,26 @@ __device__ __forceinline__ void search_range_body(const CorrParams &p, const uin
             if (force_chain || !(L < 4.0e9) || fabs(fr - 0.5) <= (L + 1.0) * 0x1p-45) {
                 // open: the reference's chain (mod.rs:523-529) over this block's window in its row-major order, from
                 // the staged tile (FA is 0 for None)
-                const uint32_t r0 = threadIdx.x >> 6, c0 = threadIdx.x & 63u;
+                // ... unless the mean is exact (n times it gives the integer sum back: a dyadic rational with at most 6
+                // fractional bits, n <= 100).  Then every deviation (< 2^14, 6 fractional bits), its square (40 bits) and
+                // every partial sum (< 2^35 in units of 2^-12) is exact, and the chain's sum IS 4^up T / n, itself such a
+                // number, so this quotient is exact too.  (The usual open window - half of the cells at v, half at v + 1,
+                // L = 3.5 exactly - is of this kind; a wave with one such lane used to walk all 100 cells for it.)
+                const double nd = (double)n;
                 double range_stdev = 0.0;
-                for (uint32_t r = 0; r < (uint32_t)SRF_TAPS; r++) {
-                    const uint32_t *row = &FA[(r0 + r) * SRF_PITCH + c0];
+                if (!force_chain && __builtin_fma(mid_corridor, nd, -(double)((unsigned long long)sv << up)) == 0.0) {
+                    range_stdev = (double)(T << (2u * up)) / nd;
+                } else {
+                    const uint32_t r0 = threadIdx.x >> 6, c0 = threadIdx.x & 63u;
+                    for (uint32_t r = 0; r < (uint32_t)SRF_TAPS; r++) {
+                        const uint32_t *row = &FA[(r0 + r) * SRF_PITCH + c0];
 #pragma unroll
-                    for (int j = 0; j < SRF_TAPS; j++) {
-                        const uint32_t w = row[j];
-                        const double delta = (double)((w & 0x3FFFFFu) << up) - mid_corridor;
-                        const double next = range_stdev + delta * delta;
-                        range_stdev = w != 0u ? next : range_stdev;
+                        for (int j = 0; j < SRF_TAPS; j++) {
+                            const uint32_t w = row[j];
+                            const double delta = (double)((w & 0x3FFFFFu) << up) - mid_corridor;
+                            const double next = range_stdev + delta * delta;
+                            range_stdev = w != 0u ? next : range_stdev;
+                        }
                     }
                 }
                 range_stdev = sqrt(range_stdev / (double)n);
@@ -2848,7 +2878,7 @@ size_t search2_split_words(uint32_t w, uint32_t rows, uint32_t stripes)
     return tiles * stripes * 256u * 4u; // one 32-byte record per (tile, stripe, thread)
 }
 
-void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s)
+void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s, bool light)
 {
     uint32_t lds = 0;
     bool any = false;
@@ -2862,7 +2892,10 @@ void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipS
     if (!any) return;
     // (the small levels' lists cannot hold as many tiles as the persistent grid has workgroups: 64^2 .. 256^2 then pay
     // for the dispatch of 2 x 34 .. 325 workgroups instead of 2 x 768)
-    const dim3 grid((unsigned)std::min<size_t>(LIST_GRID, entries), 1, (unsigned)n);
+    // light: behind the box walk of a rectified pair, whose lists hold the border tiles at most - an empty list costs the
+    // dispatch of the grid, 4.5 us for 2 x 34 workgroups and 11.5 us for 2 x 768; the workgroups loop over the lists
+    const size_t want = light ? LIST_GRID / 6 : (n == 2 ? LIST_GRID / 2 : LIST_GRID);
+    const dim3 grid((unsigned)std::min<size_t>(want, entries), 1, (unsigned)n);
     if (jobs[0].counters)
         hipLaunchKernelGGL(search3_fallback_kernel<true>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
     else

@@ -342,6 +342,10 @@ static int stage_images(cvhip_ctx *c, int k, const uint8_t *img1, size_t n1, con
 static int mark_level_read(cvhip_ctx *c, int k, hipStream_t s)
 {
     if (k < 0 || k >= 16) return CVHIP_OK;
+    // (both images borrowed from the caller: the level's area of the pool has no readers, and the event's barrier packet
+    // would hold the stream for ~6 us between the search and the filter of every level)
+    const size_t off = img_level_offset(c->max_px, k);
+    if (c->cur_img[0] != c->img[0] + off && c->cur_img[1] != c->img[1] + off) return CVHIP_OK;
     if (!c->level_read[k]) CVHIP_TRY_HIP(hipEventCreateWithFlags(&c->level_read[k], hipEventDisableTiming));
     CVHIP_TRY_HIP(hipEventRecord(c->level_read[k], s));
     return CVHIP_OK;
@@ -570,7 +574,7 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
                     launch_search3_box(jobs, m, pl.stepped, pl.transposed, pl.mfma ? 1 : (pl.pair ? 2 : 0), s, side, d.box_ev[0], d.box_ev[1]);
                 }, s));
-                CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s); }, s));
+                CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s, !pl.stepped && !pl.transposed); }, s));
             } else {
                 // candidate filter over every tile; the (rare) tiles with whole-corridor pixels queue themselves for
                 // the fallback kernel, whose declined list stays empty here
@@ -1017,7 +1021,7 @@ int level_begin(cvhip_ctx *ctx, const uint8_t *img1, uint32_t w1, uint32_t h1, c
         // coarse levels starved their small kernels - a 30 us box launch took the 370 us of the statistics kernel,
         // stream priorities notwithstanding; at four per CU the chain still lost 0.17 ms; at two the statistics of the
         // full-resolution level are not done when that level's turn comes: step 5.60 / 5.45 / 5.37 / 5.47 ms for
-        // 0 / 32 / 48 / 64 KB)
+        // 0 / 32 / 48 / 64 KB in round 4; 4.93 / 4.86 / 4.86 / 4.84 ms for 24 / 32 / 40 / 48 KB with the four-pixel kernel)
         launch_window_stats_pair(ctx->cur_img[0], w1, h1, st0, ctx->cur_img[1], w2, h2, st1, sr0, sr1, ctx->min_stdev, nullptr, side,
                                  48u * 1024u);
         CVHIP_TRY_HIP(hipEventRecord(d.sa.done[k], side));

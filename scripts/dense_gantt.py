@@ -10,7 +10,7 @@ for f in glob.glob(f"{sys.argv[1]}/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-firsts = [i for i, r in enumerate(rows) if "search2_filter_kernel" in r["Kernel_Name"]]
+firsts = [i for i, r in enumerate(rows) if "search2_filter_split_kernel<false, 1>" in r["Kernel_Name"]]
 i0, i1 = firsts[n] - 1, firsts[n + 1] - 1
 t0 = int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i1]:
