@@ -216,8 +216,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096, help="image side (default: BASELINE's 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simulate-shard", default="", help="num/den: time one rank's share of a den-GPU band-mode run on 1 GPU")

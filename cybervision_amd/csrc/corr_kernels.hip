@@ -226,19 +226,20 @@ __device__ __forceinline__ v2f row_sq_acc2(v2f sd, const v2f (&g)[KERNEL_WIDTH],
 // Both images of a level in one launch (blockIdx.z picks the image; the grid covers the larger one).  zero_words:
 // eight u32 cleared by the first thread - the work-list counts of the level's two search passes, which start
 // after this kernel on the same stream.
-constexpr int WS_PX = 4;                     // vertically adjacent pixels per lane
+constexpr int WS_PX = 8;                     // vertically adjacent pixels per lane
+constexpr int WS_HALF = WS_PX / 2;           // pixel q shares its packed chain with pixel q + WS_HALF
 constexpr int WS_ROWS = 4 * WS_PX;           // pixel rows per workgroup
-constexpr int WS_LROWS = KERNEL_WIDTH + WS_PX - 1; // image rows one lane's four windows cover
+constexpr int WS_LROWS = KERNEL_WIDTH + WS_PX - 1; // image rows one lane's windows cover
 __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob jb, float min_stdev,
                                                             uint32_t *__restrict__ zero_words)
 {
-    // The 64x16 tile's 74x26 source bytes are staged once in LDS (one dword load per thread instead of 33
+    // The 64x32 tile's 74x42 source bytes are staged once in LDS (one dword load per thread instead of 33
     // unaligned loads per pixel, which made the kernel address-unit-bound); each lane then reads its 12
-    // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.  A lane's four pixels
-    // (x, y) .. (x, y + 3) cover 14 image rows R0 .. R13, extracted and summed once.  The serial chains of mod.rs:727-733
+    // bytes per window row as four aligned LDS dwords and funnel-shifts them into place.  A lane's eight pixels
+    // (x, y) .. (x, y + 7) cover 18 image rows R0 .. R17, extracted and summed once.  The serial chains of mod.rs:727-733
     // run two pixels to a packed instruction: pixel q's window row j is image row j + q, so the pair of rows
-    // {R_r, R_r+2}, converted into the two halves of 11 register pairs, feeds step (r, .) of pixels 0 and 2 and step
-    // (r - 1, .) of pixels 1 and 3 - the per-pixel operation order is untouched.
+    // {R_r, R_r+4}, converted into the two halves of 11 register pairs, feeds step (r - q, .) of pixels q and q + 4 for
+    // q = 0 .. 3 - every row is converted twice for eight pixels, and the per-pixel operation order is untouched.
     __shared__ uint32_t tile[(WS_ROWS + KERNEL_WIDTH - 1) * (WS_PITCH / 4)];
     if (zero_words && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) zero_words[threadIdx.x] = 0u;
     const StatsJob &job = blockIdx.z == 0 ? ja : jb;
@@ -294,27 +295,31 @@ __global__ __launch_bounds__(256) void window_stats_kernel(StatsJob ja, StatsJob
         for (int r = 0; r < KERNEL_WIDTH; r++) isum[0] += rs[r];
 #pragma unroll
         for (int q = 1; q < WS_PX; q++) isum[q] = isum[q - 1] - rs[q - 1] + rs[q - 1 + KERNEL_WIDTH];
-        float avg[WS_PX];
+        v2f avg2[WS_HALF], sd2[WS_HALF];
 #pragma unroll
-        for (int q = 0; q < WS_PX; q++) avg[q] = (float)isum[q] / (float)KERNEL_POINT_COUNT;
-        const v2f avg02 = {avg[0], avg[2]}, avg13 = {avg[1], avg[3]};
-        v2f sd02 = {0.0f, 0.0f}, sd13 = {0.0f, 0.0f};
+        for (int q = 0; q < WS_HALF; q++) {
+            avg2[q] = v2f{(float)isum[q] / (float)KERNEL_POINT_COUNT, (float)isum[q + WS_HALF] / (float)KERNEL_POINT_COUNT};
+            sd2[q] = v2f{0.0f, 0.0f};
+        }
 #pragma unroll
-        for (int r = 0; r < KERNEL_WIDTH + 1; r++) {
+        for (int r = 0; r < KERNEL_WIDTH + WS_HALF - 1; r++) {
             // one pair of rows at a time: without this the compiler converts all rows up front
-            asm volatile("" : "+v"(rows[r].a), "+v"(rows[r].b), "+v"(rows[r].c), "+v"(sd02), "+v"(sd13));
+            asm volatile("" : "+v"(rows[r].a), "+v"(rows[r].b), "+v"(rows[r].c));
+#pragma unroll
+            for (int q = 0; q < WS_HALF; q++) asm volatile("" : "+v"(sd2[q]));
             v2f g[KERNEL_WIDTH];
 #pragma unroll
             for (int c = 0; c < KERNEL_WIDTH; c++)
-                g[c] = v2f{byte_f32(row12_word(rows[r], c), c & 3), byte_f32(row12_word(rows[r + 2], c), c & 3)};
-            if (r < KERNEL_WIDTH) sd02 = row_sq_acc2(sd02, g, avg02);
-            if (r >= 1) sd13 = row_sq_acc2(sd13, g, avg13);
+                g[c] = v2f{byte_f32(row12_word(rows[r], c), c & 3), byte_f32(row12_word(rows[r + WS_HALF], c), c & 3)};
+#pragma unroll
+            for (int q = 0; q < WS_HALF; q++)
+                if (r >= q && r < q + KERNEL_WIDTH) sd2[q] = row_sq_acc2(sd2[q], g, avg2[q]);
         }
-        const float sd[WS_PX] = {sd02.x, sd13.x, sd02.y, sd13.y};
 #pragma unroll
         for (int q = 0; q < WS_PX; q++) {
             if (!in[q]) continue;
-            const float stdev = sqrtf(sd[q] / (float)KERNEL_POINT_COUNT);
+            const float sd = q < WS_HALF ? sd2[q % WS_HALF].x : sd2[q % WS_HALF].y;
+            const float stdev = sqrtf(sd / (float)KERNEL_POINT_COUNT);
             const bool valid = finite_f32(stdev) && !(fabsf(stdev) < min_stdev);
             iout[q] = make_uint2(isum[q] | (valid ? 0x80000000u : 0u), __float_as_uint(stdev));
         }
