@@ -2907,9 +2907,14 @@ void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipS
         hipLaunchKernelGGL(search3_fallback_kernel<false>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
 }
 
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, int form, hipStream_t s,
-                        hipStream_t side, hipEvent_t fork, hipEvent_t join)
+// fallback_skip_exact >= 0: where the two directions go out on two streams (the stepped instantiations with a side
+// stream), each direction's fallback kernel is launched here too, behind its own box kernel - the first direction's few,
+// slow tiles (a declined tile takes ~0.1 ms of one workgroup) then run under the second direction's box walk instead of
+// after it.  Returns whether the fallback kernels went out (else the caller launches them).
+bool launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, int form, hipStream_t s,
+                        hipStream_t side, hipEvent_t fork, hipEvent_t join, int fallback_skip_exact)
 {
+    bool fallbacks_out = false;
     // form (rectified affine pairs only - lines that never step, row-major): 0 = the box walk, one column per lane; 1 = the
     // filter on the matrix pipe (search version 5); 2 = the box walk with two columns per lane (search3_box2_kernel)
     const bool mfma = form == 1;
@@ -2921,13 +2926,13 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
             gx = std::max(gx, (p.w1 + P2_OUT - 1) / P2_OUT);
             gy = std::max(gy, (p.row1 - p.row0 + 3) / 4);
         }
-        if (!gx || !gy) return;
+        if (!gx || !gy) return false;
         const dim3 grid(gx, gy, (unsigned)n);
         if (jobs[0].counters)
             hipLaunchKernelGGL(search3_box2_kernel<true>, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]);
         else
             hipLaunchKernelGGL(search3_box2_kernel<false>, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]);
-        return;
+        return false;
     }
     // rectified affine pairs under search version 5: the filter on the matrix pipe (search4_mfma_kernel); a pass that counts
     // candidates (profiling) takes the box kernel - the matrix-pipe walk does not know, value by value, which pixel ends up
@@ -2940,10 +2945,10 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
             gx = std::max(gx, (p.w1 + S4_TW - 1) / S4_TW);
             gy = std::max(gy, (p.row1 - p.row0 + S4_TH - 1) / S4_TH);
         }
-        if (!gx || !gy) return;
+        if (!gx || !gy) return false;
         const dim3 grid(gx, gy, (unsigned)n);
         hipLaunchKernelGGL(search4_mfma_kernel<false>, grid, dim3(256), 0, s, jobs[0], jobs[n - 1]);
-        return;
+        return false;
     }
     // lanes along x, 4 rows per workgroup - or, transposed, lanes along y and 4 columns per workgroup
     uint32_t gx = 0, gy = 0;
@@ -2953,7 +2958,7 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
         gx = std::max(gx, transposed ? (p.row1 - p.row0 + S3_OUT - 1) / S3_OUT : (p.w1 + S3_OUT - 1) / S3_OUT);
         gy = std::max(gy, transposed ? (p.w1 + 3) / 4 : (p.row1 - p.row0 + 3) / 4);
     }
-    if (!gx || !gy) return;
+    if (!gx || !gy) return false;
     const dim3 grid(gx, gy, (unsigned)n);
     size_t lean_pad = 0;
 #ifdef CVHIP_ABLATIONS
@@ -2965,13 +2970,18 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
         const bool forked = side && fork && join && n == 2 && job_active(jobs[0]) && job_active(jobs[1]) &&
                             hipEventRecord(fork, s) == hipSuccess && hipStreamWaitEvent(side, fork, 0) == hipSuccess;
         for (int i = 0; i < n; i++)
-            if (job_active(jobs[i]))
+            if (job_active(jobs[i])) {
                 hipLaunchKernelGGL(kernel, dim3(gx, gy, 1), dim3(256),
                                    search3_step_lds_bytes(jobs[i].p.box_pd, jobs[i].p.box_sh, jobs[i].p.box_wide != 0),
                                    forked && i == 1 ? side : s, jobs[i].p,
                                    jobs[i].img1, jobs[i].img2, jobs[i].stats1, jobs[i].stats1, jobs[i].stats2,
                                    (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out, jobs[i].out_score, jobs[i].counters,
                                    jobs[i].declined, jobs[i].whole);
+                if (forked && fallback_skip_exact >= 0) {
+                    launch_search3_fallback(&jobs[i], 1, fallback_skip_exact != 0, i == 1 ? side : s, false);
+                    fallbacks_out = true;
+                }
+            }
         if (forked) { // (an error here surfaces at the caller's hipGetLastError / the next synchronisation)
             (void)hipEventRecord(join, side);
             (void)hipStreamWaitEvent(s, join, 0);
@@ -2989,6 +2999,7 @@ void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
     case 6: wide ? launch_each(search3_box_single_kernel<true, true, false, true>) : launch_each(search3_box_single_kernel<true, true, false, false>); break;
     default: wide ? launch_each(search3_box_single_kernel<true, true, true, true>) : launch_each(search3_box_single_kernel<true, true, true, false>); break;
     }
+    return fallbacks_out;
 }
 
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h)

@@ -571,10 +571,13 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
                         if (!ev) CVHIP_TRY_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
                     CVHIP_TRY_HIP(aux_stream(d, 1, &side));
                 }
+                bool fallbacks_out = false; // (on two streams each direction's fallback kernel follows its own box kernel)
                 CVHIP_TRY(timed(c, cvhip_ctx::K_SEARCH, [&] {
-                    launch_search3_box(jobs, m, pl.stepped, pl.transposed, pl.mfma ? 1 : (pl.pair ? 2 : 0), s, side, d.box_ev[0], d.box_ev[1]);
+                    fallbacks_out = launch_search3_box(jobs, m, pl.stepped, pl.transposed, pl.mfma ? 1 : (pl.pair ? 2 : 0), s, side, d.box_ev[0],
+                                                       d.box_ev[1], side ? ((p.debug & 1) ? 1 : 0) : -1);
                 }, s));
-                CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s, !pl.stepped && !pl.transposed); }, s));
+                if (!fallbacks_out)
+                    CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s, !pl.stepped && !pl.transposed); }, s));
             } else {
                 // candidate filter over every tile; the (rare) tiles with whole-corridor pixels queue themselves for
                 // the fallback kernel, whose declined list stays empty here

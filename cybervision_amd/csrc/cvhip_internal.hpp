@@ -119,8 +119,8 @@ void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s);
 void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s, bool light = false);
 // (side / fork / join: the stepped instantiations launch one kernel per direction - with a side stream the second one goes
 // there, between the two events, so that the first launch's tail is filled)
-void launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, int form, hipStream_t s,
-                        hipStream_t side = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
+bool launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, int form, hipStream_t s,
+                        hipStream_t side = nullptr, hipEvent_t fork = nullptr, hipEvent_t join = nullptr, int fallback_skip_exact = -1);
 size_t search3_worklist_capacity(uint32_t max_w, uint32_t max_h);
 void launch_cross_check(uint32_t *own, const uint32_t *other, uint32_t ow, uint32_t oh, uint32_t rw, uint32_t rh,
                         uint32_t row0, uint32_t row1, hipStream_t s);
@@ -253,6 +253,9 @@ struct Device {
     // rather than one per purpose: streams beyond the process' hardware queues are mapped onto queues already in use (in
     // round 3, with a stream of its own for the statistics, config 5's RANSAC stage ran 22 -> 27 ms in a process that had
     // used both; in round 4 four generator streams beat two with GPU_MAX_HW_QUEUES at its default of 4 as with 8)
+    // (the stepped box launches' second stream at the LOWEST priority - so that the first direction ends early and its fallback
+    // kernel runs under the second direction's walk - was tried in round 5: the dispatch order follows the priority, but the
+    // low-priority walk then starves beside the statistics stream: geometry sweep 6.5 .. 8.0 -> 8.2 .. 10.1 ms)
     hipStream_t aux[4] = {};
     hipEvent_t orb_ev[3] = {nullptr, nullptr, nullptr}; // cvhip_orb_extract_batch's fork / join events
     hipEvent_t box_ev[2] = {nullptr, nullptr};          // the stepped box launches' fork / join (launch_passes)
