@@ -2838,7 +2838,7 @@ static uint32_t search2_lds_bytes(const CorrParams &p)
     return shallow ? (uint32_t)S2_LDS_BYTES : (uint32_t)S2_LDS_BYTES_STEEP;
 }
 
-constexpr int LIST_GRID = 768; // persistent workgroups of the work-list kernels (an empty list costs their dispatch)
+constexpr int LIST_GRID = 512; // persistent workgroups of the work-list kernels, all jobs of a launch together
 
 // The candidate filter over every tile; tiles with whole-corridor pixels queue themselves on the job's whole list
 // for search3_fallback_kernel (launched behind it; its declined list stays empty).
@@ -2883,7 +2883,7 @@ size_t search2_split_words(uint32_t w, uint32_t rows, uint32_t stripes)
     return tiles * stripes * 256u * 4u; // one 32-byte record per (tile, stripe, thread)
 }
 
-void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s, bool light)
+void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s)
 {
     uint32_t lds = 0;
     bool any = false;
@@ -2895,11 +2895,11 @@ void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipS
         entries = std::max(entries, search3_worklist_capacity(jobs[i].p.w1, jobs[i].p.row1 - jobs[i].p.row0));
     }
     if (!any) return;
-    // (the small levels' lists cannot hold as many tiles as the persistent grid has workgroups: 64^2 .. 256^2 then pay
-    // for the dispatch of 2 x 34 .. 325 workgroups instead of 2 x 768)
-    // light: behind the box walk of a rectified pair, whose lists hold the border tiles at most - an empty list costs the
-    // dispatch of the grid, 4.5 us for 2 x 34 workgroups and 11.5 us for 2 x 768; the workgroups loop over the lists
-    const size_t want = light ? LIST_GRID / 6 : (n == 2 ? LIST_GRID / 2 : LIST_GRID);
+    // As many workgroups as the chip holds at once (two per CU: 40 - 64 KB of LDS each), over both jobs; they loop over the
+    // lists.  More only queue behind those - and an EMPTY list, the usual case behind the box walk of a rectified pair, costs
+    // the dispatch of the grid: 4.5 us for 2 x 34 workgroups, 6 us for 2 x 256, 11.5 us for the 2 x 768 of round 4, per level.
+    // (The small levels' lists cannot hold even that many tiles: 64^2 .. 256^2 launch 2 x 34 .. 2 x 325 at most.)
+    const size_t want = (size_t)LIST_GRID / (n == 2 ? 2 : 1);
     const dim3 grid((unsigned)std::min<size_t>(want, entries), 1, (unsigned)n);
     if (jobs[0].counters)
         hipLaunchKernelGGL(search3_fallback_kernel<true>, grid, dim3(256), lds, s, jobs[0], jobs[n - 1], skip_exact ? 1 : 0, lds);
@@ -2978,7 +2978,7 @@ bool launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool t
                                    (const uint32_t *)jobs[i].range, jobs[i].contenders, jobs[i].out, jobs[i].out_score, jobs[i].counters,
                                    jobs[i].declined, jobs[i].whole);
                 if (forked && fallback_skip_exact >= 0) {
-                    launch_search3_fallback(&jobs[i], 1, fallback_skip_exact != 0, i == 1 ? side : s, false);
+                    launch_search3_fallback(&jobs[i], 1, fallback_skip_exact != 0, i == 1 ? side : s);
                     fallbacks_out = true;
                 }
             }

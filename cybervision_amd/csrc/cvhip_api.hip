@@ -577,7 +577,7 @@ static int launch_passes(cvhip_ctx *c, PassPlan *plans, int n, bool zero_counts,
                                                        d.box_ev[1], side ? ((p.debug & 1) ? 1 : 0) : -1);
                 }, s));
                 if (!fallbacks_out)
-                    CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s, !pl.stepped && !pl.transposed); }, s));
+                    CVHIP_TRY(timed(c, cvhip_ctx::K_EXACT, [&] { launch_search3_fallback(jobs, m, (p.debug & 1) != 0, s); }, s));
             } else {
                 // candidate filter over every tile; the (rare) tiles with whole-corridor pixels queue themselves for
                 // the fallback kernel, whose declined list stays empty here

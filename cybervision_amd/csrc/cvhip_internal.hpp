@@ -116,7 +116,7 @@ void launch_search(const CorrParams &p, const uint8_t *img1, const uint8_t *img2
                    const uint2 *stats2, const uint32_t *range, uint32_t *out, float *out_score,
                    unsigned long long *cand_counter, hipStream_t s);
 void launch_search2_filter(const SearchJob *jobs, int n, hipStream_t s);
-void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s, bool light = false);
+void launch_search3_fallback(const SearchJob *jobs, int n, bool skip_exact, hipStream_t s);
 // (side / fork / join: the stepped instantiations launch one kernel per direction - with a side stream the second one goes
 // there, between the two events, so that the first launch's tail is filled)
 bool launch_search3_box(const SearchJob *jobs, int n, bool stepped_lines, bool transposed, int form, hipStream_t s,
