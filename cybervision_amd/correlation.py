@@ -54,6 +54,8 @@ class GpuDevice:
         if hardware_mode == HardwareMode.Cpu:
             raise ValueError("HardwareMode.Cpu has no GPU device (the CPU path is the reference's own)")
         self._h = C.c_void_p()
+        self.hardware_mode, self.ordinal = hardware_mode, ordinal
+        self._side_handles: list["GpuDevice"] = []  # further handles on the same GPU, each with a stream of its own (side_handle)
         low = int(hardware_mode == HardwareMode.GpuLowPower)
         if stream is None:
             rc = _lib.lib().cvhip_device_create(low, ordinal, C.byref(self._h))
@@ -71,7 +73,17 @@ class GpuDevice:
     def synchronize(self):
         _lib.check(_lib.lib().cvhip_device_synchronize(self._h), "cvhip_device_synchronize")
 
+    def side_handle(self, i: int) -> "GpuDevice":
+        """The i-th further device handle on this handle's GPU, with a private stream, created on first use and closed with
+        this one: independent jobs (the pairs of reconstruct_dense) run side by side on them."""
+        while len(self._side_handles) <= i:
+            self._side_handles.append(GpuDevice(self.hardware_mode, self.ordinal, None))
+        return self._side_handles[i]
+
     def close(self):
+        for d in getattr(self, "_side_handles", []):
+            d.close()
+        self._side_handles = []
         if getattr(self, "_h", None):
             _lib.lib().cvhip_device_destroy(self._h)
             self._h = None

@@ -97,6 +97,54 @@ class ImageReconstruction:
         return self._timed("dense", run)
 
 
+    def correlate_dense_set(self, jobs, borrow=False):
+        """jobs: [(pyr1, pyr2, f)] - the pairs of reconstruct_dense's loop (reconstruction.rs:680-730), each a correlate_dense of
+        its own -> [(xy, corr)].  The pairs are independent: with device-resident pyramids (borrow) every pair runs on a device
+        handle - a stream - of its own, so that one pair's coarse levels (chains of small dependent launches that leave the
+        chip idle) run under another pair's full-resolution levels.  Results are those of the calls one after the other."""
+        if not borrow or len(jobs) < 2:
+            return [self.correlate_dense(p1, p2, f, borrow=borrow) for p1, p2, f in jobs]
+        import torch
+
+        mode = correlation.ProjectionMode(int(self.projection_mode))
+        devs = [self.device] + [self.device.side_handle(i) for i in range(len(jobs) - 1)]
+
+        def dims(img):
+            return (int(img.shape[1]), int(img.shape[0]))
+
+        outs = []
+        for p1, _, _ in jobs:
+            w, h = dims(p1[0])
+            outs.append((torch.empty((h, w, 2), dtype=torch.int32, device=p1[0].device),
+                         torch.empty((h, w), dtype=torch.float32, device=p1[0].device)))
+        torch.cuda.synchronize(jobs[0][0][0].device)  # (the outputs exist before a private stream writes them)
+
+        def run():
+            pcs = []
+            try:
+                for dev, (p1, p2, f) in zip(devs, jobs):
+                    pc = correlation.PointCorrelations(dev, dims(p1[0]), dims(p2[0]), f, mode)
+                    pcs.append(pc)
+                    pc.set_borrow_inputs(True)
+                    pc.set_stats_ahead(dev is self.device)  # (one statistics side stream: every further stream of the process
+                    #                                          shares a hardware queue with one already in use)
+                res = []
+                for pc, (p1, p2, f), (oxy, ocorr) in zip(pcs, jobs, outs):
+                    steps = correlation.optimal_scale_steps(*dims(p1[0]))
+                    for i in range(steps + 1):
+                        k = steps - i
+                        pc.correlate_images(p1[k], p2[k], 1.0 / float(1 << k))
+                    res.append(pc.complete(out_xy=oxy, out_corr=ocorr))
+                for dev in devs:
+                    dev.synchronize()
+                return res
+            finally:
+                for pc in pcs:
+                    pc.close()
+
+        return self._timed("dense", run)
+
+
 def padded_pyramid(pyr):
     """Device copies of a pyramid's levels with 64 readable bytes behind each (what cvhip_ctx_set_borrow_inputs asks
     for); host pyramids are returned as they are.  -> (pyramid, borrowable)."""
@@ -130,11 +178,13 @@ class ProgressBar:
 
 
 def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = ProjectionMode.Perspective, seed: int = 0,
-                      dense: bool = True, borrow: bool = False, listener: bool = False, images=None):
+                      dense: bool = True, borrow: bool = False, listener: bool = False, images=None, concurrent_pairs: bool = True):
     """The two pair loops of `reconstruct` (reconstruction.rs:261-277 sparse, :680-730 dense) over n images:
     for every i < j the sparse stage (ORB on both, matcher, RANSAC); then, for every pair that produced an F, the
     dense correlation.  The reference re-extracts an image's keypoints for every pair it takes part in; the result
-    is a pure function of the image, so they are extracted once per image here.
+    is a pure function of the image, so they are extracted once per image here.  concurrent_pairs (device-resident pyramids):
+    the pairs' dense correlations - independent of each other - run side by side, each on a stream of its own
+    (ImageReconstruction.correlate_dense_set); False: one after the other, as the reference's loop does.
     -> dict: keypoints [n], pairs {(i, j): {matches, f, inliers, (xy, corr)}}, timings_ms per stage."""
     rec = ImageReconstruction(device, projection_mode)
     if images is not None:
@@ -160,7 +210,12 @@ def reconstruct_pairs(device, pyramids, projection_mode: ProjectionMode = Projec
             except Exception as exc:  # "Failed to match images" (reconstruction.rs:268-274): the pair is skipped
                 entry["error"] = str(exc)
             pairs[(i, j)] = entry
-    if dense:
+    if dense and borrow and images is None and concurrent_pairs:
+        todo = [(key, entry) for key, entry in pairs.items() if entry["f"] is not None]
+        results = rec.correlate_dense_set([(pyramids[i], pyramids[j], entry["f"]) for (i, j), entry in todo], borrow=True)
+        for (_, entry), (xy, corr) in zip(todo, results):
+            entry["xy"], entry["corr"] = xy, corr
+    elif dense:
         for (i, j), entry in pairs.items():
             if entry["f"] is None:
                 continue
