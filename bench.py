@@ -176,7 +176,9 @@ def measure_sfm3(size, steps, warmup, dev=None, pencil=0, listener=True, lanczos
     return {"pyramids": ("Lanczos3 on the device inside the step (cvhip_resize_lanczos3), rebuilt per stage as the reference does" if lanczos
                          else "2x2 box pyramids, prebuilt and resident: SourceImage::resize (reconstruction.rs:146-162) is EXCLUDED from the step"),
             "pencil": "thin_svd_rows_5_6 (reference)" if pencil == 0 else "null_space (textbook)",
-            "ransac_listener": "report_status + report_matches attached (reconstruction.rs:510-518)" if listener else "none", "size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
+            "ransac_listener": "report_status + report_matches attached (reconstruction.rs:510-518)" if listener else "none",
+            "dense_pairs": "the three pairs' correlations side by side, a device handle (stream) each (correlate_dense_set)" if images is None else "one after the other",
+            "size": size, "levels": lsteps + 1, "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 3), "stage_ms": stage_ms,
             "dense_mpixels_per_s": round(n_pairs * size * size / 1e6 / (stage_ms["dense"] / 1e3), 2),
             "whole_pipeline_mpixels_per_s": round(3 * size * size / 1e6 / (dt / steps), 2),
             "keypoints": [int(len(k[0])) for k in res["keypoints"]], "matches": matches, "ransac_inliers": inliers,

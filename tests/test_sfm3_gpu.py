@@ -113,7 +113,8 @@ def test_sfm3_full_size_properties_2048(gpu_device, oracle_fm):
     views, pyramids, K, poses = build_views(size)
     dev_pyr = [[torch.from_numpy(l).cuda() for l in p] for p in pyramids]
     # as bench.py runs config 5: levels padded and resident, used in place by the dense stage, statistics ahead - the second
-    # run of every pair below goes through the copying path, and the two must agree bit for bit
+    # the three pairs' dense correlations side by side, each on a device handle of its own (correlate_dense_set) - the second
+    # run of every pair below goes through the copying path, alone, and the two must agree bit for bit
     padded = [reconstruction.padded_pyramid(p)[0] for p in dev_pyr]
     res = reconstruction.reconstruct_pairs(gpu_device, padded, fundamentalmatrix.ProjectionMode.Perspective, seed=5, borrow=True)
     # determinism of the sparse front end: a second extraction of every view gives the same keypoints and descriptors
