@@ -1356,3 +1356,45 @@ def test_library_rccl_path_world2():
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {rank} ok" in out, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,tilt", [(8192, 8192, 0.0), (9001, 6003, 7.0)])
+def test_sizes_beyond_the_benchmark_equal_exact_kernel(gpu_device, w, h, tilt):
+    """Twice the benchmark's side (8 levels; the search range's integer sums at their stated limit of 8192) and a ragged
+    9001 x 6003 pair with tilted lines (no dimension a multiple of any tile): the default search against the plain exact
+    kernel, match grids and score bits of both directions, everything resident on the device."""
+    import torch
+
+    a, b, _ = synth.make_pair_torch(w, h, tilt_deg=tilt, device="cuda")
+    steps = synth.optimal_scale_steps(w, h)
+    d1, d2 = synth.box_pyramid_torch(a, steps), synth.box_pyramid_torch(b, steps)
+    F = synth.f_tilt(tilt) if tilt else synth.F_HORIZONTAL
+    torch.cuda.synchronize()  # (the device handle submits to a stream of its own)
+
+    def run(version):
+        pc = correlation.PointCorrelations(gpu_device, (w, h), (w, h), F, correlation.ProjectionMode.Affine)
+        try:
+            pc.set_exact_scores(True)
+            if version is not None:
+                pc.set_search_version(version)
+            for i in range(steps + 1):
+                k = steps - i
+                pc.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+            out = []
+            for d in (correlation.CorrelationDirection.Forward, correlation.CorrelationDirection.Reverse):
+                xy = torch.empty((h, w, 2), dtype=torch.int32, device="cuda")
+                corr = torch.empty((h, w), dtype=torch.float32, device="cuda")
+                pc.complete(d, out_xy=xy, out_corr=corr)
+                out.append((xy, corr))
+            gpu_device.synchronize()
+            return out
+        finally:
+            pc.close()
+
+    got, want = run(None), run(1)
+    for (xy, corr), (xy1, corr1) in zip(got, want):
+        valid = xy1[..., 0] >= 0
+        assert 0.8 < float(valid.float().mean()) < 0.95
+        assert torch.equal(xy, xy1)
+        assert torch.equal(corr.view(torch.int32)[valid], corr1.view(torch.int32)[valid])
