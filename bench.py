@@ -607,6 +607,51 @@ def main():
 
     pc.close()
     pc = None
+    pair_pipeline = None
+    if extras and hasattr(dev, "side_handle"):
+        # ---- pair after pair, as reconstruct_dense's loop issues them (reconstruction.rs:680-730), on TWO contexts used in turn, a
+        # device handle (stream) each: the tail of pair i - its last filter and the expansion of the grid, which cannot fill
+        # the chip - and the first, small levels of pair i + 1 run side by side.  Throughput of the sequence, not one pair's
+        # latency (that is the headline); same grids.
+        handles = [dev, dev.side_handle(0)]
+        ctxs, outs = [], []
+        for hnd in handles:
+            q = correlation.PointCorrelations(hnd, (W, H), (W, H), synth.F_HORIZONTAL, correlation.ProjectionMode.Affine)
+            q.set_borrow_inputs(True)
+            q.set_stats_ahead(hnd is dev)
+            ctxs.append(q)
+            outs.append((torch.empty((H, W, 2), dtype=torch.int32, device="cuda"), torch.empty((H, W), dtype=torch.float32, device="cuda")))
+        torch.cuda.synchronize()
+
+        def pair_on(n):
+            q, (oxy, oco) = ctxs[n & 1], outs[n & 1]
+            q.first_pass = True
+            for j in range(steps + 1):
+                k = steps - j
+                q.correlate_images(d1[k], d2[k], 1.0 / float(1 << k))
+            q.complete(out_xy=oxy, out_corr=oco)
+
+        def fence_both():
+            for hnd in handles:
+                hnd.synchronize()
+
+        for n in range(4):
+            pair_on(n)
+        fence_both()
+        n_pp = 20
+        t1 = time.perf_counter()
+        for n in range(n_pp):
+            pair_on(n)
+        fence_both()
+        pp_ms = (time.perf_counter() - t1) * 1e3 / n_pp
+        same_pp = bool(torch.equal(outs[0][0], out_xy) and torch.equal(outs[1][0], out_xy) and
+                       torch.equal(outs[1][1].view(torch.int32)[out_xy[..., 0] >= 0], out_corr.view(torch.int32)[out_xy[..., 0] >= 0]))
+        pair_pipeline = {"ms_per_pair": round(pp_ms, 4), "mpixels_per_s": round(W * H / 1e6 / (pp_ms / 1e3), 1), "pairs": n_pp,
+                         "results_equal_headline": same_pp,
+                         "note": "two contexts used in turn, a device handle (stream) each: pair i + 1's first levels under pair i's last filter and expansion"}
+        for q in ctxs:
+            q.close()
+        del ctxs, outs
     if extras:
         # ---- the same workload with the epipolar lines tilted: pairs displaced along the tilted direction
         # (synth.make_pair(tilt_deg=...)), F = synth.f_tilt(theta); everything else as in the headline step
@@ -807,6 +852,8 @@ def main():
             }
         if readback is not None:
             result["readback"] = readback
+        if pair_pipeline is not None:
+            result["pair_pipeline"] = pair_pipeline
         if geometry_sweep is not None:
             result["geometry_sweep"] = geometry_sweep
         if sfm3 is not None:
